@@ -1,0 +1,192 @@
+/* dhmc.h — C ABI of the MI355X many-chain NUTS hot path (libdhmc_amd.so).
+ *
+ * Drop-in boundary for the hot path of tpapp/DynamicHMC.jl v3.6.0 (paths below are relative
+ * to the reference checkout).  The reference runs ONE chain per call of `mcmc_with_warmup`
+ * and crosses no FFI; the natural cut for a device implementation is seam (iv) of SURVEY.md
+ * §8(b): `warmup(sampling_logdensity, stage, warmup_state)` (src/mcmc.jl:99,134,258) and the
+ * two per-draw loops (src/mcmc.jl:271-280 and :374-379).  One ABI call here does what one of
+ * those loops does, for all `chains` chains of the context at once; everything below the loop
+ * (sample_tree NUTS.jl:232, sample_trajectory trees.jl:283, adjacent_tree trees.jl:231,
+ * leapfrog hamiltonian.jl:273, logdensity hamiltonian.jl:251, kinetic_energy :103,
+ * combine_turn_statistics NUTS.jl:132, combine_proposals NUTS.jl:51, adapt_stepsize
+ * stepsize.jl:147) runs inside HIP kernels.
+ *
+ * Conventions
+ *  - All floating point is IEEE binary64, as in the reference (mcmc.jl:230,238; NUTS.jl:210).
+ *  - Arrays are chain-major and unpadded: a [C][N][D] array holds chain c, draw n at
+ *    offset (c*N + n)*D, i.e. Julia's column-major posterior_matrix[D,N] per chain
+ *    (mcmc.jl:230,275,376) with a leading chain dimension.
+ *  - Every buffer passed in is owned by the caller.  `*_on_device` says whether a pointer is a
+ *    device (HIP) pointer or a host pointer; host buffers are staged by the library.
+ *  - Every function returns a DHMC_* code; no C++ exception crosses the boundary.  Conditions
+ *    the reference signals with `throw` for ONE chain are recorded in that chain's status word
+ *    (dhmc_get_status) and the call returns DHMC_ERR_CHAIN_FAILURE; the host wrapper re-raises
+ *    them as DynamicHMCError (utilities.jl:17-27).  Argument violations that the reference
+ *    rejects with @argcheck return DHMC_ERR_INVALID_ARGUMENT.
+ *  - A context is confined to one host thread at a time; distinct contexts (one per GPU) may be
+ *    driven concurrently.  Calls are synchronous with respect to host output buffers.
+ *
+ * Random streams (the reference draws from a caller-supplied AbstractRNG in the order
+ * p -> directions -> tree draws, NUTS.jl:232-233; no test pins a stream).  The ABI fixes a
+ * counter-based stream so that results do not depend on how chains are scheduled or sharded:
+ *   Philox4x32-10, key = (seed[31:0], global chain index),
+ *   counter = (index, purpose, transition number of that chain, seed[63:32]).
+ *   purpose 0: momentum normals.  Call `index` = lane + 64*kk yields the N(0,1) pair for
+ *              coordinates e0 = (index%64) + 128*(index/64) and e1 = e0 + 64 by Box–Muller
+ *              (dhmc_detmath.h det_randn2, r1 = words[1]<<32|words[0], r2 = words[3]<<32|words[2]);
+ *              p = W .* z as rand_p (hamiltonian.jl:124).
+ *   purpose 1: directions = word 0 of call index 0 (trees.jl:23).
+ *   purpose 2: the k-th Exp(1) draw consumed by the transition (rand_bool_logprob,
+ *              NUTS.jl:43-45; only drawn when logprob < 0), det_randexp(r1) of call index k,
+ *              in the depth-first post-order of trees.jl:231-262.
+ *   purpose 3: momentum for the initial step size search (mcmc.jl:139), as purpose 0.
+ *   purpose 4: initial position U[-2,2)^D (mcmc.jl:108): call index j yields coordinates
+ *              e0,e1 as for purpose 0, q = u01_closed_open(r)*4 - 2.
+ * A Julia `TapeRNG <: AbstractRNG` that replays this stream makes the real reference
+ * reproduce these draws.
+ */
+#ifndef DHMC_H
+#define DHMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes -------------------------------------------------------------------- */
+#define DHMC_OK 0
+#define DHMC_ERR_INVALID_ARGUMENT 1 /* ArgumentError of @argcheck: NUTS.jl:190-191, stepsize.jl:31-33,108-111,135,148, mcmc.jl:191-192, hamiltonian.jl:63,146-147 */
+#define DHMC_ERR_HIP 2              /* a HIP runtime call failed; see dhmc_last_error */
+#define DHMC_ERR_UNSUPPORTED 3      /* valid request outside what this build implements */
+#define DHMC_ERR_CHAIN_FAILURE 4    /* >=1 chain hit a reference `throw` site; see dhmc_get_status */
+#define DHMC_ERR_NO_DEVICE 5        /* no HIP device / kernels unavailable: there is NO CPU fallback */
+
+/* ---- per-chain status bits (reference throw sites) ----------------------------------- */
+#define DHMC_ST_NONFINITE_POSITION 1u      /* hamiltonian.jl:203 "Position vector has non-finite elements." */
+#define DHMC_ST_INVALID_INITIAL 2u         /* hamiltonian.jl:212-216 strict evaluate_ℓ at the initial point */
+#define DHMC_ST_STEPSIZE_SEARCH_FAILED 4u  /* stepsize.jl:57-59 */
+#define DHMC_ST_NONFINITE_START_DENSITY 8u /* stepsize.jl:77-79 */
+
+/* ---- target family: the device-side stand-in for LogDensityProblems.logdensity_and_gradient
+ *      (hamiltonian.jl:204; capabilities/dimension checks hamiltonian.jl:146-147) ---------- */
+#define DHMC_TARGET_STD_NORMAL 0  /* l(q) = -1/2 sum q^2, grad = -q.            params: none */
+#define DHMC_TARGET_DIAG_NORMAL 1 /* l = -1/2 sum prec_i (q_i-mu_i)^2.          params: double mu[D], prec[D] */
+#define DHMC_TARGET_TRIDIAG_NORMAL 2 /* l = -1/2 q'Pq, P symmetric tridiagonal.  params: double diag[D], off[D] (off[D-1] ignored) */
+#define DHMC_TARGET_FUNNEL 3      /* Neal's funnel: v=q_0~N(0,3^2), q_i|v~N(0,e^v). params: none */
+#define DHMC_TARGET_LOGISTIC 4    /* Bernoulli-logit regression, N(0,I) prior.  params: int64 n; double X[n][D]; double y[n] */
+#define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
+
+/* ---- kinetic energy (GaussianKineticEnergy, hamiltonian.jl:56-87) -------------------- */
+#define DHMC_METRIC_DIAG 0  /* per-chain diagonal M^-1 [C][D]; the unit metric (hamiltonian.jl:87) is diag of ones */
+#define DHMC_METRIC_DENSE 1 /* one dense M^-1 [D][D] shared by all chains of the context */
+
+typedef struct dhmc_ctx dhmc_ctx;
+
+typedef struct dhmc_config {
+    int32_t device;        /* HIP device ordinal */
+    int32_t dim;           /* D = LogDensityProblems.dimension(l) */
+    int32_t chains;        /* C chains owned by this context */
+    int32_t chain_offset;  /* global index of chain 0 (RNG key); shards of one job use disjoint ranges */
+    int32_t metric;        /* DHMC_METRIC_* */
+    int32_t target;        /* DHMC_TARGET_* */
+    const void* target_params; /* host pointer, copied at create */
+    uint64_t target_params_bytes;
+    int32_t max_depth;     /* NUTS.max_depth, 0 < max_depth <= 32 (NUTS.jl:190); default 10 (:166) */
+    int32_t reserved;
+    double min_delta;      /* NUTS.min_Δ < 0 (NUTS.jl:191); default -1000 */
+    uint64_t seed;
+} dhmc_config;
+
+/* InitialStepsizeSearch (stepsize.jl:23-36) */
+typedef struct dhmc_stepsize_search {
+    double initial_eps;       /* > 0, default 0.1 */
+    double log_threshold;     /* finite, < 0, default log(0.8) */
+    int32_t maxiter_crossing; /* >= 50, default 400 */
+    int32_t reserved;
+} dhmc_stepsize_search;
+
+/* DualAveraging (stepsize.jl:98-118) plus how one call maps onto a TuningNUTS stage
+ * (mcmc.jl:266 initial_adaptation_state at stage start; :285 final_ϵ at stage end). */
+typedef struct dhmc_dual_averaging {
+    double delta;  /* 0 < δ < 1, default 0.8 */
+    double gamma;  /* γ > 0, default 0.05 */
+    double kappa;  /* 0.5 < κ <= 1, default 0.75 */
+    int32_t t0;    /* t₀ >= 0, default 10 */
+    int32_t init;     /* !=0: (re)initialise the adaptation state from the current ε before the first transition */
+    int32_t finalize; /* !=0: set ε := final_ϵ = exp(logϵ̄) after the last transition */
+    int32_t reserved;
+} dhmc_dual_averaging;
+
+/* Caller-owned result buffers of one dhmc_run call; any pointer may be NULL (not recorded).
+ * Fields mirror what the per-draw loops store (mcmc.jl:275-277,376-377) and
+ * TreeStatisticsNUTS (NUTS.jl:208-221). */
+typedef struct dhmc_outputs {
+    int32_t on_device;       /* !=0: all non-NULL pointers are device pointers */
+    int32_t reserved;
+    double* draws;           /* [C][N][D] posterior_matrix[:, i] = Q.q */
+    double* logdensities;    /* [C][N]    Q.ℓq */
+    double* eps;             /* [C][N]    ϵs[i] (warmup only in the reference, mcmc.jl:273) */
+    double* pi;              /* [C][N]    TreeStatisticsNUTS.π = logdensity(H, ζ) */
+    double* acceptance_rate; /* [C][N] */
+    int64_t* steps;          /* [C][N] */
+    int64_t* term_left;      /* [C][N]    InvalidTree.left  (trees.jl:180-202; (1,0) = REACHED_MAX_DEPTH) */
+    int64_t* term_right;     /* [C][N]    InvalidTree.right */
+    int32_t* depth;          /* [C][N] */
+    uint32_t* directions;    /* [C][N]    Directions.flags as drawn */
+} dhmc_outputs;
+
+/* ---- lifecycle ----------------------------------------------------------------------- */
+int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out);
+int dhmc_destroy(dhmc_ctx* ctx);
+/* hipStream_t to launch on (NULL = the default stream). */
+int dhmc_set_stream(dhmc_ctx* ctx, void* hip_stream);
+const char* dhmc_last_error(const dhmc_ctx* ctx);
+const char* dhmc_version(void);
+
+/* ---- warmup state: WarmupState(Q, κ, ϵ) per chain (mcmc.jl:72-79) -------------------- */
+/* initialize_warmup_state (mcmc.jl:129-132): q0 [C][D], or NULL for random_position
+ * (mcmc.jl:108); evaluates l strictly (hamiltonian.jl:202-217, strict=true), sets κ to the unit
+ * metric and ε to "unspecified" (NaN).  Clears status words and transition counters. */
+int dhmc_init(dhmc_ctx* ctx, const double* q0, int q0_on_device);
+/* q [C][D], lq [C], grad [C][D]; any may be NULL. */
+int dhmc_get_position(dhmc_ctx* ctx, double* q, double* lq, double* grad, int on_device);
+/* GaussianKineticEnergy(Diagonal(minv)) (hamiltonian.jl:80): minv [C][D] if per_chain else [D]. */
+int dhmc_set_metric_diag(dhmc_ctx* ctx, const double* minv, int per_chain, int on_device);
+int dhmc_get_metric_diag(dhmc_ctx* ctx, double* minv, int on_device); /* [C][D] */
+/* GaussianKineticEnergy(M⁻¹) dense (hamiltonian.jl:73): minv [D][D] symmetric, shared. */
+int dhmc_set_metric_dense(dhmc_ctx* ctx, const double* minv, int on_device);
+/* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */
+int dhmc_set_stepsize(dhmc_ctx* ctx, const double* eps, int per_chain, int on_device);
+int dhmc_get_stepsize(dhmc_ctx* ctx, double* eps, int on_device); /* [C] */
+int dhmc_get_status(dhmc_ctx* ctx, uint32_t* status); /* host [C] */
+
+/* ---- warmup(::InitialStepsizeSearch) (mcmc.jl:134-148 -> stepsize.jl:46-85) ---------- */
+int dhmc_find_initial_stepsize(dhmc_ctx* ctx, const dhmc_stepsize_search* params);
+
+/* ---- the per-draw loops (mcmc.jl:271-280 with `da`, :374-379 with da == NULL) -------- */
+int dhmc_run(dhmc_ctx* ctx, int64_t n_transitions, const dhmc_dual_averaging* da,
+             const dhmc_outputs* out);
+
+/* ---- end-of-stage metric update (mcmc.jl:209-223,281-284): κ := GaussianKineticEnergy(
+ *      regularize_M⁻¹(sample_M⁻¹(Diagonal, posterior_matrix), λ)) per chain from that chain's
+ *      own draws [C][N][D] (device pointer if on_device).  regularize is the identity for
+ *      Diagonal (mcmc.jl:223); lambda is accepted for signature parity. */
+int dhmc_update_metric_diag(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda,
+                            int on_device);
+
+/* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
+int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);
+int dhmc_export_state(dhmc_ctx* ctx, void* host_blob, uint64_t nbytes);
+int dhmc_import_state(dhmc_ctx* ctx, const void* host_blob, uint64_t nbytes);
+
+/* ---- measurement: HIP-event time of the kernels of the last dhmc_run on its stream --- */
+double dhmc_last_run_kernel_ms(const dhmc_ctx* ctx);
+/* bytes of device workspace the context holds (sizing for 288 GB HBM) */
+uint64_t dhmc_workspace_bytes(const dhmc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHMC_H */

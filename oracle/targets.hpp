@@ -1,0 +1,100 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU definitions of the shipped log-density family, i.e. what the user would hand the
+// reference through LogDensityProblems.logdensity_and_gradient (src/hamiltonian.jl:204).
+// The reference's own test targets come from LogDensityTestSuite 0.7, which is not vendored
+// under /root/reference ("parity unpinned" for their constants); these are defined here and
+// documented in DESIGN.md.  Arithmetic order is part of the definition (the device functors
+// in dynamichmc.jl_amd/csrc/targets.hpp restate it).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <vector>
+#include "mathops.hpp"
+
+namespace oracle {
+
+struct Target {
+    int D = 0;
+    virtual ~Target() {}
+    // (ℓq, ∇ℓq) = logdensity_and_gradient(ℓ, q)
+    virtual void eval(const MathOps& M, const double* q, double& lq, double* g) const = 0;
+    // true when a finite q implies a finite gradient and ℓq is finite or -Inf, so the
+    // gradient scan of evaluate_ℓ (src/hamiltonian.jl:205) cannot trigger
+    virtual bool grad_finite_if_q_finite() const { return false; }
+};
+
+// DHMC_TARGET_STD_NORMAL: ℓ = -1/2 Σ q², ∇ℓ = -q
+struct StdNormal : Target {
+    explicit StdNormal(int d) { D = d; }
+    void eval(const MathOps&, const double* q, double& lq, double* g) const override {
+        lq = -0.5 * wave_dot(q, q, D);
+        for (int i = 0; i < D; ++i) g[i] = -q[i];
+    }
+};
+
+// DHMC_TARGET_DIAG_NORMAL: ℓ = -1/2 Σ prec_i (q_i - mu_i)²
+struct DiagNormal : Target {
+    std::vector<double> mu, prec;
+    DiagNormal(int d, const double* m, const double* p) : mu(m, m + d), prec(p, p + d) { D = d; }
+    void eval(const MathOps&, const double* q, double& lq, double* g) const override {
+        std::vector<double> dv(D), w(D);
+        for (int i = 0; i < D; ++i) {
+            dv[i] = q[i] - mu[i];
+            w[i] = prec[i] * dv[i];
+            g[i] = -w[i];
+        }
+        lq = -0.5 * wave_dot(dv.data(), w.data(), D);
+    }
+};
+
+// DHMC_TARGET_TRIDIAG_NORMAL: ℓ = -1/2 q'Pq with P symmetric tridiagonal (diag, off)
+struct TridiagNormal : Target {
+    std::vector<double> diag, off;
+    TridiagNormal(int d, const double* a, const double* b) : diag(a, a + d), off(b, b + d) { D = d; }
+    void eval(const MathOps&, const double* q, double& lq, double* g) const override {
+        std::vector<double> Pq(D);
+        for (int i = 0; i < D; ++i) {
+            double t = diag[i] * q[i];
+            if (i > 0) t = t + off[i - 1] * q[i - 1];
+            if (i < D - 1) t = t + off[i] * q[i + 1];
+            Pq[i] = t;
+            g[i] = -t;
+        }
+        lq = -0.5 * wave_dot(q, Pq.data(), D);
+    }
+};
+
+// DHMC_TARGET_FUNNEL (Neal): v = q_0 ~ N(0, 3²), q_i | v ~ N(0, e^v), i >= 1
+//   ℓ = -v²/18 - 1/2 e^{-v} Σ q_i² - (D-1)/2 v
+struct Funnel : Target {
+    explicit Funnel(int d) { D = d; }
+    void eval(const MathOps& M, const double* q, double& lq, double* g) const override {
+        double v = q[0];
+        double ev = M.exp(-v);
+        std::vector<double> x(q, q + D);
+        x[0] = 0.0;
+        double S = wave_dot(x.data(), x.data(), D);
+        double hd = 0.5 * (double)(D - 1);
+        double hes = (0.5 * ev) * S;
+        lq = ((-(v * v) / 18.0) - hes) - hd * v;
+        g[0] = ((-v / 9.0) + hes) - hd;
+        for (int i = 1; i < D; ++i) g[i] = -(ev * q[i]);
+    }
+};
+
+// DHMC_TARGET_ALWAYS_DIVERGENT: the reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)
+struct AlwaysDivergent : Target {
+    explicit AlwaysDivergent(int d) { D = d; }
+    void eval(const MathOps&, const double* q, double& lq, double* g) const override {
+        bool allzero = true;
+        for (int i = 0; i < D; ++i) {
+            g[i] = 1.0;
+            if (q[i] != 0.0) allzero = false;
+        }
+        lq = allzero ? 0.0 : -INFINITY;
+    }
+};
+
+}  // namespace oracle

@@ -1,0 +1,117 @@
+"""The ABI's deterministic scalar math (include/dhmc_detmath.h) against libm.
+
+These functions replace Julia's exp/log/log1p/randn/randexp on the hot path (call sites in the
+header).  Bar: within 2 ulp of numpy/libm over the ranges the sampler uses, so the substitution
+stays inside the reference's own tolerance class.
+"""
+import numpy as np
+import oracle_lib as ol
+
+RNG = np.random.default_rng(0x23EF614D)
+
+
+def ulp_err(got, ref):
+    ref = np.asarray(ref, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.abs(got - ref) / np.spacing(np.abs(ref))
+
+
+def test_exp():
+    x = np.concatenate([RNG.uniform(-745, 709, 200000), RNG.uniform(-40, 5, 200000), RNG.normal(0, 1e-3, 1000)])
+    assert ulp_err(ol.detmath(0, x), np.exp(x)).max() <= 2.0
+    assert ol.detmath(0, [-np.inf])[0] == 0.0
+    assert ol.detmath(0, [np.inf])[0] == np.inf
+    assert ol.detmath(0, [0.0])[0] == 1.0
+    assert np.isnan(ol.detmath(0, [np.nan])[0])
+
+
+def test_log():
+    x = np.concatenate([np.exp(RNG.uniform(-700, 700, 200000)), RNG.uniform(0.5, 2.0, 200000),
+                        RNG.uniform(0, 1, 100000), [5e-324, 1e-310, 10.0, 1.0]])
+    assert ulp_err(ol.detmath(1, x), np.log(x)).max() <= 2.0
+    assert ol.detmath(1, [1.0])[0] == 0.0
+    assert ol.detmath(1, [0.0])[0] == -np.inf
+    assert np.isnan(ol.detmath(1, [-1.0])[0])
+    assert ol.detmath(1, [np.inf])[0] == np.inf
+
+
+def test_log1p_and_logaddexp():
+    u = np.concatenate([RNG.uniform(0, 1, 100000), np.exp(-RNG.uniform(0, 745, 100000))])
+    assert ulp_err(ol.detmath(2, u), np.log1p(u)).max() <= 2.0
+    x = RNG.uniform(-50, 10, 100000); y = x + RNG.normal(0, 20, 100000)
+    got = ol.detmath(8, x, y)
+    # max + log1p(.) cancels when the result is near 0: the bound is absolute, in ulps of max(x, y)
+    assert (np.abs(got - np.logaddexp(x, y)) / np.spacing(np.maximum(np.abs(np.maximum(x, y)), 1.0))).max() <= 2.0
+    # the -Inf rules the tree engine relies on (trees.jl:145 with ω = -Inf; NUTS.jl:79)
+    ninf = -np.inf
+    assert ol.detmath(8, [ninf], [ninf])[0] == ninf
+    assert ol.detmath(8, [ninf], [-3.5])[0] == -3.5
+    assert ol.detmath(8, [-3.5], [ninf])[0] == -3.5
+    # symmetric bit for bit
+    assert np.array_equal(got, ol.detmath(8, y, x))
+
+
+def test_sincos2pi():
+    a = np.concatenate([RNG.uniform(0, 1, 300000), [0.0, 0.25, 0.5, 0.75, 0.125, 1 - 2.0**-53]])
+    s, c = ol.detmath(3, a), ol.detmath(4, a)
+    # reference in x87 extended precision with an exact quadrant reduction (sin(2*pi*a) computed
+    # naively in double loses relative accuracy near the zeros through the rounding of 2*pi)
+    al = a.astype(np.longdouble)
+    pi_ld = np.arctan(np.longdouble(1)) * 4
+    t = 4 * al
+    n = np.floor(t + np.longdouble(0.5))
+    x = (t - n) * pi_ld / 2
+    s0, c0 = np.sin(x), np.cos(x)
+    q = n.astype(np.int64) & 3
+    sr = np.choose(q, [s0, c0, -s0, -c0]).astype(np.float64)
+    cr = np.choose(q, [c0, -s0, -c0, s0]).astype(np.float64)
+    m = sr != 0
+    assert ulp_err(s[m], sr[m]).max() <= 2.0
+    m = cr != 0
+    assert ulp_err(c[m], cr[m]).max() <= 2.0
+    assert np.abs(s * s + c * c - 1).max() < 5e-16
+    assert ol.detmath(3, [0.25])[0] == 1.0 and ol.detmath(4, [0.5])[0] == -1.0
+
+
+def _bits_as_double(u64):
+    return np.asarray(u64, np.uint64).view(np.float64)
+
+
+def test_randexp_randn_moments():
+    n = 400000
+    r1 = RNG.integers(0, 2**64, n, dtype=np.uint64)
+    r2 = RNG.integers(0, 2**64, n, dtype=np.uint64)
+    e = ol.detmath(5, _bits_as_double(r1))
+    assert np.all(e >= 0) and np.isfinite(e).all()
+    assert abs(e.mean() - 1) < 0.01 and abs(e.var() - 1) < 0.02
+    z0 = ol.detmath(6, _bits_as_double(r1), _bits_as_double(r2))
+    z1 = ol.detmath(7, _bits_as_double(r1), _bits_as_double(r2))
+    for z in (z0, z1):
+        assert abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.01
+        assert abs((z**4).mean() - 3) < 0.06
+    assert abs(np.corrcoef(z0, z1)[0, 1]) < 0.01
+    # extreme bit patterns stay finite
+    ext = np.array([0, 2**64 - 1, 1 << 11, (1 << 11) - 1], np.uint64)
+    assert np.isfinite(ol.detmath(5, _bits_as_double(ext))).all()
+    assert np.isfinite(ol.detmath(6, _bits_as_double(ext), _bits_as_double(ext[::-1].copy()))).all()
+
+
+def test_pow():
+    m = np.arange(2, 5000, dtype=np.float64)
+    got = ol.detmath(9, m, np.full_like(m, -0.75))
+    assert (np.abs(got - m**-0.75) / m**-0.75).max() < 4e-15
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    assert [hex(v) for v in ol.philox([0, 0, 0, 0], [0, 0])] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(v) for v in ol.philox([0xffffffff] * 4, [0xffffffff] * 2)] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(v) for v in ol.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_wave_dot_matches_plain_dot():
+    for n in (1, 3, 30, 64, 65, 100, 1000, 1024):
+        a = RNG.normal(size=n); b = RNG.normal(size=n)
+        assert abs(ol.wave_dot(a, b) - float(np.dot(a, b))) <= 1e-13 * np.abs(a * b).sum()
+    assert ol.wave_dot(np.array([np.nan]), np.array([1.0])) != ol.wave_dot(np.array([np.nan]), np.array([1.0]))  # NaN

@@ -1,0 +1,151 @@
+"""Replay of test/test_NUTS.jl and the deterministic parts of test/test_stepsize.jl,
+test/test_hamiltonian.jl against the oracle."""
+import math
+
+import numpy as np
+import pytest
+import oracle_lib as ol
+
+RNG = np.random.default_rng(0x8332E05C)
+
+
+def test_rand_bool_logprob():  # test_NUTS.jl:10-21
+    for prob in np.arange(1, 10) / 10:
+        cnt, used = ol.rand_bool_logprob(math.log(prob), 10000, seed=int(prob * 100))
+        assert abs(cnt / 10000 - prob) <= 0.02
+        assert used == 10000
+    # logprob >= 0 never touches the RNG
+    for lp in (0.0, 10.0):
+        cnt, used = ol.rand_bool_logprob(lp, 10000)
+        assert cnt == 10000 and used == 0
+
+
+def test_low_level_turn_statistics():  # test_NUTS.jl:27-42
+    p = np.ones(3); c = 0.1
+    t1 = np.stack([p, p - c, p, p - c, p])
+    t2 = np.stack([3 * p, 3 * p + c, 3 * p, 3 * p + c, 3 * p])
+    t3 = np.stack([2 * p, 2 * p + c, 2 * p, 2 * p + c, -2 * p])
+    turning, rho = ol.combine_turn(t1, t2)
+    assert not turning
+    assert np.array_equal(rho, t1[4] + t2[4])
+    turning, _ = ol.combine_turn(t1, t3)
+    assert turning
+
+
+def test_low_level_visited_statistics():  # test_NUTS.jl:44-55
+    for det in (True, False):
+        assert np.isclose(ol.acceptance([math.log(0.3)], [0], det), 0.3)
+        assert np.isclose(ol.acceptance([math.log(0.6)], [0], det), 0.6)
+        a = ol.acceptance([math.log(0.3), math.log(0.3), math.log(0.6), math.log(10)], [0, 0, 0, 1], det)
+        assert np.isclose(a, 0.4)
+
+
+def test_unconditional_divergence():  # test_NUTS.jl:75-85
+    o = ol.Oracle(3, 4, target=ol.TARGET_ALWAYS_DIVERGENT)
+    o.init(np.zeros((4, 3)))
+    o.set_stepsize(1.0)
+    r = o.run(1)
+    assert np.all(r["term_left"] == r["term_right"])      # is_divergent
+    assert np.all(r["acceptance_rate"] == 0)
+    assert np.all(r["depth"] == 0)
+    assert np.all(r["steps"] == 1)
+    assert np.all(r["draws"] == 0)                         # proposal unchanged
+
+
+def test_logdensity_infinity_fallbacks():  # test_hamiltonian.jl:197-200
+    assert ol.logdensity(-np.inf, [1.0], [1.0]) == -np.inf
+    assert ol.logdensity(np.nan, [1.0], [1.0]) == -np.inf
+    assert ol.logdensity(9.0, [np.nan], [1.0]) == -np.inf
+    assert ol.logdensity(9.0, [2.0], [1.0]) == 7.0
+
+
+def _leapfrog_gaussian(q, p, mu, prec, eps, m):  # test_hamiltonian.jl:72-78, independent formula
+    u = np.sqrt(1 / m)
+    grad = lambda x: -prec * (x - mu)
+    ph = p + eps / 2 * grad(q)
+    q1 = q + eps * u * (u * ph)
+    p1 = ph + eps / 2 * grad(q1)
+    return q1, p1
+
+
+def test_leapfrog_calculation():  # test_hamiltonian.jl:69-109 (diagonal target variant)
+    n = 3
+    m = RNG.normal(size=n) ** 2 + 0.01
+    mu = RNG.normal(size=n); prec = 1 / (RNG.normal(size=n) ** 2 + 0.01)
+    q = RNG.normal(size=n); p = RNG.normal(size=n)
+    eps = 0.05
+    cfg = ol.make_config(n, 1, target=ol.TARGET_DIAG_NORMAL, params=np.concatenate([mu, prec]))
+    qs, ps, _, _, st = ol.leapfrog(cfg, 1 / m, q, p, eps, 100)
+    assert st == 0
+    for i in range(100):
+        q, p = _leapfrog_gaussian(q, p, mu, prec, eps, m)
+        assert np.allclose(qs[i], q, rtol=math.sqrt(np.finfo(float).eps))
+        assert np.allclose(ps[i], p, rtol=math.sqrt(np.finfo(float).eps))
+
+
+def test_nan_position_flags_error():  # test_hamiltonian.jl:111-115 (throw -> status bit)
+    o = ol.Oracle(3, 1)
+    rc = o.init(np.full((1, 3), np.nan), allow_failure=True)
+    assert rc == ol.ERR_CHAIN_FAILURE and o.status()[0] & ol.ST_NONFINITE_POSITION
+
+
+def test_leapfrog_energy_and_reversibility():  # test_hamiltonian.jl:118-153
+    for _ in range(50):
+        n = 5
+        minv = 1 / (RNG.normal(size=n) ** 2 + 0.01)
+        mu = RNG.normal(size=n); prec = 1 / (RNG.normal(size=n) ** 2 + 0.01)
+        q = mu + RNG.normal(size=n) / np.sqrt(prec); p = RNG.normal(size=n) / np.sqrt(minv)
+        cfg = ol.make_config(n, 1, target=ol.TARGET_DIAG_NORMAL, params=np.concatenate([mu, prec]))
+        eps = 0.1 * min(1.0, float(np.sqrt(1 / (prec * minv)).min()))
+        qs, ps, pis, _, _ = ol.leapfrog(cfg, minv, q, p, eps, 10)
+        pi0 = ol.leapfrog(cfg, minv, q, p, 0.0, 1)[2][0]
+        assert np.all(np.abs(pis - pi0) < 0.5)            # :118-141
+        q1, p1 = ol.leapfrog(cfg, minv, q, p, eps, 1)[:2]
+        q2, p2 = ol.leapfrog(cfg, minv, q1[0], p1[0], -eps, 1)[:2]
+        assert np.abs(p2[0] - p).max() <= 1e-5 and np.abs(q2[0] - q).max() <= 1e-6   # :143-153
+
+
+def test_stepsize_general_rootfinding():  # test_stepsize.jl:9-25
+    thr = math.log(0.8)
+    rc, eps = ol.find_initial_stepsize_linear(-3.0)
+    assert rc == 0 and eps == 0.05 and -3 * eps > thr > -3 * 0.1
+    rc, eps = ol.find_initial_stepsize_linear(-3.0, initial_eps=0.01)
+    assert rc == 0 and eps == 0.08 and -3 * eps < thr < -3 * 0.01
+    rc, _ = ol.find_initial_stepsize_linear(0.0, intercept=1.0)   # constant A: the reference throws
+    assert rc == 1
+    assert ol.find_initial_stepsize_linear(-3.0, log_threshold=float("nan"))[0] == 2   # :13
+    assert ol.find_initial_stepsize_linear(-3.0, log_threshold=1.0)[0] == 2            # :14
+    assert ol.find_initial_stepsize_linear(-3.0, initial_eps=-0.5)[0] == 2             # :15
+    assert ol.find_initial_stepsize_linear(-3.0, maxiter=2)[0] == 2                    # :16
+
+
+def test_dual_averaging_known_values():  # test_stepsize.jl:42-44 + SURVEY.md §8a row a24
+    for det in (True, False):
+        st = ol.da_init(100.0, det)
+        assert st[4] == 0 and st[1] == 1 and st[2] == 0
+        st = ol.da_init(1.0, det)
+        st = ol.da_adapt(st, 0.5, det=det)
+        assert st[1] == 2 and np.isclose(st[2], 0.025, rtol=1e-14)
+        assert np.isclose(st[3], 1.5954783118074982, rtol=1e-14)
+        assert np.isclose(st[4], 0.9486770801170034, rtol=1e-14)
+        st = ol.da_adapt(st, 1.0, det=det)
+        assert st[1] == 3 and np.isclose(st[2], 0.0076923076923077, rtol=1e-12)
+        assert np.isclose(st[3], 2.036115737983449, rtol=1e-14)
+        assert np.isclose(st[4], 1.4257269995496586, rtol=1e-14)
+
+
+def _dummy_acceptance_rate(eps, sigma, rng):  # test_stepsize.jl:33
+    return min(1 / eps * math.exp(rng.normal() * sigma - sigma ** 2 / 2), 1)
+
+
+@pytest.mark.parametrize("eps0,iters,sigma,atol", [(100.0, 500, 0.05, 0.02), (2.0, 2000, 0.05, 0.01),
+                                                   (20.0, 10000, 2.0, 0.04)])
+def test_dual_averaging_convergence(eps0, iters, sigma, atol):  # test_stepsize.jl:37-71
+    rng = np.random.default_rng(1)
+    delta = 0.65
+    st = ol.da_init(eps0)
+    for _ in range(iters):
+        st = ol.da_adapt(st, _dummy_acceptance_rate(math.exp(st[3]), sigma, rng), delta=delta)
+    fe = math.exp(st[4])
+    mean_rate = np.mean([_dummy_acceptance_rate(fe, sigma, rng) for _ in range(10000)])
+    assert abs(mean_rate - delta) <= atol
