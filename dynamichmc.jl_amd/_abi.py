@@ -1,0 +1,91 @@
+"""ctypes binding of the C ABI in include/dhmc.h (libdhmc_amd.so, built in-tree under lib/).
+
+This is the whole Python<->HIP surface: plain pointers and sizes, no torch types.  There is no
+CPU fallback — if the library is missing or no HIP device is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libdhmc_amd.so")
+
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE = range(6)
+ST_NONFINITE_POSITION, ST_INVALID_INITIAL, ST_STEPSIZE_SEARCH_FAILED, ST_NONFINITE_START_DENSITY = 1, 2, 4, 8
+TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT = range(6)
+METRIC_DIAG, METRIC_DENSE = 0, 1
+
+ERROR_NAMES = {ERR_INVALID_ARGUMENT: "invalid argument", ERR_HIP: "HIP runtime error",
+               ERR_UNSUPPORTED: "unsupported configuration", ERR_CHAIN_FAILURE: "chain failure",
+               ERR_NO_DEVICE: "no HIP device (there is no CPU fallback)"}
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dim", C.c_int32), ("chains", C.c_int32),
+                ("chain_offset", C.c_int32), ("metric", C.c_int32), ("target", C.c_int32),
+                ("target_params", C.c_void_p), ("target_params_bytes", C.c_uint64),
+                ("max_depth", C.c_int32), ("reserved", C.c_int32), ("min_delta", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+class StepsizeSearch(C.Structure):
+    _fields_ = [("initial_eps", C.c_double), ("log_threshold", C.c_double),
+                ("maxiter_crossing", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DualAveragingABI(C.Structure):
+    _fields_ = [("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double),
+                ("t0", C.c_int32), ("init", C.c_int32), ("finalize", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("on_device", C.c_int32), ("reserved", C.c_int32), ("draws", C.c_void_p),
+                ("logdensities", C.c_void_p), ("eps", C.c_void_p), ("pi", C.c_void_p),
+                ("acceptance_rate", C.c_void_p), ("steps", C.c_void_p), ("term_left", C.c_void_p),
+                ("term_right", C.c_void_p), ("depth", C.c_void_p), ("directions", C.c_void_p)]
+
+
+OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np.float64),
+                 ("pi", np.float64), ("acceptance_rate", np.float64), ("steps", np.int64),
+                 ("term_left", np.int64), ("term_right", np.int64), ("depth", np.int32),
+                 ("directions", np.uint32)]
+
+# every symbol include/dhmc.h declares
+SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", "dhmc_version",
+           "dhmc_init", "dhmc_get_position", "dhmc_set_metric_diag", "dhmc_get_metric_diag",
+           "dhmc_set_metric_dense", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
+           "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_state_bytes",
+           "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
+           "dhmc_last_run_leapfrogs", "dhmc_workspace_bytes"]
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdhmc_amd.so from the package tree.  Never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                f"{LIB_PATH} not found: build it with `make -C dynamichmc.jl_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(L, s)
+        L.dhmc_last_error.restype = C.c_char_p
+        L.dhmc_version.restype = C.c_char_p
+        L.dhmc_last_run_kernel_ms.restype = C.c_double
+        L.dhmc_last_run_leapfrogs.restype = C.c_uint64
+        L.dhmc_workspace_bytes.restype = C.c_uint64
+        for name in SYMBOLS:
+            if name.startswith("dhmc_") and name not in ("dhmc_last_error", "dhmc_version", "dhmc_last_run_kernel_ms",
+                                                         "dhmc_last_run_leapfrogs", "dhmc_workspace_bytes"):
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib

@@ -1,0 +1,201 @@
+"""Low-level multi-chain context: a thin object over the C ABI (one per GPU).
+
+Mirrors the reference's WarmupState(Q, κ, ϵ) (src/mcmc.jl:72-79) for C chains at once and the
+calls that act on it.  Failures the reference raises as DynamicHMCError / ArgumentError are
+re-raised here under the same names.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+
+
+class DynamicHMCError(Exception):
+    """Counterpart of DynamicHMC.DynamicHMCError (src/utilities.jl:17-27): `message` plus a
+    dict of debug information (here: the failing chains and their status words)."""
+
+    def __init__(self, message, **debug_information):
+        super().__init__(message)
+        self.message = message
+        self.debug_information = debug_information
+
+    def __str__(self):
+        s = f"DynamicHMC error: {self.message}"
+        for k, v in self.debug_information.items():
+            s += f"\n  {k} = {v}"
+        return s
+
+
+STATUS_MESSAGES = [
+    (abi.ST_NONFINITE_POSITION, "Position vector has non-finite elements."),               # hamiltonian.jl:203
+    (abi.ST_INVALID_INITIAL, "Invalid log posterior or non-finite gradient at the initial position."),  # :212-216
+    (abi.ST_STEPSIZE_SEARCH_FAILED, "Initial stepsize search reached maximum number of iterations without crossing."),  # stepsize.jl:58
+    (abi.ST_NONFINITE_START_DENSITY, "Starting point has non-finite density."),           # stepsize.jl:78
+]
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a.data_ptr()))  # torch tensor
+
+
+def _is_device(a):
+    return not isinstance(a, np.ndarray) and hasattr(a, "data_ptr") and a.is_cuda
+
+
+class DeviceContext:
+    def __init__(self, dim, chains, target=abi.TARGET_STD_NORMAL, target_params=None, seed=0x23EF614D,
+                 max_depth=10, min_delta=-1000.0, chain_offset=0, metric=abi.METRIC_DIAG, device=0,
+                 stream=None):
+        self.D, self.C = int(dim), int(chains)
+        cfg = abi.Config()
+        cfg.device, cfg.dim, cfg.chains, cfg.chain_offset = device, self.D, self.C, chain_offset
+        cfg.metric, cfg.target, cfg.max_depth, cfg.min_delta, cfg.seed = metric, target, max_depth, min_delta, seed
+        if target_params is not None:
+            target_params = np.ascontiguousarray(target_params)
+            cfg.target_params = target_params.ctypes.data
+            cfg.target_params_bytes = target_params.nbytes
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = abi.lib().dhmc_create(C.byref(cfg), C.byref(self.h))
+        if rc != abi.OK:
+            self.h = None
+            self._raise(rc, "dhmc_create")
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- error mapping ---------------------------------------------------------------------
+    def _raise(self, rc, what):
+        if rc == abi.ERR_INVALID_ARGUMENT:
+            raise ValueError(f"ArgumentError in {what}")  # the reference's @argcheck failures
+        if rc == abi.ERR_CHAIN_FAILURE:
+            st = self.status()
+            bad = np.nonzero(st)[0]
+            bits = int(np.bitwise_or.reduce(st[bad]))
+            msg = next(m for b, m in STATUS_MESSAGES if bits & b)
+            raise DynamicHMCError(msg, chains=bad[:16].tolist(), n_failed=int(bad.size), status=st[bad[:16]].tolist())
+        detail = abi.lib().dhmc_last_error(self.h).decode() if self.h else ""
+        raise RuntimeError(f"{what}: {abi.ERROR_NAMES.get(rc, rc)} {detail}")
+
+    def _chk(self, rc, what, allow_failure=False):
+        if rc == abi.OK or (allow_failure and rc == abi.ERR_CHAIN_FAILURE):
+            return rc
+        self._raise(rc, what)
+
+    def close(self):
+        if getattr(self, "h", None):
+            abi.lib().dhmc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state -----------------------------------------------------------------------------
+    def set_stream(self, stream):
+        self._chk(abi.lib().dhmc_set_stream(self.h, C.c_void_p(int(stream))), "dhmc_set_stream")
+
+    def init(self, q0=None, allow_failure=False):
+        """initialize_warmup_state (mcmc.jl:129-132)."""
+        if q0 is not None and isinstance(q0, np.ndarray):
+            q0 = np.ascontiguousarray(np.broadcast_to(q0, (self.C, self.D)), np.float64)
+        return self._chk(abi.lib().dhmc_init(self.h, _ptr(q0), int(q0 is not None and _is_device(q0))), "dhmc_init", allow_failure)
+
+    def position(self):
+        q = np.zeros((self.C, self.D)); lq = np.zeros(self.C); g = np.zeros((self.C, self.D))
+        self._chk(abi.lib().dhmc_get_position(self.h, _ptr(q), _ptr(lq), _ptr(g), 0), "dhmc_get_position")
+        return q, lq, g
+
+    def set_metric_diag(self, minv):
+        minv = np.ascontiguousarray(minv, np.float64)
+        self._chk(abi.lib().dhmc_set_metric_diag(self.h, _ptr(minv), int(minv.ndim == 2), 0), "dhmc_set_metric_diag")
+
+    def metric_diag(self):
+        m = np.zeros((self.C, self.D))
+        self._chk(abi.lib().dhmc_get_metric_diag(self.h, _ptr(m), 0), "dhmc_get_metric_diag")
+        return m
+
+    def set_stepsize(self, eps):
+        eps = np.ascontiguousarray(np.atleast_1d(eps), np.float64)
+        self._chk(abi.lib().dhmc_set_stepsize(self.h, _ptr(eps), int(eps.size == self.C), 0), "dhmc_set_stepsize")
+
+    def stepsize(self):
+        e = np.zeros(self.C)
+        self._chk(abi.lib().dhmc_get_stepsize(self.h, _ptr(e), 0), "dhmc_get_stepsize")
+        return e
+
+    def status(self):
+        s = np.zeros(self.C, np.uint32)
+        rc = abi.lib().dhmc_get_status(self.h, _ptr(s))
+        if rc != abi.OK:
+            raise RuntimeError("dhmc_get_status failed")
+        return s
+
+    def find_initial_stepsize(self, initial_eps=0.1, log_threshold=float(np.log(0.8)), maxiter_crossing=400,
+                              allow_failure=False):
+        p = abi.StepsizeSearch(initial_eps, log_threshold, maxiter_crossing, 0)
+        return self._chk(abi.lib().dhmc_find_initial_stepsize(self.h, C.byref(p)), "dhmc_find_initial_stepsize", allow_failure)
+
+    # ---- the per-draw loops ----------------------------------------------------------------
+    def run_into(self, N, arrays, da=None, allow_failure=False):
+        """dhmc_run into caller-owned buffers (`arrays`: name -> numpy array or CUDA torch tensor)."""
+        o = abi.Outputs()
+        dev = [_is_device(a) for a in arrays.values() if a is not None]
+        if dev and any(dev) != all(dev):
+            raise ValueError("output buffers must be all host or all device")
+        o.on_device = int(bool(dev) and all(dev))
+        for name, _ in abi.OUTPUT_FIELDS:
+            a = arrays.get(name)
+            setattr(o, name, _ptr(a).value if a is not None else None)
+        dap = None
+        if da is not None:
+            d = dict(delta=0.8, gamma=0.05, kappa=0.75, t0=10, init=1, finalize=1)
+            d.update(da)
+            dap = abi.DualAveragingABI(d["delta"], d["gamma"], d["kappa"], d["t0"], d["init"], d["finalize"], 0)
+        rc = abi.lib().dhmc_run(self.h, C.c_int64(N), C.byref(dap) if dap is not None else None, C.byref(o))
+        return self._chk(rc, "dhmc_run", allow_failure)
+
+    def run(self, N, da=None, fields=None, allow_failure=False):
+        arrs = {}
+        for name, dt in abi.OUTPUT_FIELDS:
+            if fields is not None and name not in fields:
+                continue
+            arrs[name] = np.zeros((self.C, N, self.D) if name == "draws" else (self.C, N), dt)
+        self.run_into(N, arrs, da=da, allow_failure=allow_failure)
+        return arrs
+
+    def update_metric_diag(self, draws, lam=0.0):
+        """κ := GaussianKineticEnergy(regularize(sample_M⁻¹(Diagonal, draws), λ)) (mcmc.jl:281-284)."""
+        if isinstance(draws, np.ndarray):
+            draws = np.ascontiguousarray(draws, np.float64)
+        n = draws.shape[1]
+        self._chk(abi.lib().dhmc_update_metric_diag(self.h, _ptr(draws), C.c_int64(n), C.c_double(lam), int(_is_device(draws))),
+                  "dhmc_update_metric_diag")
+
+    # ---- resume ----------------------------------------------------------------------------
+    def export_state(self):
+        n = C.c_uint64()
+        self._chk(abi.lib().dhmc_state_bytes(self.h, C.byref(n)), "dhmc_state_bytes")
+        blob = np.zeros(n.value, np.uint8)
+        self._chk(abi.lib().dhmc_export_state(self.h, _ptr(blob), n), "dhmc_export_state")
+        return blob
+
+    def import_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._chk(abi.lib().dhmc_import_state(self.h, _ptr(blob), C.c_uint64(blob.size)), "dhmc_import_state")
+
+    # ---- measurement -----------------------------------------------------------------------
+    def last_run_kernel_ms(self):
+        return abi.lib().dhmc_last_run_kernel_ms(self.h)
+
+    def last_run_leapfrogs(self):
+        return int(abi.lib().dhmc_last_run_leapfrogs(self.h))
+
+    def workspace_bytes(self):
+        return int(abi.lib().dhmc_workspace_bytes(self.h))

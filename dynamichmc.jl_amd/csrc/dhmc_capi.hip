@@ -1,0 +1,538 @@
+// libdhmc_amd.so — host side of the C ABI declared in include/dhmc.h.
+//
+// Owns the opaque context (device-resident chain state + workspace), validates arguments where
+// the reference uses @argcheck, launches the HIP kernels of nuts_kernels.hpp on the caller's
+// stream, and maps per-chain failure words onto return codes.  There is NO CPU path in this
+// library: without a HIP device every entry point that computes returns DHMC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dhmc.h"
+#include "nuts_kernels.hpp"
+
+using namespace dhmc;
+
+struct dhmc_ctx {
+    dhmc_config cfg{};
+    int Dpad = 0, NPL = 0, nvec = 0;
+    hipStream_t stream = nullptr;
+    ChainArrays st{};
+    TargetParams tp{};
+    void* d_tp_a = nullptr;
+    void* d_tp_b = nullptr;
+    unsigned long long* d_counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    unsigned long long last_leapfrogs = 0;
+    uint64_t ws_bytes = 0;
+    std::string err;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            return DHMC_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+template <class Tp>
+int dev_alloc(dhmc_ctx* c, Tp** p, size_t count) {
+    void* v = nullptr;
+    HIP_TRY(c, hipMalloc(&v, count * sizeof(Tp)));
+    c->allocs.push_back(v);
+    c->ws_bytes += count * sizeof(Tp);
+    *p = (Tp*)v;
+    return DHMC_OK;
+}
+
+int npl_for_dim(int D) {
+    int npl = (D + WAVE - 1) / WAVE;
+    for (int cand : {1, 2, 4, 8, 16})
+        if (npl <= cand) return cand;
+    return 0;
+}
+
+// ---- kernel dispatch over (target family, slots per lane) ---------------------------------
+template <class T, int NPL>
+void launch_run(const RunParams& P, hipStream_t s) {
+    hipLaunchKernelGGL((nuts_run_kernel<T, NPL>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad), s, P);
+}
+template <class T, int NPL>
+void launch_init(const InitParams& P, hipStream_t s) {
+    hipLaunchKernelGGL((init_kernel<T, NPL>), dim3(P.C), dim3(WAVE), 0, s, P);
+}
+template <class T, int NPL>
+void launch_search(const SearchParams& P, hipStream_t s) {
+    hipLaunchKernelGGL((stepsize_search_kernel<T, NPL>), dim3(P.C), dim3(WAVE), sizeof(double) * P.Dpad, s, P);
+}
+
+enum class Op { Run, Init, Search };
+
+template <class T, int NPL>
+void dispatch_op(Op op, const void* P, hipStream_t s) {
+    switch (op) {
+    case Op::Run: launch_run<T, NPL>(*(const RunParams*)P, s); break;
+    case Op::Init: launch_init<T, NPL>(*(const InitParams*)P, s); break;
+    case Op::Search: launch_search<T, NPL>(*(const SearchParams*)P, s); break;
+    }
+}
+template <class T>
+int dispatch_npl(int npl, Op op, const void* P, hipStream_t s) {
+    switch (npl) {
+    case 1: dispatch_op<T, 1>(op, P, s); return DHMC_OK;
+    case 2: dispatch_op<T, 2>(op, P, s); return DHMC_OK;
+    case 4: dispatch_op<T, 4>(op, P, s); return DHMC_OK;
+    case 8: dispatch_op<T, 8>(op, P, s); return DHMC_OK;
+    case 16: dispatch_op<T, 16>(op, P, s); return DHMC_OK;
+    default: return DHMC_ERR_UNSUPPORTED;
+    }
+}
+int dispatch(const dhmc_ctx* c, Op op, const void* P) {
+    switch (c->cfg.target) {
+    case DHMC_TARGET_STD_NORMAL: return dispatch_npl<StdNormalT>(c->NPL, op, P, c->stream);
+    case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, c->stream);
+    case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, c->stream);
+    case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, c->stream);
+    case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, c->stream);
+    default: return DHMC_ERR_UNSUPPORTED;
+    }
+}
+void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
+    int D = c->cfg.dim, Dp = c->Dpad, C = c->cfg.chains;
+    switch (c->NPL) {
+    case 1: hipLaunchKernelGGL((metric_diag_kernel<1>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    case 2: hipLaunchKernelGGL((metric_diag_kernel<2>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    case 4: hipLaunchKernelGGL((metric_diag_kernel<4>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    case 8: hipLaunchKernelGGL((metric_diag_kernel<8>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    default: hipLaunchKernelGGL((metric_diag_kernel<16>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    }
+}
+
+// Stage a host array onto the device (returns a temp the caller frees), or pass through.
+struct Staged {
+    const void* dev = nullptr;
+    void* temp = nullptr;
+};
+int stage_in(dhmc_ctx* c, const void* p, size_t bytes, int on_device, Staged* s) {
+    if (on_device) { s->dev = p; return DHMC_OK; }
+    HIP_TRY(c, hipMalloc(&s->temp, bytes));
+    HIP_TRY(c, hipMemcpyAsync(s->temp, p, bytes, hipMemcpyHostToDevice, c->stream));
+    s->dev = s->temp;
+    return DHMC_OK;
+}
+void stage_free(dhmc_ctx* c, Staged* s) {
+    if (s->temp) { (void)hipStreamSynchronize(c->stream); (void)hipFree(s->temp); s->temp = nullptr; }
+}
+
+int read_status(dhmc_ctx* c, std::vector<uint32_t>& st) {
+    st.resize(c->cfg.chains);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), c->st.status, sizeof(uint32_t) * st.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DHMC_OK;
+}
+int status_code(dhmc_ctx* c) {
+    std::vector<uint32_t> st;
+    int rc = read_status(c, st);
+    if (rc != DHMC_OK) return rc;
+    for (uint32_t s : st)
+        if (s) return DHMC_ERR_CHAIN_FAILURE;
+    return DHMC_OK;
+}
+
+int copy_out_padded(dhmc_ctx* c, const double* padded, double* dst, int on_device) {
+    int D = c->cfg.dim, C = c->cfg.chains;
+    size_t n = (size_t)C * D;
+    double* d = dst;
+    void* temp = nullptr;
+    if (!on_device) {
+        HIP_TRY(c, hipMalloc(&temp, n * sizeof(double)));
+        d = (double*)temp;
+    }
+    hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, D, c->Dpad, C, padded, d);
+    HIP_TRY(c, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(c, hipMemcpyAsync(dst, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(temp);
+    }
+    return DHMC_OK;
+}
+int copy_out_scalar(dhmc_ctx* c, const void* src, void* dst, size_t bytes, int on_device) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DHMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dhmc_version(void) { return "dhmc_amd 0.1.0 (gfx950)"; }
+
+const char* dhmc_last_error(const dhmc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
+    if (!cfg || !out) return DHMC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (cfg->dim <= 0 || cfg->chains <= 0 || cfg->chain_offset < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!(0 < cfg->max_depth && cfg->max_depth <= 32)) return DHMC_ERR_INVALID_ARGUMENT;  // NUTS.jl:190
+    if (!(cfg->min_delta < 0)) return DHMC_ERR_INVALID_ARGUMENT;                           // NUTS.jl:191
+    if (cfg->metric != DHMC_METRIC_DIAG) return DHMC_ERR_UNSUPPORTED;
+    const int D = cfg->dim;
+    switch (cfg->target) {
+    case DHMC_TARGET_STD_NORMAL: case DHMC_TARGET_ALWAYS_DIVERGENT: break;
+    case DHMC_TARGET_FUNNEL: if (D < 2) return DHMC_ERR_INVALID_ARGUMENT; break;
+    case DHMC_TARGET_DIAG_NORMAL: case DHMC_TARGET_TRIDIAG_NORMAL:
+        if (!cfg->target_params || cfg->target_params_bytes != sizeof(double) * 2 * (size_t)D) return DHMC_ERR_INVALID_ARGUMENT;
+        break;
+    default: return DHMC_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return DHMC_ERR_NO_DEVICE;
+    dhmc_ctx* c = new (std::nothrow) dhmc_ctx();
+    if (!c) return DHMC_ERR_HIP;
+    c->cfg = *cfg;
+    c->cfg.target_params = nullptr;
+    c->NPL = npl_for_dim(D);
+    if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
+    c->Dpad = c->NPL * WAVE;
+    c->nvec = ws_nvec(cfg->max_depth);
+    auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
+    const size_t C = cfg->chains, Dp = c->Dpad;
+    int rc;
+    if ((rc = dev_alloc(c, &c->st.q, C * Dp))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.g, C * Dp))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.lq, C))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.minv, C * Dp))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.W, C * Dp))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.eps, C))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.da, C))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.transition, C))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.status, C))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->st.ws, C * (size_t)c->nvec * Dp))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->d_counter, 1))) return fail(rc);
+    if (hipMemset(c->st.q, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (hipMemset(c->st.g, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (hipMemset(c->st.da, 0, C * sizeof(DAState)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (hipMemset(c->st.status, 0, C * sizeof(uint32_t)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (hipMemset(c->st.transition, 0, C * sizeof(uint32_t)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL) {
+        std::vector<double> a(Dp, 0.0), b(Dp, 0.0);
+        const double* src = (const double*)cfg->target_params;
+        std::memcpy(a.data(), src, sizeof(double) * D);
+        std::memcpy(b.data(), src + D, sizeof(double) * D);
+        double *da = nullptr, *db = nullptr;
+        if ((rc = dev_alloc(c, &da, Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &db, Dp))) return fail(rc);
+        if (hipMemcpy(da, a.data(), Dp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(db, b.data(), Dp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        c->tp.a = da;
+        c->tp.b = db;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
+    // unit metric, ε unspecified
+    {
+        std::vector<double> ones(C * Dp, 1.0), w(C * Dp, 0.0), nanv(C, std::nan(""));
+        for (size_t ch = 0; ch < C; ++ch)
+            for (int e = 0; e < D; ++e) w[ch * Dp + e] = 1.0;
+        if (hipMemcpy(c->st.minv, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(c->st.W, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(c->st.eps, nanv.data(), C * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+    }
+    *out = c;
+    return DHMC_OK;
+}
+
+int dhmc_destroy(dhmc_ctx* c) {
+    if (!c) return DHMC_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return DHMC_OK;
+}
+
+int dhmc_set_stream(dhmc_ctx* c, void* s) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    c->stream = (hipStream_t)s;
+    return DHMC_OK;
+}
+
+int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    Staged s;
+    if (q0) {
+        int rc = stage_in(c, q0, sizeof(double) * (size_t)c->cfg.chains * c->cfg.dim, q0_on_device, &s);
+        if (rc) return rc;
+    }
+    InitParams P{c->cfg.dim, c->Dpad, c->cfg.chains, c->cfg.chain_offset, c->cfg.seed, (const double*)s.dev, c->st, c->tp};
+    int rc = dispatch(c, Op::Init, &P);
+    if (rc) { stage_free(c, &s); return rc; }
+    HIP_TRY(c, hipGetLastError());
+    stage_free(c, &s);
+    return status_code(c);
+}
+
+int dhmc_get_position(dhmc_ctx* c, double* q, double* lq, double* grad, int on_device) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc;
+    if (q && (rc = copy_out_padded(c, c->st.q, q, on_device))) return rc;
+    if (grad && (rc = copy_out_padded(c, c->st.g, grad, on_device))) return rc;
+    if (lq && (rc = copy_out_scalar(c, c->st.lq, lq, sizeof(double) * c->cfg.chains, on_device))) return rc;
+    return DHMC_OK;
+}
+
+int dhmc_set_metric_diag(dhmc_ctx* c, const double* minv, int per_chain, int on_device) {
+    if (!c || !minv) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int D = c->cfg.dim, C = c->cfg.chains;
+    const size_t n = per_chain ? (size_t)C * D : (size_t)D;
+    if (!on_device) {
+        for (size_t i = 0; i < n; ++i)
+            if (!(minv[i] > 0) || !std::isfinite(minv[i])) return DHMC_ERR_INVALID_ARGUMENT;
+    }
+    Staged s;
+    int rc = stage_in(c, minv, n * sizeof(double), on_device, &s);
+    if (rc) return rc;
+    size_t tot = (size_t)C * c->Dpad;
+    hipLaunchKernelGGL(set_metric_diag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, D, c->Dpad, C,
+                       (const double*)s.dev, per_chain, c->st.minv, c->st.W);
+    HIP_TRY(c, hipGetLastError());
+    stage_free(c, &s);
+    return DHMC_OK;
+}
+
+int dhmc_get_metric_diag(dhmc_ctx* c, double* minv, int on_device) {
+    if (!c || !minv) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return copy_out_padded(c, c->st.minv, minv, on_device);
+}
+
+int dhmc_set_metric_dense(dhmc_ctx* c, const double*, int) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    return DHMC_ERR_UNSUPPORTED;
+}
+
+int dhmc_set_stepsize(dhmc_ctx* c, const double* eps, int per_chain, int on_device) {
+    if (!c || !eps) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int C = c->cfg.chains;
+    std::vector<double> h(C);
+    if (on_device) {
+        if (!per_chain) return DHMC_ERR_INVALID_ARGUMENT;
+        HIP_TRY(c, hipMemcpyAsync(h.data(), eps, sizeof(double) * C, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        for (int i = 0; i < C; ++i) h[i] = eps[per_chain ? i : 0];
+    }
+    for (int i = 0; i < C; ++i)
+        if (!(h[i] > 0)) return DHMC_ERR_INVALID_ARGUMENT;  // stepsize.jl:135
+    HIP_TRY(c, hipMemcpyAsync(c->st.eps, h.data(), sizeof(double) * C, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DHMC_OK;
+}
+
+int dhmc_get_stepsize(dhmc_ctx* c, double* eps, int on_device) {
+    if (!c || !eps) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return copy_out_scalar(c, c->st.eps, eps, sizeof(double) * c->cfg.chains, on_device);
+}
+
+int dhmc_get_status(dhmc_ctx* c, uint32_t* status) {
+    if (!c || !status) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return copy_out_scalar(c, c->st.status, status, sizeof(uint32_t) * c->cfg.chains, 0);
+}
+
+int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    dhmc_stepsize_search d{0.1, std::log(0.8), 400, 0};
+    if (p) d = *p;
+    if (!(std::isfinite(d.log_threshold) && d.log_threshold < 0)) return DHMC_ERR_INVALID_ARGUMENT;  // stepsize.jl:31
+    if (!(std::isfinite(d.initial_eps) && 0 < d.initial_eps)) return DHMC_ERR_INVALID_ARGUMENT;      // :32
+    if (!(d.maxiter_crossing >= 50)) return DHMC_ERR_INVALID_ARGUMENT;                                // :33
+    const int C = c->cfg.chains;
+    std::vector<double> h(C);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->st.eps, sizeof(double) * C, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (double e : h)
+        if (!std::isnan(e)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:137 "stepsize ϵ manually specified"
+    SearchParams P{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold,
+                   d.maxiter_crossing, c->st, c->tp};
+    int rc = dispatch(c, Op::Search, &P);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    return status_code(c);
+}
+
+int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {
+    if (!c || N < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (da) {
+        if (!(0 < da->delta && da->delta < 1)) return DHMC_ERR_INVALID_ARGUMENT;  // stepsize.jl:108
+        if (!(da->gamma > 0)) return DHMC_ERR_INVALID_ARGUMENT;                   // :109
+        if (!(0.5 < da->kappa && da->kappa <= 1)) return DHMC_ERR_INVALID_ARGUMENT;  // :110
+        if (!(da->t0 >= 0)) return DHMC_ERR_INVALID_ARGUMENT;                     // :111
+    }
+    const int C = c->cfg.chains, D = c->cfg.dim;
+    if (!da || da->init) {
+        std::vector<double> h(C);
+        HIP_TRY(c, hipMemcpyAsync(h.data(), c->st.eps, sizeof(double) * C, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (double e : h)
+            if (!(e > 0)) return DHMC_ERR_INVALID_ARGUMENT;  // stepsize.jl:135
+    }
+    c->last_ms = 0.0;
+    c->last_leapfrogs = 0;
+    if (N == 0) return status_code(c);
+
+    RunParams P{};
+    P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset;
+    P.max_depth = c->cfg.max_depth; P.nvec = c->nvec; P.min_delta = c->cfg.min_delta; P.seed = c->cfg.seed;
+    P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
+    if (da) {
+        P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
+        P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;
+    }
+    // outputs: device pointers pass through; host pointers are staged through temporaries
+    struct Field { void** dev; void* host; size_t bytes; };
+    std::vector<Field> staged;
+    const size_t CN = (size_t)C * N;
+    auto bind = [&](void* user, void** slot, size_t bytes) -> int {
+        *slot = nullptr;
+        if (!user) return DHMC_OK;
+        if (out->on_device) { *slot = user; return DHMC_OK; }
+        HIP_TRY(c, hipMalloc(slot, bytes));
+        staged.push_back({slot, user, bytes});
+        return DHMC_OK;
+    };
+    int rc = DHMC_OK;
+    if (out) {
+        if (!rc) rc = bind(out->draws, (void**)&P.out.draws, CN * D * sizeof(double));
+        if (!rc) rc = bind(out->logdensities, (void**)&P.out.logdensities, CN * sizeof(double));
+        if (!rc) rc = bind(out->eps, (void**)&P.out.eps, CN * sizeof(double));
+        if (!rc) rc = bind(out->pi, (void**)&P.out.pi, CN * sizeof(double));
+        if (!rc) rc = bind(out->acceptance_rate, (void**)&P.out.acceptance_rate, CN * sizeof(double));
+        if (!rc) rc = bind(out->steps, (void**)&P.out.steps, CN * sizeof(int64_t));
+        if (!rc) rc = bind(out->term_left, (void**)&P.out.term_left, CN * sizeof(int64_t));
+        if (!rc) rc = bind(out->term_right, (void**)&P.out.term_right, CN * sizeof(int64_t));
+        if (!rc) rc = bind(out->depth, (void**)&P.out.depth, CN * sizeof(int32_t));
+        if (!rc) rc = bind(out->directions, (void**)&P.out.directions, CN * sizeof(uint32_t));
+    }
+    auto cleanup = [&]() { for (auto& f : staged) if (*f.dev) (void)hipFree(*f.dev); };
+    if (rc) { cleanup(); return rc; }
+
+    hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
+    if (e == hipSuccess) {
+        rc = dispatch(c, Op::Run, &P);
+        if (rc) { cleanup(); return rc; }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+    if (e == hipSuccess)
+        for (auto& f : staged) {
+            e = hipMemcpyAsync(f.host, *f.dev, f.bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) break;
+        }
+    if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->last_ms = ms;
+    }
+    cleanup();
+    if (e != hipSuccess) { c->err = std::string("dhmc_run: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
+    return status_code(c);
+}
+
+int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
+    if (!c || !draws) return DHMC_ERR_INVALID_ARGUMENT;
+    if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192 (N >= 20 is the host wrapper's check)
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    Staged s;
+    int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * c->cfg.dim, on_device, &s);
+    if (rc) return rc;
+    launch_metric(c, (const double*)s.dev, n);
+    HIP_TRY(c, hipGetLastError());
+    stage_free(c, &s);
+    return DHMC_OK;
+}
+
+// ---- resume blob: header + raw images of the per-chain arrays -------------------------------
+struct BlobHeader {
+    uint64_t magic;
+    int32_t dim, chains, Dpad, reserved;
+};
+static const uint64_t BLOB_MAGIC = 0x31434d4844ull;  // "DHMC1"
+
+int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {
+    if (!c || !nbytes) return DHMC_ERR_INVALID_ARGUMENT;
+    const uint64_t C = c->cfg.chains, Dp = c->Dpad;
+    *nbytes = sizeof(BlobHeader) + 4 * C * Dp * sizeof(double) + 2 * C * sizeof(double) + C * sizeof(DAState) + 2 * C * sizeof(uint32_t);
+    return DHMC_OK;
+}
+
+static int blob_io(dhmc_ctx* c, char* blob, bool exporting) {
+    const size_t C = c->cfg.chains, Dp = c->Dpad;
+    char* p = blob + sizeof(BlobHeader);
+    auto io = [&](void* dev, size_t bytes) -> hipError_t {
+        hipError_t e = exporting ? hipMemcpy(p, dev, bytes, hipMemcpyDeviceToHost) : hipMemcpy(dev, p, bytes, hipMemcpyHostToDevice);
+        p += bytes;
+        return e;
+    };
+    HIP_TRY(c, io(c->st.q, C * Dp * sizeof(double)));
+    HIP_TRY(c, io(c->st.g, C * Dp * sizeof(double)));
+    HIP_TRY(c, io(c->st.minv, C * Dp * sizeof(double)));
+    HIP_TRY(c, io(c->st.W, C * Dp * sizeof(double)));
+    HIP_TRY(c, io(c->st.lq, C * sizeof(double)));
+    HIP_TRY(c, io(c->st.eps, C * sizeof(double)));
+    HIP_TRY(c, io(c->st.da, C * sizeof(DAState)));
+    HIP_TRY(c, io(c->st.transition, C * sizeof(uint32_t)));
+    HIP_TRY(c, io(c->st.status, C * sizeof(uint32_t)));
+    return DHMC_OK;
+}
+
+int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
+    uint64_t need;
+    if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BlobHeader h{BLOB_MAGIC, c->cfg.dim, c->cfg.chains, c->Dpad, 0};
+    std::memcpy(host_blob, &h, sizeof(h));
+    return blob_io(c, (char*)host_blob, true);
+}
+
+int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
+    uint64_t need;
+    if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
+    BlobHeader h;
+    std::memcpy(&h, host_blob, sizeof(h));
+    if (h.magic != BLOB_MAGIC || h.dim != c->cfg.dim || h.chains != c->cfg.chains || h.Dpad != c->Dpad) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return blob_io(c, const_cast<char*>((const char*)host_blob), false);
+}
+
+double dhmc_last_run_kernel_ms(const dhmc_ctx* c) { return c ? c->last_ms : 0.0; }
+uint64_t dhmc_last_run_leapfrogs(const dhmc_ctx* c) { return c ? c->last_leapfrogs : 0; }
+uint64_t dhmc_workspace_bytes(const dhmc_ctx* c) { return c ? c->ws_bytes : 0; }
+
+}  // extern "C"

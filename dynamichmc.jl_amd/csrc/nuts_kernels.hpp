@@ -1,0 +1,764 @@
+// HIP kernels of the many-chain NUTS hot path for MI355X (gfx950).  One wavefront = one chain.
+//
+// What runs here, per chain and per transition, is the body of the reference's per-draw loops
+// (src/mcmc.jl:271-280 and :374-379): sample_tree (src/NUTS.jl:232-241) — momentum refresh
+// (hamiltonian.jl:124), tree doubling (trees.jl:283-319) with the recursive adjacent_tree
+// (trees.jl:231-262) unrolled into an iterative binary-counter merge, leapfrog
+// (hamiltonian.jl:273-282), joint log density (hamiltonian.jl:251-256), the generalised
+// U-turn test (NUTS.jl:130-139), multinomial / biased progressive proposal selection
+// (trees.jl:143-161, NUTS.jl:43-53), the acceptance statistic (NUTS.jl:59-89) — followed by
+// the dual-averaging update (stepsize.jl:147-156).
+//
+// Mapping to the machine
+//  * lane l of the chain's wave owns coordinates l, l+64, ... of every D-vector (wave.hpp);
+//    the phase point being integrated (q, p, ∇ℓ) and the running subtree summary of the
+//    merge cascade (first momentum, Σp) stay in VGPRs across leapfrog steps; control flow
+//    (direction, depth, validity, accept) is wave-uniform and runs on the scalar unit.
+//  * per-chain diagonal M⁻¹ is staged once per launch in LDS;
+//  * suspended subtree summaries (one per set bit of the leaf counter), the two trajectory
+//    edges and the candidate proposals live in a per-chain HBM workspace that is touched
+//    LIFO, so it is served by L2 / Infinity Cache.  Proposals are never copied: a merge
+//    picks a slot index (the reference's pointer selection, NUTS.jl:52), and a leaf's
+//    position is written to a slot only if it survives its whole merge cascade.
+//  * dot products: NPL lane-local fma's + one batched 64-lane butterfly per group of dots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dhmc.h"
+#include "../../include/dhmc_detmath.h"
+#include "philox_dev.hpp"
+#include "targets.hpp"
+#include "wave.hpp"
+
+namespace dhmc {
+
+// DualAveragingState (stepsize.jl:121-127)
+struct DAState {
+    double mu;
+    double Hbar;
+    double logeps;
+    double logeps_bar;
+    int64_t m;
+};
+
+struct DeviceOutputs {
+    double* draws;
+    double* logdensities;
+    double* eps;
+    double* pi;
+    double* acceptance_rate;
+    int64_t* steps;
+    int64_t* term_left;
+    int64_t* term_right;
+    int32_t* depth;
+    uint32_t* directions;
+};
+
+struct ChainArrays {
+    double* q;       // [C][Dpad]
+    double* g;       // [C][Dpad]
+    double* lq;      // [C]
+    double* minv;    // [C][Dpad]  pads = 1
+    double* W;       // [C][Dpad]  sqrt(1/minv), pads = 0
+    double* eps;     // [C]
+    DAState* da;     // [C]
+    uint32_t* transition;  // [C]
+    uint32_t* status;      // [C]
+    double* ws;      // [C][nvec][Dpad] workspace
+};
+
+struct RunParams {
+    int D, Dpad, C, chain_offset, max_depth, nvec;
+    double min_delta;
+    uint64_t seed;
+    int64_t N;
+    ChainArrays st;
+    int adapt, da_init, da_finalize, t0;
+    double delta, gamma, kappa;
+    DeviceOutputs out;
+    TargetParams tp;
+    unsigned long long* leapfrog_counter;  // total leapfrog steps of the launch (may be null)
+};
+
+// workspace vector indices (units of Dpad doubles inside one chain's block)
+__host__ __device__ inline int ws_p0() { return 0; }
+__host__ __device__ inline int ws_edge(int dir, int which) { return 1 + 3 * dir + which; }  // which: 0 q, 1 p, 2 g
+__host__ __device__ inline int ws_rho_top() { return 7; }
+__host__ __device__ inline int ws_stack(int level, int which) { return 8 + 3 * level + which; }  // 0 first, 1 last, 2 rho
+__host__ __device__ inline int ws_slot(int max_depth, int s, int which) { return 8 + 3 * max_depth + 2 * s + which; }  // 0 q, 1 g
+__host__ __device__ inline int ws_nslots(int max_depth) { return max_depth + 3; }
+__host__ __device__ inline int ws_nvec(int max_depth) { return 8 + 3 * max_depth + 2 * ws_nslots(max_depth); }
+
+// LDS carve (one wave per block): m[Dpad] then per-level and per-slot scalars
+constexpr int LDS_LEVELS = 32;
+constexpr int LDS_SLOTS = 36;
+__host__ __device__ inline size_t lds_bytes(int Dpad) {
+    return sizeof(double) * ((size_t)Dpad + 3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
+}
+
+__device__ __forceinline__ double joint_logdensity(double lq, double K) {  // hamiltonian.jl:251-256
+    if (!dm_isfinite(lq)) return -dm_inf();
+    return lq - (dm_isfinite(K) ? K : dm_inf());
+}
+
+// evaluate_ℓ(ℓ, q) (hamiltonian.jl:202-217) + the kinetic part of logdensity for the point
+// (q, p): returns ℓq after the -Inf demotion rules and K = p·M⁻¹p / 2.  `p` must already be
+// the full-step momentum computed from g.  Sets *pos_bad when the position has a non-finite
+// coordinate (the reference throws there, :203).
+template <class T, int NPL>
+__device__ __forceinline__ void eval_point(const T& tgt, const double* __restrict__ m_lds, int lane, int D,
+                                           const double (&q)[NPL], double (&g)[NPL], double& lpart_or_lq,
+                                           bool& pos_finite, bool& grad_finite) {
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) fin = fin && dm_isfinite(q[k]);
+    pos_finite = wave_all(fin);
+    lpart_or_lq = tgt.eval(q, g, lane, D);
+    if constexpr (!T::kGradFiniteIfPosFinite) {
+        bool gf = true;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) gf = gf && dm_isfinite(g[k]);
+        grad_finite = wave_all(gf);
+    } else {
+        grad_finite = true;
+    }
+}
+
+__device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool grad_finite) {
+    if (!pos_finite) return -dm_inf();
+    bool ok = (dm_isfinite(lq) && grad_finite) || lq == -dm_inf();
+    return ok ? lq : -dm_inf();
+}
+
+// One leapfrog step in registers (hamiltonian.jl:273-282) followed by the leaf's joint log
+// density.  eps is signed (backward motion = negative ϵ, NUTS.jl:30).
+template <class T, int NPL>
+__device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __restrict__ m_lds, int lane, int D,
+                                              double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
+                                              double eps, double& lq_out, double& pi_out, bool& pos_finite) {
+    const double h = eps / 2;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        double pm = p[k] + h * g[k];                 // :277
+        double t = m_lds[lane + WAVE * k] * pm;      // ∇kinetic_energy(κ, pₘ) = M⁻¹ pₘ
+        q[k] = q[k] + eps * t;                       // :278
+        p[k] = pm;
+    }
+    double lres;
+    bool gfin;
+    eval_point<T, NPL>(tgt, m_lds, lane, D, q, g, lres, pos_finite, gfin);   // :279
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        p[k] = p[k] + h * g[k];                      // :280
+        double ps = m_lds[lane + WAVE * k] * p[k];   // p♯ = M⁻¹ p'
+        kacc = __builtin_fma(p[k], ps, kacc);
+    }
+    double lq, K;
+    if constexpr (T::kDeferred) {
+        double r[2] = {lres, kacc};
+        wave_allreduce<2>(r);
+        lq = tgt.finish(r[0]);
+        K = r[1] / 2.0;
+    } else {
+        lq = lres;
+        K = wave_allreduce1(kacc) / 2.0;
+    }
+    lq = demote_lq(lq, pos_finite, gfin);
+    lq_out = uni_f64(lq);
+    pi_out = uni_f64(joint_logdensity(lq, K));
+}
+
+// combine_turn_statistics (NUTS.jl:132-139) of a suspended summary L (memory; build order:
+// first, last, rho) with the running summary cur (registers: cf = first, p = last, cr = rho),
+// time-ordered by the build direction (trees.jl:135-141).  Returns turning; on return
+// cf/cr hold the merged summary's first momentum and ρ (its last momentum is still p).
+template <int NPL, bool FWD, bool LEAFL>
+__device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const double* __restrict__ Ll,
+                                           const double* __restrict__ Lr, const double* __restrict__ m_lds,
+                                           int lane, double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double lf = Lf[e];
+        const double ll = LEAFL ? lf : Ll[e];
+        const double lr = LEAFL ? lf : Lr[e];
+        const double mk = m_lds[e];
+        // x = earlier in time, y = later:  (p₋, p₊, ρ)
+        const double xm = FWD ? lf : p[k], xp = FWD ? ll : cf[k], xr = FWD ? lr : cr[k];
+        const double ym = FWD ? cf[k] : ll, yp = FWD ? p[k] : lf, yr = FWD ? cr[k] : lr;
+        const double s1 = xr + ym;      // x.ρ + y.p₋      (:134)
+        const double s2 = xp + yr;      // x.p₊ + y.ρ      (:135)
+        const double r = xr + yr;       // ρ               (:136)
+        const double a = mk * xm;       // x.p♯₋
+        const double b = mk * ym;       // y.p♯₋
+        const double c = mk * xp;       // x.p♯₊
+        const double d = mk * yp;       // y.p♯₊
+        acc[0] = __builtin_fma(a, s1, acc[0]);
+        acc[1] = __builtin_fma(b, s1, acc[1]);
+        acc[2] = __builtin_fma(c, s2, acc[2]);
+        acc[3] = __builtin_fma(d, s2, acc[3]);
+        acc[4] = __builtin_fma(a, r, acc[4]);
+        acc[5] = __builtin_fma(d, r, acc[5]);
+        cf[k] = lf;
+        cr[k] = r;
+    }
+    wave_allreduce<6>(acc);
+    return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
+}
+
+template <int NPL>
+__device__ __forceinline__ bool merge_turn_dispatch(bool fwd, bool leafL, const double* Lf, const double* Ll,
+                                                    const double* Lr, const double* m_lds, int lane,
+                                                    double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
+    if (fwd) {
+        if (leafL) return merge_turn<NPL, true, true>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        return merge_turn<NPL, true, false>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    }
+    if (leafL) return merge_turn<NPL, false, true>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    return merge_turn<NPL, false, false>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+}
+
+// p = W .* randn (hamiltonian.jl:124) from the chain's stream.
+template <int NPL>
+__device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t purpose, uint32_t transition,
+                                                const double* __restrict__ Wrow, int lane, double (&p)[NPL]) {
+#pragma unroll
+    for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+        uint64_t r1, r2;
+        stream_raw64(key, (uint32_t)(lane + WAVE * kk), purpose, transition, r1, r2);
+        double z0, z1;
+        det_randn2(r1, r2, &z0, &z1);
+        p[2 * kk] = Wrow[lane + WAVE * (2 * kk)] * z0;
+        if (2 * kk + 1 < NPL) p[2 * kk + 1] = Wrow[lane + WAVE * (2 * kk + 1)] * z1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The per-draw loop kernel.
+// ------------------------------------------------------------------------------------------
+template <class T, int NPL>
+__global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
+    const int chain = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int D = P.D, Dpad = P.Dpad;
+
+    extern __shared__ double lds[];
+    double* m_lds = lds;                              // [Dpad]
+    double* lv_omega = lds + Dpad;                    // [LDS_LEVELS]
+    double* lv_vlsa = lv_omega + LDS_LEVELS;
+    double* lv_vsteps = lv_vlsa + LDS_LEVELS;
+    double* sl_lq = lv_vsteps + LDS_LEVELS;           // [LDS_SLOTS]
+    double* sl_pi = sl_lq + LDS_SLOTS;
+    int* lv_zeta = (int*)(sl_pi + LDS_SLOTS);         // [LDS_LEVELS]
+
+    const T tgt(P.tp);
+    const size_t row = (size_t)chain * Dpad;
+    double* const ws = P.st.ws + (size_t)chain * P.nvec * Dpad;
+    auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
+
+    {
+        const double* mrow = P.st.minv + row;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) m_lds[lane + WAVE * k] = mrow[lane + WAVE * k];
+    }
+    const double* Wrow = P.st.W + row;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+    const int max_depth = P.max_depth;
+    const int nslots = ws_nslots(max_depth);
+
+    double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
+    ldv<NPL>(P.st.q + row, lane, q);
+    ldv<NPL>(P.st.g + row, lane, g);
+    double lq_cur = P.st.lq[chain];
+    double eps_fixed = P.st.eps[chain];
+    DAState da = P.st.da[chain];
+    uint32_t status = P.st.status[chain];
+    const uint32_t tr0 = P.st.transition[chain];
+    unsigned long long total_steps = 0;
+
+    if (P.adapt && P.da_init) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
+        double le = det_log(eps_fixed);
+        da.mu = det_log(10.0) + le;
+        da.m = 1;
+        da.Hbar = 0.0;
+        da.logeps = le;
+        da.logeps_bar = 0.0;
+    }
+
+    // the chain's current position occupies proposal slot `init_slot` of the workspace
+    int init_slot = 0;
+    stv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
+    stv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+
+    for (int64_t n = 0; n < P.N; ++n) {
+        const uint32_t tr = tr0 + (uint32_t)n;
+        const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
+
+        // ---- sample_tree (NUTS.jl:232-241): p, directions, π₀ --------------------------
+        sample_momentum<NPL>(key, PURPOSE_MOMENTUM, tr, Wrow, lane, p);
+        uint32_t dirs;
+        {
+            uint32_t w[4];
+            philox4x32_10(0u, PURPOSE_DIRECTIONS, tr, key.seed_hi, key.k0, key.k1, w);
+            dirs = uni_u32(w[0]);
+        }
+        const uint32_t directions0 = dirs;
+        double pi0;
+        {
+            double kacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], m_lds[lane + WAVE * k] * p[k], kacc);
+            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
+        }
+        stv<NPL>(wsv(ws_p0()), lane, p);
+        sl_lq[init_slot] = lq_cur;
+        sl_pi[init_slot] = pi0;
+
+        // ---- sample_trajectory (trees.jl:283-319) ---------------------------------------
+        int eq[2], ep[2], eg[2];  // workspace vector indices of the two edges z₋ (0), z₊ (1)
+        eq[0] = eq[1] = ws_slot(max_depth, init_slot, 0);
+        ep[0] = ep[1] = ws_p0();
+        eg[0] = eg[1] = ws_slot(max_depth, init_slot, 1);
+        int rho_idx = ws_p0();
+        int reg_edge = 2;  // which edge the registers (q,p,g) hold: 0, 1 or 2 = both
+        uint64_t free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
+        int zeta_top = init_slot;
+        double omega_top = 0.0;
+        double vtop_lsa = -dm_inf();
+        int64_t vtop_steps = 0;
+        int depth = 0;
+        int64_t i_minus = 0, i_plus = 0;
+        int64_t term_left = 1, term_right = 0;  // REACHED_MAX_DEPTH
+        uint32_t nrand = 0;
+
+        auto randexp = [&]() -> double {  // Random.randexp at NUTS.jl:44
+            uint64_t r1, r2;
+            stream_raw64(key, nrand++, PURPOSE_TREE, tr, r1, r2);
+            return uni_f64(det_randexp(r1));
+        };
+        auto alloc_slot = [&]() -> int {
+            int s = __builtin_ctzll(free_mask);
+            free_mask &= ~(1ull << s);
+            return s;
+        };
+
+        bool finished = false;
+        while (!finished && depth < max_depth) {
+            const bool fwd = (dirs & 1u) != 0;  // next_direction (trees.jl:31-34)
+            dirs >>= 1;
+            const int dir = fwd ? 1 : 0;
+            if (reg_edge != 2 && reg_edge != dir) {
+                ldv<NPL>(wsv(eq[dir]), lane, q);
+                ldv<NPL>(wsv(ep[dir]), lane, p);
+                ldv<NPL>(wsv(eg[dir]), lane, g);
+            }
+            int64_t i = fwd ? i_plus : i_minus;
+            const int64_t di = fwd ? 1 : -1;
+            const double eps_s = fwd ? eps : -eps;
+            const uint32_t nleaf = 1u << depth;
+
+            // ---- adjacent_tree(rng, trajectory, z, i, depth, is_forward), iteratively ----
+            bool invalid = false;
+            double v_lsa = 0.0;       // visited statistic of the running subtree
+            int64_t v_steps = 0;
+            for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
+                double lq_leaf, pi_leaf;
+                bool pos_finite;
+                leapfrog_leaf<T, NPL>(tgt, m_lds, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite);
+                if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
+                i += di;
+                total_steps += 1;
+                const double delta = pi_leaf - pi0;             // NUTS.jl:150
+                v_lsa = delta < 0.0 ? delta : 0.0;              // min(Δ, 0)   (NUTS.jl:79)
+                v_steps = 1;
+                int level = 0;
+                if (delta < P.min_delta) {                      // divergent leaf (NUTS.jl:151; trees.jl:236-237)
+                    term_left = term_right = i;
+                    invalid = true;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) { cf[k] = p[k]; cr[k] = p[k]; }
+                    double c_omega = delta;
+                    int c_zeta = -1;  // -1: the proposal is the leaf held in registers
+                    for (;;) {
+                        const bool sub = ((j >> level) & 1u) != 0;
+                        const bool top = !sub && (j == nleaf - 1) && (level == depth);
+                        if (!sub && !top) break;
+                        const double *Lf, *Ll, *Lr;
+                        bool leafL;
+                        if (sub) {
+                            Lf = wsv(ws_stack(level, 0)); Ll = wsv(ws_stack(level, 1)); Lr = wsv(ws_stack(level, 2));
+                            leafL = (level == 0);
+                        } else {
+                            Lf = wsv(ep[1 - dir]); Ll = wsv(ep[dir]); Lr = wsv(rho_idx);
+                            leafL = (depth == 0);
+                        }
+                        const bool turning = merge_turn_dispatch<NPL>(fwd, leafL, Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+                        if (sub) {
+                            // v = v₋ ⊕ v₊ (trees.jl:249)
+                            v_lsa = uni_f64(det_logaddexp(lv_vlsa[level], v_lsa));
+                            v_steps += (int64_t)lv_vsteps[level];
+                            if (turning) {                       // trees.jl:255
+                                term_left = i - di * (((int64_t)2 << level) - 1);
+                                term_right = i;
+                                invalid = true;
+                                level += 1;
+                                break;
+                            }
+                            // combine_proposals_and_logweights(…, is_doubling = false) (trees.jl:258)
+                            const double wl = lv_omega[level];
+                            const double w = uni_f64(det_logaddexp(wl, c_omega));
+                            const double logprob2 = c_omega - w;
+                            const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
+                            const int lz = lv_zeta[level];
+                            if (pick) {
+                                free_mask |= (1ull << lz);
+                            } else {
+                                if (c_zeta >= 0) free_mask |= (1ull << c_zeta);
+                                c_zeta = lz;
+                            }
+                            c_omega = w;
+                            level += 1;
+                        } else {
+                            // top level (trees.jl:294-316)
+                            vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));
+                            vtop_steps += v_steps;
+                            const double w = uni_f64(det_logaddexp(omega_top, c_omega));
+                            const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
+                            const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
+                            if (pick) {
+                                if (c_zeta < 0) {
+                                    c_zeta = alloc_slot();
+                                    stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 0)), lane, q);
+                                    stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 1)), lane, g);
+                                    sl_lq[c_zeta] = lq_leaf;
+                                    sl_pi[c_zeta] = pi_leaf;
+                                }
+                                if (zeta_top != init_slot) free_mask |= (1ull << zeta_top);
+                                zeta_top = c_zeta;
+                            } else if (c_zeta >= 0) {
+                                free_mask |= (1ull << c_zeta);
+                            }
+                            omega_top = w;
+                            depth += 1;
+                            if (fwd) i_plus = i; else i_minus = i;
+                            if (turning) {                       // trees.jl:315-316
+                                term_left = i_minus;
+                                term_right = i_plus;
+                                finished = true;
+                            } else if (depth < max_depth) {
+                                // the new edge and Σp of the whole trajectory
+                                eq[dir] = ws_edge(dir, 0); ep[dir] = ws_edge(dir, 1); eg[dir] = ws_edge(dir, 2);
+                                stv<NPL>(wsv(eq[dir]), lane, q);
+                                stv<NPL>(wsv(ep[dir]), lane, p);
+                                stv<NPL>(wsv(eg[dir]), lane, g);
+                                stv<NPL>(wsv(ws_rho_top()), lane, cr);
+                                rho_idx = ws_rho_top();
+                            }
+                            reg_edge = dir;
+                            level = -1;  // handled
+                            break;
+                        }
+                    }
+                    if (level >= 0 && !invalid) {
+                        // suspend the running subtree at `level` until its right sibling is built
+                        if (c_zeta < 0) {
+                            c_zeta = alloc_slot();
+                            stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 0)), lane, q);
+                            stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 1)), lane, g);
+                            sl_lq[c_zeta] = lq_leaf;
+                            sl_pi[c_zeta] = pi_leaf;
+                        }
+                        if (level == 0) {
+                            stv<NPL>(wsv(ws_stack(0, 0)), lane, p);
+                        } else {
+                            stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
+                            stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
+                            stv<NPL>(wsv(ws_stack(level, 2)), lane, cr);
+                        }
+                        lv_omega[level] = c_omega;
+                        lv_vlsa[level] = v_lsa;
+                        lv_vsteps[level] = (double)v_steps;
+                        lv_zeta[level] = c_zeta;
+                    }
+                }
+                if (invalid) {
+                    // unwind the recursion: every suspended left sibling contributes its visited
+                    // statistic (trees.jl:244,249-250)
+                    for (int l2 = level; l2 < depth; ++l2) {
+                        if ((j >> l2) & 1u) {
+                            v_lsa = uni_f64(det_logaddexp(lv_vlsa[l2], v_lsa));
+                            v_steps += (int64_t)lv_vsteps[l2];
+                        }
+                    }
+                    vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));   // trees.jl:294
+                    vtop_steps += v_steps;
+                    finished = true;                                       // trees.jl:297
+                }
+            }
+        }
+
+        // ---- TreeStatisticsNUTS and the new position (NUTS.jl:238-240) -----------------
+        const double acc_rate = [&]() {
+            double a = det_exp(vtop_lsa) / (double)vtop_steps;             // NUTS.jl:87
+            return uni_f64(a < 1.0 ? a : 1.0);
+        }();
+        init_slot = zeta_top;
+        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
+        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+        lq_cur = uni_f64(sl_lq[init_slot]);
+        const double pi_stat = uni_f64(sl_pi[init_slot]);
+
+        const size_t o = (size_t)chain * P.N + n;
+        if (P.out.draws) {
+            double* drow = P.out.draws + o * D;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];     // mcmc.jl:275,376
+        }
+        if (lane == 0) {
+            if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
+            if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273
+            if (P.out.pi) P.out.pi[o] = pi_stat;
+            if (P.out.acceptance_rate) P.out.acceptance_rate[o] = acc_rate;
+            if (P.out.steps) P.out.steps[o] = vtop_steps;
+            if (P.out.term_left) P.out.term_left[o] = term_left;
+            if (P.out.term_right) P.out.term_right[o] = term_right;
+            if (P.out.depth) P.out.depth[o] = depth;
+            if (P.out.directions) P.out.directions[o] = directions0;
+        }
+
+        if (P.adapt) {  // adapt_stepsize (stepsize.jl:147-156)
+            da.m += 1;
+            const double m = (double)da.m;
+            da.Hbar += (P.delta - acc_rate - da.Hbar) / (m + (double)P.t0);
+            da.logeps = da.mu - __builtin_sqrt(m) / P.gamma * da.Hbar;
+            da.logeps_bar += det_pow_pos(m, -P.kappa) * (da.logeps - da.logeps_bar);
+        }
+    }
+
+    // ---- write the chain back (WarmupState + adaptation state) --------------------------
+    stv<NPL>(P.st.q + row, lane, q);
+    stv<NPL>(P.st.g + row, lane, g);
+    if (lane == 0) {
+        P.st.lq[chain] = lq_cur;
+        if (P.adapt) {
+            P.st.da[chain] = da;
+            if (P.da_finalize) P.st.eps[chain] = det_exp(da.logeps_bar);   // final_ϵ (stepsize.jl:170; mcmc.jl:285)
+        }
+        P.st.transition[chain] = tr0 + (uint32_t)P.N;
+        P.st.status[chain] = status;
+        if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// initialize_warmup_state (mcmc.jl:129-132): position (given or random_position, mcmc.jl:108),
+// strict evaluate_ℓ (hamiltonian.jl:202-217).
+// ------------------------------------------------------------------------------------------
+struct InitParams {
+    int D, Dpad, C, chain_offset;
+    uint64_t seed;
+    const double* q0;  // [C][D] unpadded device pointer, or null for random
+    ChainArrays st;
+    TargetParams tp;
+};
+
+template <class T, int NPL>
+__global__ __launch_bounds__(64) void init_kernel(InitParams P) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int D = P.D, Dpad = P.Dpad;
+    const T tgt(P.tp);
+    const size_t row = (size_t)chain * Dpad;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+    double q[NPL], g[NPL];
+    if (P.q0) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            int e = lane + WAVE * k;
+            q[k] = e < D ? P.q0[(size_t)chain * D + e] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+            uint64_t r1, r2;
+            stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_INIT_POSITION, 0u, r1, r2);
+            int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
+            q[2 * kk] = e0 < D ? u01_closed_open(r1) * 4 - 2 : 0.0;
+            if (2 * kk + 1 < NPL) q[2 * kk + 1] = e1 < D ? u01_closed_open(r2) * 4 - 2 : 0.0;
+        }
+    }
+    double lres;
+    bool pfin, gfin;
+    eval_point<T, NPL>(tgt, nullptr, lane, D, q, g, lres, pfin, gfin);
+    double lq = T::kDeferred ? tgt.finish(wave_allreduce1(lres)) : lres;
+    uint32_t status = 0;
+    if (!pfin) {
+        status |= DHMC_ST_NONFINITE_POSITION;
+        lq = -dm_inf();
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] = 0.0;
+    } else {
+        bool ok = (dm_isfinite(lq) && gfin) || lq == -dm_inf();
+        if (!ok) {  // strict: the reference throws (hamiltonian.jl:212-216)
+            status |= DHMC_ST_INVALID_INITIAL;
+            lq = -dm_inf();
+        }
+    }
+    stv<NPL>(P.st.q + row, lane, q);
+    stv<NPL>(P.st.g + row, lane, g);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        int e = lane + WAVE * k;
+        P.st.minv[row + e] = 1.0;                 // GaussianKineticEnergy(N) (hamiltonian.jl:87)
+        P.st.W[row + e] = e < D ? 1.0 : 0.0;
+    }
+    if (lane == 0) {
+        P.st.lq[chain] = lq;
+        P.st.eps[chain] = dm_nan();               // ϵ = nothing (mcmc.jl:130)
+        P.st.transition[chain] = 0;
+        P.st.status[chain] = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// warmup(::InitialStepsizeSearch) (mcmc.jl:134-148): z = (Q, rand_p), then
+// find_initial_stepsize (stepsize.jl:46-60) on A(ϵ) = logdensity(leapfrog(z, ϵ)) - logdensity(z)
+// (stepsize.jl:75-85).
+// ------------------------------------------------------------------------------------------
+struct SearchParams {
+    int D, Dpad, C, chain_offset;
+    uint64_t seed;
+    double initial_eps, log_threshold;
+    int maxiter;
+    ChainArrays st;
+    TargetParams tp;
+};
+
+template <class T, int NPL>
+__global__ __launch_bounds__(64) void stepsize_search_kernel(SearchParams P) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int D = P.D, Dpad = P.Dpad;
+    extern __shared__ double lds[];
+    double* m_lds = lds;
+    const T tgt(P.tp);
+    const size_t row = (size_t)chain * Dpad;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) m_lds[lane + WAVE * k] = P.st.minv[row + lane + WAVE * k];
+    double q0[NPL], p0[NPL], g0[NPL], q[NPL], p[NPL], g[NPL];
+    ldv<NPL>(P.st.q + row, lane, q0);
+    ldv<NPL>(P.st.g + row, lane, g0);
+    const double lq0 = P.st.lq[chain];
+    uint32_t status = P.st.status[chain];
+    sample_momentum<NPL>(key, PURPOSE_SEARCH_MOMENTUM, P.st.transition[chain], P.st.W + row, lane, p0);
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p0[k], m_lds[lane + WAVE * k] * p0[k], kacc);
+    const double l0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc) / 2.0));
+    if (!dm_isfinite(l0)) {  // stepsize.jl:77-79
+        if (lane == 0) P.st.status[chain] = status | DHMC_ST_NONFINITE_START_DENSITY;
+        return;
+    }
+    auto A = [&](double eps) -> double {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { q[k] = q0[k]; p[k] = p0[k]; g[k] = g0[k]; }
+        double lq1, pi1;
+        bool pfin;
+        leapfrog_leaf<T, NPL>(tgt, m_lds, lane, D, q, p, g, eps, lq1, pi1, pfin);
+        if (!pfin) status |= DHMC_ST_NONFINITE_POSITION;
+        return pi1 - l0;
+    };
+    double eps = P.initial_eps;
+    const double Ae = A(eps);
+    const bool dbl = Ae > P.log_threshold;
+    bool found = false;
+    for (int it = 0; it < P.maxiter; ++it) {
+        const double eps1 = dbl ? 2 * eps : eps / 2;
+        const double Ae1 = A(eps1);
+        if (dbl ? (Ae1 < P.log_threshold) : (Ae1 > P.log_threshold)) {
+            eps = eps1;
+            found = true;
+            break;
+        }
+        eps = eps1;
+    }
+    if (!found) status |= DHMC_ST_STEPSIZE_SEARCH_FAILED;  // stepsize.jl:57-59
+    if (lane == 0) {
+        P.st.eps[chain] = eps;
+        P.st.status[chain] = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// End-of-stage metric: κ = GaussianKineticEnergy(Diagonal(var(posterior_matrix; dims=2)))
+// (mcmc.jl:209,281-284; hamiltonian.jl:80) per chain from its own draws [C][N][D].
+// Statistics.var with dims reduces sequentially over draws: mean = (Σx)/n, Σ(x-mean)²/(n-1).
+// ------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(64) void metric_diag_kernel(int D, int Dpad, int64_t N, const double* __restrict__ draws,
+                                                         double* __restrict__ minv, double* __restrict__ W) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const double* base = draws + (size_t)chain * N * D;
+    double s[NPL], ss[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { s[k] = 0.0; ss[k] = 0.0; }
+    for (int64_t i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            int e = lane + WAVE * k;
+            if (e < D) s[k] = s[k] + base[(size_t)i * D + e];
+        }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) s[k] = s[k] / (double)N;
+    for (int64_t i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            int e = lane + WAVE * k;
+            if (e < D) {
+                double d = base[(size_t)i * D + e] - s[k];
+                ss[k] = ss[k] + d * d;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        int e = lane + WAVE * k;
+        size_t o = (size_t)chain * Dpad + e;
+        if (e < D) {
+            double var = ss[k] / (double)(N - 1);
+            minv[o] = var;
+            W[o] = __builtin_sqrt(1.0 / var);
+        } else {
+            minv[o] = 1.0;
+            W[o] = 0.0;
+        }
+    }
+}
+
+// Set M⁻¹ from a user array (GaussianKineticEnergy(Diagonal), hamiltonian.jl:80)
+__global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __restrict__ src, int per_chain,
+                                       double* __restrict__ minv, double* __restrict__ W) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * Dpad) return;
+    int c = (int)(idx / Dpad), e = (int)(idx % Dpad);
+    if (e < D) {
+        double m = src[per_chain ? (size_t)c * D + e : (size_t)e];
+        minv[idx] = m;
+        W[idx] = __builtin_sqrt(1.0 / m);
+    } else {
+        minv[idx] = 1.0;
+        W[idx] = 0.0;
+    }
+}
+
+// padded [C][Dpad] <-> unpadded [C][D]
+__global__ void unpad_kernel(int D, int Dpad, int C, const double* __restrict__ src, double* __restrict__ dst) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * D) return;
+    int c = (int)(idx / D), e = (int)(idx % D);
+    dst[idx] = src[(size_t)c * Dpad + e];
+}
+
+}  // namespace dhmc

@@ -1,0 +1,37 @@
+// Philox4x32-10 on the device and the dhmc stream convention (include/dhmc.h): key =
+// (seed lo, global chain index), counter = (index, purpose, transition, seed hi).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dhmc {
+
+enum : uint32_t { PURPOSE_MOMENTUM = 0, PURPOSE_DIRECTIONS = 1, PURPOSE_TREE = 2,
+                  PURPOSE_SEARCH_MOMENTUM = 3, PURPOSE_INIT_POSITION = 4 };
+
+struct ChainKey {
+    uint32_t k0, k1, seed_hi;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void stream_raw64(const ChainKey& key, uint32_t index, uint32_t purpose,
+                                              uint32_t transition, uint64_t& r1, uint64_t& r2) {
+    uint32_t w[4];
+    philox4x32_10(index, purpose, transition, key.seed_hi, key.k0, key.k1, w);
+    r1 = ((uint64_t)w[1] << 32) | w[0];
+    r2 = ((uint64_t)w[3] << 32) | w[2];
+}
+
+}  // namespace dhmc

@@ -1,0 +1,143 @@
+// Device-side log densities: the stand-in for the user's
+// LogDensityProblems.logdensity_and_gradient (reference src/hamiltonian.jl:204), evaluated
+// inside the leapfrog with no host round trip.  One functor per DHMC_TARGET_* family
+// (include/dhmc.h); the arithmetic order of each is part of its definition and is the same as
+// the CPU definition the parity tests check against.
+//
+// Interface (q, g are the lane's NPL slots of the padded vectors; pads hold 0):
+//   double eval(q, g, lane, D)   fills g = ∇ℓ(q) and returns either the lane's partial sum of
+//                                the reduction that gives ℓ (kDeferred = true; the caller
+//                                batches the wave reduction with the kinetic energy's and then
+//                                calls finish()), or ℓ itself (kDeferred = false).
+//   kGradFiniteIfPosFinite       a finite position implies (ℓ finite or -Inf) and, when ℓ is
+//                                finite, a finite gradient: the ∇ℓ scan of evaluate_ℓ
+//                                (src/hamiltonian.jl:205) cannot change the outcome and is skipped.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/dhmc_detmath.h"
+#include "wave.hpp"
+
+namespace dhmc {
+
+struct TargetParams {
+    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      (padded to Dpad, device)
+    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off
+    int64_t n;
+};
+
+struct StdNormalT {
+    static constexpr bool kDeferred = true;
+    static constexpr bool kGradFiniteIfPosFinite = true;
+    __device__ explicit StdNormalT(const TargetParams&) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int, int) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            acc = __builtin_fma(q[k], q[k], acc);
+            g[k] = -q[k];
+        }
+        return acc;
+    }
+    __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
+};
+
+struct DiagNormalT {
+    static constexpr bool kDeferred = true;
+    static constexpr bool kGradFiniteIfPosFinite = true;
+    const double* mu;
+    const double* prec;
+    __device__ explicit DiagNormalT(const TargetParams& p) : mu(p.a), prec(p.b) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            double d = q[k] - mu[lane + WAVE * k];
+            double w = prec[lane + WAVE * k] * d;
+            acc = __builtin_fma(d, w, acc);
+            g[k] = -w;
+        }
+        return acc;
+    }
+    __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
+};
+
+// ℓ = -1/2 q'Pq, P symmetric tridiagonal: (Pq)_i = diag_i q_i + off_{i-1} q_{i-1} + off_i q_{i+1}
+struct TridiagNormalT {
+    static constexpr bool kDeferred = true;
+    static constexpr bool kGradFiniteIfPosFinite = true;
+    const double* diag;
+    const double* off;
+    __device__ explicit TridiagNormalT(const TargetParams& p) : diag(p.a), off(p.b) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            int e = lane + WAVE * k;
+            // neighbours: e-1 is lane-1 of this slot (lane 63 of slot k-1 for lane 0), e+1 likewise
+            double left_same = __shfl_up(q[k], 1);
+            double left_prev = (k > 0) ? __shfl(q[k > 0 ? k - 1 : 0], WAVE - 1) : 0.0;
+            double qm = (lane == 0) ? left_prev : left_same;
+            double right_same = __shfl_down(q[k], 1);
+            double right_next = (k + 1 < NPL) ? __shfl(q[k + 1 < NPL ? k + 1 : k], 0) : 0.0;
+            double qp = (lane == WAVE - 1) ? right_next : right_same;
+            double t = diag[e] * q[k];
+            if (e > 0 && e < D) t = t + off[e - 1] * qm;
+            if (e < D - 1) t = t + off[e] * qp;
+            acc = __builtin_fma(q[k], t, acc);
+            g[k] = -t;
+        }
+        return acc;
+    }
+    __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
+};
+
+// Neal's funnel: v = q_0 ~ N(0, 3²), q_i | v ~ N(0, e^v):
+//   ℓ = -v²/18 - 1/2 e^{-v} Σ_{i>=1} q_i² - (D-1)/2 v
+struct FunnelT {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kGradFiniteIfPosFinite = false;
+    __device__ explicit FunnelT(const TargetParams&) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        double v = readlane_f64(q[0], 0);
+        double ev = det_exp(-v);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            double x = (k == 0 && lane == 0) ? 0.0 : q[k];
+            acc = __builtin_fma(x, x, acc);
+        }
+        double S = wave_allreduce1(acc);
+        double hd = 0.5 * (double)(D - 1);
+        double hes = (0.5 * ev) * S;
+        double lq = ((-(v * v) / 18.0) - hes) - hd * v;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] = -(ev * q[k]);
+        if (lane == 0) g[0] = ((-v / 9.0) + hes) - hd;
+        return lq;
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+
+// The reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)
+struct AlwaysDivergentT {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kGradFiniteIfPosFinite = true;
+    __device__ explicit AlwaysDivergentT(const TargetParams&) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        bool zero = true;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            g[k] = (lane + WAVE * k < D) ? 1.0 : 0.0;
+            zero = zero && (q[k] == 0.0);
+        }
+        return wave_all(zero) ? 0.0 : -dm_inf();
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+
+}  // namespace dhmc

@@ -1,0 +1,84 @@
+// Wavefront-level primitives for the one-wave-per-chain NUTS kernels (gfx950, wave64).
+//
+// Layout rule used everywhere: a D-vector of a chain is spread over the 64 lanes of the
+// chain's wavefront, lane l owning coordinates l, l+64, l+128, ... (slot k <-> coordinate
+// l + 64 k).  A global load/store of slot k is therefore one fully coalesced 512-byte
+// access per wave instruction, and a dot product is NPL lane-local fma's followed by a
+// 64-lane butterfly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dhmc {
+
+constexpr int WAVE = 64;
+
+// Make a wave-uniform value provably uniform (SGPR) so branches on it are scalar branches.
+__device__ __forceinline__ uint32_t uni_u32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int uni_i32(int x) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)x); }
+__device__ __forceinline__ double uni_f64(double x) {
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// One DPP-moved copy of a double (two 32-bit DPP movs).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t)b, lane);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// All-reduce sums of N independent values over the 64 lanes, every lane (and the returned
+// value, made scalar) getting the same bits.  The pairing is the xor butterfly 1,2,4,8,16,32:
+// the ABI's summation order (include/dhmc.h; oracle/mathops.hpp wave_tree).  Steps 1-8 are
+// DPP (quad_perm, row_half_mirror, row_mirror: equal to xor 1,2,4,8 because the lanes of
+// each already-reduced group hold identical values); 16 and 32 go through readlane of the
+// four row totals, which also leaves the result in SGPRs.
+template <int N>
+__device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x4E>(v[i]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x141>(v[i]);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x140>(v[i]);  // row_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double r0 = readlane_f64(v[i], 0), r1 = readlane_f64(v[i], 16);
+        double r2 = readlane_f64(v[i], 32), r3 = readlane_f64(v[i], 48);
+        v[i] = (r0 + r1) + (r2 + r3);
+    }
+}
+__device__ __forceinline__ double wave_allreduce1(double x) {
+    double v[1] = {x};
+    wave_allreduce<1>(v);
+    return v[0];
+}
+
+__device__ __forceinline__ bool wave_all(bool pred) { return __ballot(pred) == ~0ull; }
+
+// Coalesced vector access: slot k of lane l <-> element l + 64 k of a padded [Dpad] row.
+template <int NPL>
+__device__ __forceinline__ void ldv(const double* __restrict__ row, int lane, double (&v)[NPL]) {
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) v[k] = row[lane + WAVE * k];
+}
+template <int NPL>
+__device__ __forceinline__ void stv(double* __restrict__ row, int lane, const double (&v)[NPL]) {
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) row[lane + WAVE * k] = v[k];
+}
+
+}  // namespace dhmc

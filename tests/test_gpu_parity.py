@@ -1,0 +1,197 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeds.
+
+Everything is compared BIT FOR BIT (np.array_equal): integer outputs (depth, steps,
+termination, directions) and floating-point outputs alike, because the ABI pins the random
+stream, the summation order and the scalar math (include/dhmc.h, include/dhmc_detmath.h).
+The looser tolerance north_star allows (fp64 tolerance on posterior moments and per-step
+Hamiltonian error) is exercised in test_gpu_statistics.py against the libm flavour of the oracle.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def assert_same(a, b, what=""):
+    for k in a:
+        if not np.array_equal(a[k], b[k]):
+            bad = np.argwhere(a[k] != b[k])
+            raise AssertionError(f"{what}: field {k} differs at {bad[:5].tolist()} "
+                                 f"gpu={a[k][tuple(bad[0])]!r} oracle={b[k][tuple(bad[0])]!r} ({len(bad)} mismatches)")
+
+
+def make_pair(pkg, D, C, target=ol.TARGET_STD_NORMAL, params=None, **kw):
+    dev = pkg.DeviceContext(D, C, target=target, target_params=params, **kw)
+    ora = ol.Oracle(D, C, target=target, params=params, threads=8, **kw)
+    return dev, ora
+
+
+def test_init_random_positions(pkg):
+    for D in (3, 30, 64, 100, 1000):
+        dev, ora = make_pair(pkg, D, 5, seed=11)
+        dev.init(); ora.init()
+        for x, y in zip(dev.position(), ora.position()):
+            assert np.array_equal(x, y)
+        q = dev.position()[0]
+        assert q.min() >= -2 and q.max() < 2 and q.std() > 0.5   # mcmc.jl:108
+
+
+@pytest.mark.parametrize("D", [3, 30, 100, 200, 500, 1000])
+def test_stepsize_search_and_fixed_run(pkg, D):
+    C = 6
+    dev, ora = make_pair(pkg, D, C, seed=D)
+    dev.init(); ora.init()
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora.stepsize())
+    a, b = dev.run(12), ora.run(12)
+    assert_same(a, b, f"D={D}")
+    assert (a["steps"] >= 1).all() and (a["depth"] >= 0).all()
+
+
+@pytest.mark.parametrize("D", [5, 100, 1000])
+def test_adaptive_stages_and_metric_update(pkg, D):
+    """The shape of the reference's default warmup (mcmc.jl:415-425), shortened: step size
+    search, a step-size-only stage, two metric stages, a final step-size stage, inference."""
+    C = 4
+    dev, ora = make_pair(pkg, D, C, seed=99)
+    dev.init(); ora.init()
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    for n, metric in ((15, False), (25, True), (30, True), (10, False)):
+        a, b = dev.run(n, da={}), ora.run(n, da={})
+        assert_same(a, b, f"D={D} stage {n}")
+        assert np.array_equal(dev.stepsize(), ora.stepsize())
+        if metric:
+            dev.update_metric_diag(a["draws"]); ora.update_metric_diag(b["draws"])
+            assert np.array_equal(dev.metric_diag(), ora.metric_diag())
+    a, b = dev.run(20), ora.run(20)
+    assert_same(a, b, f"D={D} inference")
+
+
+def test_split_stage_equals_whole_stage(pkg):
+    """One TuningNUTS stage issued as two dhmc_run calls (init on the first, finalize on the
+    second) equals one call: the adaptation state persists in the context."""
+    D, C = 50, 4
+    dev1 = pkg.DeviceContext(D, C, seed=5); dev2 = pkg.DeviceContext(D, C, seed=5)
+    for d in (dev1, dev2):
+        d.init(); d.find_initial_stepsize()
+    whole = dev1.run(30, da={})
+    p1 = dev2.run(18, da=dict(init=1, finalize=0))
+    p2 = dev2.run(12, da=dict(init=0, finalize=1))
+    for k in whole:
+        assert np.array_equal(whole[k], np.concatenate([p1[k], p2[k]], axis=1)), k
+    assert np.array_equal(dev1.stepsize(), dev2.stepsize())
+
+
+def test_chain_offset_sharding_is_partition_independent(pkg):
+    """Chains [0,8) in one context == chains [0,4) and [4,8) in two contexts (multi-GPU shards)."""
+    D = 40
+    full = pkg.DeviceContext(D, 8, seed=3)
+    lo = pkg.DeviceContext(D, 4, seed=3, chain_offset=0)
+    hi = pkg.DeviceContext(D, 4, seed=3, chain_offset=4)
+    outs = []
+    for d in (full, lo, hi):
+        d.init(); d.find_initial_stepsize()
+        outs.append(d.run(10, da={}))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], np.concatenate([outs[1][k], outs[2][k]], axis=0)), k
+
+
+def test_diag_normal_target(pkg):
+    rng = np.random.default_rng(0)
+    D, C = 70, 5
+    mu = rng.normal(size=D); prec = 1 / (rng.normal(size=D) ** 2 + 0.1)
+    params = np.concatenate([mu, prec])
+    dev, ora = make_pair(pkg, D, C, target=ol.TARGET_DIAG_NORMAL, params=params, seed=21)
+    dev.init(); ora.init()
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    a, b = dev.run(25, da={}), ora.run(25, da={})
+    assert_same(a, b, "diag normal")
+
+
+def test_tridiag_normal_target(pkg):
+    # AR(1)-type precision: correlated MVN with O(D) gradient (BASELINE config 3's target)
+    for D in (7, 130):
+        rho = 0.5
+        diag = np.full(D, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
+        off = np.full(D, -rho / (1 - rho ** 2))
+        params = np.concatenate([diag, off])
+        dev, ora = make_pair(pkg, D, 4, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=8)
+        dev.init(); ora.init()
+        dev.find_initial_stepsize(); ora.find_initial_stepsize()
+        a, b = dev.run(20, da={}), ora.run(20, da={})
+        assert_same(a, b, f"tridiag D={D}")
+
+
+def test_funnel_target_divergences(pkg):
+    """Neal's funnel D=30 (BASELINE config 4): per-chain divergent tree depths and divergences."""
+    D, C = 30, 64
+    dev, ora = make_pair(pkg, D, C, target=ol.TARGET_FUNNEL, seed=4)
+    dev.init(); ora.init()
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    a, b = dev.run(40, da={}), ora.run(40, da={})
+    assert_same(a, b, "funnel warmup")
+    a, b = dev.run(40), ora.run(40)
+    assert_same(a, b, "funnel inference")
+    assert len(np.unique(a["depth"])) >= 3          # depths really differ across chains
+
+
+def test_always_divergent(pkg):  # test_NUTS.jl:75-85 through the HIP path
+    dev = pkg.DeviceContext(3, 4, target=ol.TARGET_ALWAYS_DIVERGENT)
+    dev.init(np.zeros((4, 3)))
+    dev.set_stepsize(1.0)
+    r = dev.run(2)
+    assert (r["term_left"] == r["term_right"]).all()
+    assert (r["acceptance_rate"] == 0).all() and (r["depth"] == 0).all() and (r["steps"] == 1).all()
+    assert (r["draws"] == 0).all()
+
+
+def test_max_depth_and_min_delta_config(pkg):
+    D, C = 20, 6
+    for md in (1, 2, 3):
+        dev, ora = make_pair(pkg, D, C, seed=1, max_depth=md)
+        dev.init(); ora.init()
+        dev.set_stepsize(0.01); ora.set_stepsize(0.01)   # tiny ϵ: every tree hits max_depth
+        a, b = dev.run(6), ora.run(6)
+        assert_same(a, b, f"max_depth={md}")
+        assert (a["depth"] == md).all() and (a["term_left"] == 1).all() and (a["term_right"] == 0).all()
+        assert (a["steps"] == 2 ** md - 1).all()
+
+
+def test_error_mapping(pkg):
+    with pytest.raises(ValueError):
+        pkg.DeviceContext(10, 2, max_depth=0)         # NUTS.jl:190
+    with pytest.raises(ValueError):
+        pkg.DeviceContext(10, 2, max_depth=33)
+    with pytest.raises(ValueError):
+        pkg.DeviceContext(10, 2, min_delta=1.0)       # NUTS.jl:191
+    dev = pkg.DeviceContext(10, 2)
+    with pytest.raises(pkg.DynamicHMCError):          # hamiltonian.jl:203
+        dev.init(np.full((2, 10), np.nan))
+    dev.init()
+    with pytest.raises(ValueError):                   # stepsize.jl:135: ϵ unspecified
+        dev.run(1)
+    with pytest.raises(ValueError):
+        dev.set_stepsize(-1.0)
+    dev.set_stepsize(0.5)
+    with pytest.raises(ValueError):                   # mcmc.jl:137: ϵ given, no search
+        dev.find_initial_stepsize()
+    with pytest.raises(ValueError):
+        dev.run(1, da=dict(delta=1.5))                # stepsize.jl:108
+
+
+def test_state_export_import_resumes_exactly(pkg):
+    D, C = 33, 3
+    a = pkg.DeviceContext(D, C, seed=12); b = pkg.DeviceContext(D, C, seed=12)
+    a.init(); a.find_initial_stepsize(); a.run(10, da={})
+    b.import_state(a.export_state())
+    ra, rb = a.run(8), b.run(8)
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
