@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py — leapfrog-steps/sec (all chains) + ESS/sec of the many-chain NUTS hot path.
+
+Workload (BASELINE.json configs[1]): 1000-dim standard MVN, diagonal mass matrix, 4096 chains
+per MI355X.  Untimed setup reproduces the reference's warmup shape in short form (random
+positions mcmc.jl:108, initial step size search, dual-averaging stages with per-chain diagonal
+metric updates, mcmc.jl:415-425) so the timed region runs at adapted per-chain ϵ and M⁻¹.
+
+One "step" = one dhmc_run call = one pass of the per-draw loop (mcmc.jl:374-379) of
+`--transitions` NUTS transitions for every chain, draws and tree statistics written to
+buffers already resident in HBM.  value = Σ leapfrog steps of all chains and ranks ÷ wall time
+of the K timed steps (barrier + synchronize on both sides, max over ranks).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+D = 1000
+CHAINS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALGO_BYTES_PER_LEAPFROG = 48 * D   # read q,p,∇ℓ + write q',p',∇ℓ' in fp64
+
+
+def setup_context(pkg, torch, rank, chains, seed, short):
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = pkg.DeviceContext(D, chains, seed=seed, chain_offset=rank * chains, device=torch.cuda.current_device(),
+                            stream=stream)
+    ctx.init()
+    ctx.find_initial_stepsize()
+    # shortened default_warmup_stages (mcmc.jl:415-425): stepsize-only, two metric windows, stepsize-only
+    stages = [(20, False), (25, True), (20, False)] if short else [(75, False), (25, True), (50, True), (100, True), (50, False)]
+    for n, metric in stages:
+        draws = torch.empty((chains, n, D), dtype=torch.float64, device="cuda") if metric else None
+        ctx.run_into(n, {"draws": draws} if metric else {}, da={})
+        if metric:
+            ctx.update_metric_diag(draws)
+        del draws
+    return ctx
+
+
+def bulk_ess_min(torch, draws, ncoord=16):
+    """Rank-normalisation-free bulk ESS (Vehtari et al. 2021 multi-chain estimator with Geyer's
+    initial positive sequence), min over a spread of `ncoord` coordinates.  draws: [C][N][D]."""
+    C, N, Dd = draws.shape
+    idx = torch.linspace(0, Dd - 1, ncoord, device=draws.device).long()
+    x = draws[:, :, idx].permute(2, 0, 1).contiguous()            # [k][C][N]
+    xm = x - x.mean(dim=2, keepdim=True)
+    nfft = 1 << (2 * N - 1).bit_length()
+    f = torch.fft.rfft(xm, n=nfft, dim=2)
+    acov = torch.fft.irfft(f * f.conj(), n=nfft, dim=2)[:, :, :N] / N   # biased autocovariance per chain
+    chain_var = acov[:, :, 0] * N / (N - 1)
+    W = chain_var.mean(dim=1)
+    B = x.mean(dim=2).var(dim=1, unbiased=True) * N if C > 1 else torch.zeros_like(W)
+    var_plus = W * (N - 1) / N + B / N
+    rho = 1 - (W[:, None] - acov.mean(dim=1)) / var_plus[:, None]      # [k][N]
+    rho[:, 0] = 1
+    T = N // 2
+    pair = rho[:, 0:2 * T:2] + rho[:, 1:2 * T:2]                        # Geyer pairs
+    pos = (pair > 0).to(pair.dtype)
+    keep = torch.cumprod(pos, dim=1)
+    pair = torch.cummin(pair.clamp(min=0) * keep + (1 - keep) * 0, dim=1).values * keep
+    tau = -1 + 2 * pair.sum(dim=1)
+    tau = torch.maximum(tau, torch.tensor(1.0 / np.log10(C * N), device=tau.device, dtype=tau.dtype))
+    return float((C * N / tau).min())
+
+
+def cpu_baseline(transitions, threads):
+    """The C++ oracle (restatement of the reference; Julia is not installed anywhere in this
+    environment) on the host cores, same workload shape on a bounded sample of chains."""
+    import oracle_lib as ol
+    chains = 8 * threads
+    o = ol.Oracle(D, chains, seed=1234, threads=threads)
+    o.init(); o.find_initial_stepsize()
+    o.run(20, da={}, fields=[])
+    r = o.run(25, da={}, fields=["draws"])
+    o.update_metric_diag(r["draws"])
+    o.run(20, da={}, fields=[])
+    t0 = time.perf_counter()
+    r = o.run(transitions, fields=["steps"])
+    dt = time.perf_counter() - t0
+    nsteps = int(r["steps"].sum())
+    return {"value": nsteps / dt, "unit": "leapfrog-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{chains} chains x {transitions} transitions, D={D}, adapted eps/diag metric, "
+                      f"{nsteps} leapfrog steps in {dt:.1f} s (C++ oracle, -O3, one chain per thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--transitions", type=int, default=20, help="NUTS transitions per chain per step")
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--full-warmup", action="store_true", help="300-transition adaptive setup instead of 65")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-transitions", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=0x23EF614D)
+    args = ap.parse_args()
+
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
+    ctx = setup_context(pkg, torch, rank, C, args.seed, not args.full_warmup)
+    out = {
+        "draws": torch.empty((C, T, D), dtype=torch.float64, device="cuda"),
+        "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
+        "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
+        "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda"),
+        "logdensities": torch.empty((C, T), dtype=torch.float64, device="cuda"),
+    }
+    keep_draws = []
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(Wn):
+        ctx.run_into(T, out)
+    sync()
+    kernel_ms, leapfrogs = [], 0
+    t0 = time.perf_counter()
+    for _ in range(K):
+        ctx.run_into(T, out)
+        kernel_ms.append(ctx.last_run_kernel_ms())
+        leapfrogs += ctx.last_run_leapfrogs()
+    sync()
+    dt = time.perf_counter() - t0
+
+    # untimed: statistics of the last step, ESS from a continuation run, gather over RCCL
+    mean_depth = float(out["depth"].double().mean())
+    mean_acc = float(out["acceptance_rate"].mean())
+    mean_steps = float(out["steps"].double().mean())
+    q = out["draws"]
+    mom = (float(q.mean()), float(q.var()))
+    ess_T = 100
+    ess_draws = torch.empty((C, ess_T, D), dtype=torch.float64, device="cuda")
+    e0 = time.perf_counter()
+    ctx.run_into(ess_T, {"draws": ess_draws})
+    torch.cuda.synchronize()
+    ess_dt = time.perf_counter() - e0
+    ess = bulk_ess_min(torch, ess_draws)
+    del ess_draws
+
+    t_max, total_leapfrogs, ess_rate = dt, leapfrogs, ess / ess_dt
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ll = torch.tensor([leapfrogs, ess / ess_dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(ll, op=dist.ReduceOp.SUM)
+        t_max, total_leapfrogs, ess_rate = float(tt[0]), float(ll[0]), float(ll[1])
+        # the one collective of the path: gather the last draw of every chain over RCCL/xGMI
+        last = out["draws"][:, -1, :].contiguous()
+        gathered = torch.empty((world * C, D), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(gathered, last)
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        per_launch = leapfrogs / K
+        achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",
+            "value": total_leapfrogs / t_max,
+            "unit": "leapfrog-steps/s",
+            "n_gpus": world, "steps": K, "warmup": Wn,
+            "ms_per_step": 1e3 * t_max / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "1000-dim standard MVN, per-chain diagonal mass matrix, 4096 chains per MI355X "
+                                   "(BASELINE.json configs[1])",
+                       "dim": D, "chains_per_gpu": C, "transitions_per_step": T,
+                       "phase": "sampling (fixed adapted eps and M^-1 per chain)", "max_depth": 10,
+                       "parallelism": f"chains sharded x{world}, no data-path collective"},
+            "ess_per_sec": ess_rate,
+            "ess_note": f"min bulk ESS over 16 coordinates, {ess_T} further draws x all chains, untimed continuation",
+            "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
+                     "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "nuts_run_kernel<StdNormalT,16>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_leapfrog": ALGO_BYTES_PER_LEAPFROG,
+                         "leapfrogs_per_launch": per_launch},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_transitions, os.cpu_count() or 1)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

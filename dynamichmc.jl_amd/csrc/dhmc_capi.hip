@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -29,6 +30,7 @@ struct dhmc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     unsigned long long last_leapfrogs = 0;
+    int l1_in_lds = 1;
     uint64_t ws_bytes = 0;
     std::string err;
     std::vector<void*> allocs;
@@ -63,9 +65,19 @@ int npl_for_dim(int D) {
 }
 
 // ---- kernel dispatch over (target family, slots per lane) ---------------------------------
+// Level-1 summaries go to LDS when four Dpad-rows per wave still leave one wave per SIMD
+// (4 waves per CU) resident: always for Dpad <= 512, and at Dpad = 1024 (33.5 KB per wave).
 template <class T, int NPL>
 void launch_run(const RunParams& P, hipStream_t s) {
-    hipLaunchKernelGGL((nuts_run_kernel<T, NPL>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad), s, P);
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)nuts_run_kernel<T, NPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        return true;
+    }();
+    (void)once;
+    if (P.l1_in_lds)
+        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, true>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, true), s, P);
+    else
+        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, false>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, false), s, P);
 }
 template <class T, int NPL>
 void launch_init(const InitParams& P, hipStream_t s) {
@@ -207,6 +219,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
     c->Dpad = c->NPL * WAVE;
     c->nvec = ws_nvec(cfg->max_depth);
+    if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
     const size_t C = cfg->chains, Dp = c->Dpad;
@@ -406,6 +419,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset;
     P.max_depth = c->cfg.max_depth; P.nvec = c->nvec; P.min_delta = c->cfg.min_delta; P.seed = c->cfg.seed;
     P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
+    P.l1_in_lds = c->l1_in_lds;
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;

@@ -69,6 +69,7 @@ struct ChainArrays {
 
 struct RunParams {
     int D, Dpad, C, chain_offset, max_depth, nvec;
+    int l1_in_lds, pad_;
     double min_delta;
     uint64_t seed;
     int64_t N;
@@ -89,11 +90,13 @@ __host__ __device__ inline int ws_slot(int max_depth, int s, int which) { return
 __host__ __device__ inline int ws_nslots(int max_depth) { return max_depth + 3; }
 __host__ __device__ inline int ws_nvec(int max_depth) { return 8 + 3 * max_depth + 2 * ws_nslots(max_depth); }
 
-// LDS carve (one wave per block): m[Dpad] then per-level and per-slot scalars
+// LDS carve (one wave per block): m[Dpad], the level-0 suspended momentum [Dpad], (optionally)
+// the level-1 suspended summary first/last [2][Dpad] — its ρ is first+last, recomputed — then
+// per-level and per-slot scalars.
 constexpr int LDS_LEVELS = 32;
 constexpr int LDS_SLOTS = 36;
-__host__ __device__ inline size_t lds_bytes(int Dpad) {
-    return sizeof(double) * ((size_t)Dpad + 3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
+__host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds) {
+    return sizeof(double) * ((size_t)Dpad * (l1_in_lds ? 4 : 2) + 3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
 }
 
 __device__ __forceinline__ double joint_logdensity(double lq, double K) {  // hamiltonian.jl:251-256
@@ -169,11 +172,17 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
     pi_out = uni_f64(joint_logdensity(lq, K));
 }
 
-// combine_turn_statistics (NUTS.jl:132-139) of a suspended summary L (memory; build order:
-// first, last, rho) with the running summary cur (registers: cf = first, p = last, cr = rho),
+// Where a suspended summary L lives.
+enum : int { SRC_MEM = 0,       // HBM workspace: three rows first / last / rho
+             SRC_MEM_LEAF = 1,  // HBM workspace, single-leaf summary: first == last == rho (one row)
+             SRC_LDS_L0 = 2,    // LDS, level-0 (single leaf) summary: one row
+             SRC_LDS_L1 = 3 };  // LDS, level-1 summary: rows first, last; rho = first + last
+
+// combine_turn_statistics (NUTS.jl:132-139) of a suspended summary L (build order: first,
+// last, rho) with the running summary cur (registers: cf = first, p = last, cr = rho),
 // time-ordered by the build direction (trees.jl:135-141).  Returns turning; on return
 // cf/cr hold the merged summary's first momentum and ρ (its last momentum is still p).
-template <int NPL, bool FWD, bool LEAFL>
+template <int NPL, bool FWD, int SRC>
 __device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const double* __restrict__ Ll,
                                            const double* __restrict__ Lr, const double* __restrict__ m_lds,
                                            int lane, double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
@@ -182,8 +191,10 @@ __device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const 
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
         const double lf = Lf[e];
-        const double ll = LEAFL ? lf : Ll[e];
-        const double lr = LEAFL ? lf : Lr[e];
+        double ll, lr;
+        if constexpr (SRC == SRC_MEM) { ll = Ll[e]; lr = Lr[e]; }
+        else if constexpr (SRC == SRC_LDS_L1) { ll = Ll[e]; lr = lf + ll; }
+        else { ll = lf; lr = lf; }
         const double mk = m_lds[e];
         // x = earlier in time, y = later:  (p₋, p₊, ρ)
         const double xm = FWD ? lf : p[k], xp = FWD ? ll : cf[k], xr = FWD ? lr : cr[k];
@@ -209,15 +220,34 @@ __device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const 
 }
 
 template <int NPL>
-__device__ __forceinline__ bool merge_turn_dispatch(bool fwd, bool leafL, const double* Lf, const double* Ll,
+__device__ __forceinline__ bool merge_turn_dispatch(bool fwd, int src, const double* Lf, const double* Ll,
                                                     const double* Lr, const double* m_lds, int lane,
                                                     double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
     if (fwd) {
-        if (leafL) return merge_turn<NPL, true, true>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-        return merge_turn<NPL, true, false>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        switch (src) {
+        case SRC_MEM: return merge_turn<NPL, true, SRC_MEM>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        case SRC_MEM_LEAF: return merge_turn<NPL, true, SRC_MEM_LEAF>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        case SRC_LDS_L0: return merge_turn<NPL, true, SRC_LDS_L0>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        default: return merge_turn<NPL, true, SRC_LDS_L1>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+        }
     }
-    if (leafL) return merge_turn<NPL, false, true>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-    return merge_turn<NPL, false, false>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    switch (src) {
+    case SRC_MEM: return merge_turn<NPL, false, SRC_MEM>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    case SRC_MEM_LEAF: return merge_turn<NPL, false, SRC_MEM_LEAF>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    case SRC_LDS_L0: return merge_turn<NPL, false, SRC_LDS_L0>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    default: return merge_turn<NPL, false, SRC_LDS_L1>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+    }
+}
+
+// Two logaddexp's in one pass: even lanes evaluate (a1, b1), odd lanes (a2, b2); the results
+// come back as scalars.  (The scalar transcendentals of the tree logic are wave-uniform; doing
+// two different ones in different lanes halves their dependent-chain latency.)
+__device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, double b2, int lane,
+                                               double& r1, double& r2) {
+    const bool odd = (lane & 1) != 0;
+    const double r = det_logaddexp(odd ? a2 : a1, odd ? b2 : b1);
+    r1 = readlane_f64(r, 0);
+    r2 = readlane_f64(r, 1);
 }
 
 // p = W .* randn (hamiltonian.jl:124) from the chain's stream.
@@ -236,22 +266,26 @@ __device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t pu
 }
 
 // ------------------------------------------------------------------------------------------
-// The per-draw loop kernel.
+// The per-draw loop kernel.  L1LDS: keep the level-1 suspended summary in LDS as well (needs
+// 4 Dpad-rows of LDS per wave, i.e. one wave per SIMD at Dpad = 1024).
 // ------------------------------------------------------------------------------------------
-template <class T, int NPL>
-__global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
+template <class T, int NPL, bool L1LDS>
+__global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P) {
     const int chain = blockIdx.x;
     const int lane = threadIdx.x;
     const int D = P.D, Dpad = P.Dpad;
 
     extern __shared__ double lds[];
-    double* m_lds = lds;                              // [Dpad]
-    double* lv_omega = lds + Dpad;                    // [LDS_LEVELS]
+    double* m_lds = lds;                                   // [Dpad]
+    double* l0_lds = lds + Dpad;                           // [Dpad]   level-0 suspended momentum
+    double* l1f_lds = lds + 2 * Dpad;                      // [Dpad]   level-1 first   (L1LDS only)
+    double* l1l_lds = lds + 3 * Dpad;                      // [Dpad]   level-1 last    (L1LDS only)
+    double* lv_omega = lds + (L1LDS ? 4 : 2) * Dpad;       // [LDS_LEVELS]
     double* lv_vlsa = lv_omega + LDS_LEVELS;
     double* lv_vsteps = lv_vlsa + LDS_LEVELS;
-    double* sl_lq = lv_vsteps + LDS_LEVELS;           // [LDS_SLOTS]
+    double* sl_lq = lv_vsteps + LDS_LEVELS;                // [LDS_SLOTS]
     double* sl_pi = sl_lq + LDS_SLOTS;
-    int* lv_zeta = (int*)(sl_pi + LDS_SLOTS);         // [LDS_LEVELS]
+    int* lv_zeta = (int*)(sl_pi + LDS_SLOTS);              // [LDS_LEVELS]
 
     const T tgt(P.tp);
     const size_t row = (size_t)chain * Dpad;
@@ -290,7 +324,19 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
     // the chain's current position occupies proposal slot `init_slot` of the workspace
     int init_slot = 0;
     stv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
-    stv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+    if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+
+    // write a leaf held in registers into a fresh proposal slot
+    uint64_t free_mask = 0;
+    auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
+        int s = __builtin_ctzll(free_mask);
+        free_mask &= ~(1ull << s);
+        stv<NPL>(wsv(ws_slot(max_depth, s, 0)), lane, q);
+        if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, s, 1)), lane, g);
+        sl_lq[s] = lq_leaf;
+        sl_pi[s] = pi_leaf;
+        return s;
+    };
 
     for (int64_t n = 0; n < P.N; ++n) {
         const uint32_t tr = tr0 + (uint32_t)n;
@@ -316,14 +362,28 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
         sl_lq[init_slot] = lq_cur;
         sl_pi[init_slot] = pi0;
 
+        // Exp(1) draws of this transition, 64 at a time: lane l holds draw (rexp_base + l)
+        uint32_t nrand = 0, rexp_base = 0;
+        double rexp_vals;
+        auto rexp_fill = [&](uint32_t base) {
+            uint64_t r1, r2;
+            stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
+            rexp_vals = det_randexp(r1);
+            rexp_base = base;
+        };
+        rexp_fill(0);
+        auto randexp = [&]() -> double {  // Random.randexp at NUTS.jl:44
+            if (nrand - rexp_base >= 64u) rexp_fill(nrand & ~63u);
+            double v = readlane_f64(rexp_vals, (int)(nrand & 63u));
+            nrand += 1;
+            return v;
+        };
+
         // ---- sample_trajectory (trees.jl:283-319) ---------------------------------------
-        int eq[2], ep[2], eg[2];  // workspace vector indices of the two edges z₋ (0), z₊ (1)
-        eq[0] = eq[1] = ws_slot(max_depth, init_slot, 0);
-        ep[0] = ep[1] = ws_p0();
-        eg[0] = eg[1] = ws_slot(max_depth, init_slot, 1);
-        int rho_idx = ws_p0();
+        // edges z₋ (0), z₊ (1): until a doubling has stored one, it is the initial point
+        bool stored0 = false, stored1 = false, rho_stored = false;
         int reg_edge = 2;  // which edge the registers (q,p,g) hold: 0, 1 or 2 = both
-        uint64_t free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
+        free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
         int zeta_top = init_slot;
         double omega_top = 0.0;
         double vtop_lsa = -dm_inf();
@@ -331,28 +391,25 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
         int depth = 0;
         int64_t i_minus = 0, i_plus = 0;
         int64_t term_left = 1, term_right = 0;  // REACHED_MAX_DEPTH
-        uint32_t nrand = 0;
-
-        auto randexp = [&]() -> double {  // Random.randexp at NUTS.jl:44
-            uint64_t r1, r2;
-            stream_raw64(key, nrand++, PURPOSE_TREE, tr, r1, r2);
-            return uni_f64(det_randexp(r1));
-        };
-        auto alloc_slot = [&]() -> int {
-            int s = __builtin_ctzll(free_mask);
-            free_mask &= ~(1ull << s);
-            return s;
-        };
 
         bool finished = false;
         while (!finished && depth < max_depth) {
             const bool fwd = (dirs & 1u) != 0;  // next_direction (trees.jl:31-34)
             dirs >>= 1;
             const int dir = fwd ? 1 : 0;
+            const bool stored_near = fwd ? stored1 : stored0;
+            const bool stored_far = fwd ? stored0 : stored1;
             if (reg_edge != 2 && reg_edge != dir) {
-                ldv<NPL>(wsv(eq[dir]), lane, q);
-                ldv<NPL>(wsv(ep[dir]), lane, p);
-                ldv<NPL>(wsv(eg[dir]), lane, g);
+                if (stored_near) {
+                    ldv<NPL>(wsv(ws_edge(dir, 0)), lane, q);
+                    ldv<NPL>(wsv(ws_edge(dir, 1)), lane, p);
+                    ldv<NPL>(wsv(ws_edge(dir, 2)), lane, g);
+                } else {  // this edge is still the initial point
+                    ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
+                    ldv<NPL>(wsv(ws_p0()), lane, p);
+                    if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+                    else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+                }
             }
             int64_t i = fwd ? i_plus : i_minus;
             const int64_t di = fwd ? 1 : -1;
@@ -387,18 +444,26 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
                         const bool top = !sub && (j == nleaf - 1) && (level == depth);
                         if (!sub && !top) break;
                         const double *Lf, *Ll, *Lr;
-                        bool leafL;
+                        int src;
                         if (sub) {
-                            Lf = wsv(ws_stack(level, 0)); Ll = wsv(ws_stack(level, 1)); Lr = wsv(ws_stack(level, 2));
-                            leafL = (level == 0);
+                            if (level == 0) { Lf = Ll = Lr = l0_lds; src = SRC_LDS_L0; }
+                            else if (L1LDS && level == 1) { Lf = l1f_lds; Ll = l1l_lds; Lr = l1f_lds; src = SRC_LDS_L1; }
+                            else {
+                                Lf = wsv(ws_stack(level, 0)); Ll = wsv(ws_stack(level, 1)); Lr = wsv(ws_stack(level, 2));
+                                src = SRC_MEM;
+                            }
                         } else {
-                            Lf = wsv(ep[1 - dir]); Ll = wsv(ep[dir]); Lr = wsv(rho_idx);
-                            leafL = (depth == 0);
+                            Lf = stored_far ? wsv(ws_edge(1 - dir, 1)) : wsv(ws_p0());
+                            Ll = stored_near ? wsv(ws_edge(dir, 1)) : wsv(ws_p0());
+                            Lr = rho_stored ? wsv(ws_rho_top()) : wsv(ws_p0());
+                            src = (depth == 0) ? SRC_MEM_LEAF : SRC_MEM;
                         }
-                        const bool turning = merge_turn_dispatch<NPL>(fwd, leafL, Lf, Ll, Lr, m_lds, lane, cf, cr, p);
+                        const bool turning = merge_turn_dispatch<NPL>(fwd, src, Lf, Ll, Lr, m_lds, lane, cf, cr, p);
                         if (sub) {
-                            // v = v₋ ⊕ v₊ (trees.jl:249)
-                            v_lsa = uni_f64(det_logaddexp(lv_vlsa[level], v_lsa));
+                            // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
+                            const double wl = lv_omega[level];
+                            double w;
+                            logaddexp_pair(lv_vlsa[level], v_lsa, wl, c_omega, lane, v_lsa, w);
                             v_steps += (int64_t)lv_vsteps[level];
                             if (turning) {                       // trees.jl:255
                                 term_left = i - di * (((int64_t)2 << level) - 1);
@@ -408,8 +473,6 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
                                 break;
                             }
                             // combine_proposals_and_logweights(…, is_doubling = false) (trees.jl:258)
-                            const double wl = lv_omega[level];
-                            const double w = uni_f64(det_logaddexp(wl, c_omega));
                             const double logprob2 = c_omega - w;
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
                             const int lz = lv_zeta[level];
@@ -423,19 +486,13 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
                             level += 1;
                         } else {
                             // top level (trees.jl:294-316)
-                            vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));
+                            double w;
+                            logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
                             vtop_steps += v_steps;
-                            const double w = uni_f64(det_logaddexp(omega_top, c_omega));
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
                             if (pick) {
-                                if (c_zeta < 0) {
-                                    c_zeta = alloc_slot();
-                                    stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 0)), lane, q);
-                                    stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 1)), lane, g);
-                                    sl_lq[c_zeta] = lq_leaf;
-                                    sl_pi[c_zeta] = pi_leaf;
-                                }
+                                if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
                                 if (zeta_top != init_slot) free_mask |= (1ull << zeta_top);
                                 zeta_top = c_zeta;
                             } else if (c_zeta >= 0) {
@@ -450,12 +507,12 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
                                 finished = true;
                             } else if (depth < max_depth) {
                                 // the new edge and Σp of the whole trajectory
-                                eq[dir] = ws_edge(dir, 0); ep[dir] = ws_edge(dir, 1); eg[dir] = ws_edge(dir, 2);
-                                stv<NPL>(wsv(eq[dir]), lane, q);
-                                stv<NPL>(wsv(ep[dir]), lane, p);
-                                stv<NPL>(wsv(eg[dir]), lane, g);
+                                stv<NPL>(wsv(ws_edge(dir, 0)), lane, q);
+                                stv<NPL>(wsv(ws_edge(dir, 1)), lane, p);
+                                stv<NPL>(wsv(ws_edge(dir, 2)), lane, g);
                                 stv<NPL>(wsv(ws_rho_top()), lane, cr);
-                                rho_idx = ws_rho_top();
+                                if (fwd) stored1 = true; else stored0 = true;
+                                rho_stored = true;
                             }
                             reg_edge = dir;
                             level = -1;  // handled
@@ -464,15 +521,12 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
                     }
                     if (level >= 0 && !invalid) {
                         // suspend the running subtree at `level` until its right sibling is built
-                        if (c_zeta < 0) {
-                            c_zeta = alloc_slot();
-                            stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 0)), lane, q);
-                            stv<NPL>(wsv(ws_slot(max_depth, c_zeta, 1)), lane, g);
-                            sl_lq[c_zeta] = lq_leaf;
-                            sl_pi[c_zeta] = pi_leaf;
-                        }
+                        if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
                         if (level == 0) {
-                            stv<NPL>(wsv(ws_stack(0, 0)), lane, p);
+                            stv<NPL>(l0_lds, lane, p);
+                        } else if (L1LDS && level == 1) {
+                            stv<NPL>(l1f_lds, lane, cf);
+                            stv<NPL>(l1l_lds, lane, p);
                         } else {
                             stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
                             stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
@@ -507,7 +561,8 @@ __global__ __launch_bounds__(64, 2) void nuts_run_kernel(RunParams P) {
         }();
         init_slot = zeta_top;
         ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
-        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+        if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+        else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
         lq_cur = uni_f64(sl_lq[init_slot]);
         const double pi_stat = uni_f64(sl_pi[init_slot]);
 

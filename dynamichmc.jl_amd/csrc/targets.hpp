@@ -9,6 +9,8 @@
 //                                the reduction that gives ℓ (kDeferred = true; the caller
 //                                batches the wave reduction with the kinetic energy's and then
 //                                calls finish()), or ℓ itself (kDeferred = false).
+//   kRecomputeGrad               ∇ℓ is cheap enough that a stored proposal keeps only q and the
+//                                gradient is re-evaluated when the proposal becomes the chain's position.
 //   kGradFiniteIfPosFinite       a finite position implies (ℓ finite or -Inf) and, when ℓ is
 //                                finite, a finite gradient: the ∇ℓ scan of evaluate_ℓ
 //                                (src/hamiltonian.jl:205) cannot change the outcome and is skipped.
@@ -28,6 +30,7 @@ struct TargetParams {
 struct StdNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kRecomputeGrad = true;
     __device__ explicit StdNormalT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int, int) const {
@@ -45,6 +48,7 @@ struct StdNormalT {
 struct DiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kRecomputeGrad = true;
     const double* mu;
     const double* prec;
     __device__ explicit DiagNormalT(const TargetParams& p) : mu(p.a), prec(p.b) {}
@@ -67,6 +71,7 @@ struct DiagNormalT {
 struct TridiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kRecomputeGrad = true;
     const double* diag;
     const double* off;
     __device__ explicit TridiagNormalT(const TargetParams& p) : diag(p.a), off(p.b) {}
@@ -99,6 +104,7 @@ struct TridiagNormalT {
 struct FunnelT {
     static constexpr bool kDeferred = false;
     static constexpr bool kGradFiniteIfPosFinite = false;
+    static constexpr bool kRecomputeGrad = true;
     __device__ explicit FunnelT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
@@ -126,6 +132,7 @@ struct FunnelT {
 struct AlwaysDivergentT {
     static constexpr bool kDeferred = false;
     static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kRecomputeGrad = true;
     __device__ explicit AlwaysDivergentT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
