@@ -30,6 +30,10 @@
 #include "targets.hpp"
 #include "wave.hpp"
 
+#ifndef DHMC_L2_REG
+#define DHMC_L2_REG 0
+#endif
+
 namespace dhmc {
 
 // DualAveragingState (stepsize.jl:121-127)
@@ -172,33 +176,21 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
     pi_out = uni_f64(joint_logdensity(lq, K));
 }
 
-// Where a suspended summary L lives.
-enum : int { SRC_MEM = 0,       // HBM workspace: three rows first / last / rho
-             SRC_MEM_LEAF = 1,  // HBM workspace, single-leaf summary: first == last == rho (one row)
-             SRC_LDS_L0 = 2,    // LDS, level-0 (single leaf) summary: one row
-             SRC_LDS_L1 = 3 };  // LDS, level-1 summary: rows first, last; rho = first + last
-
-// combine_turn_statistics (NUTS.jl:132-139) of a suspended summary L (build order: first,
-// last, rho) with the running summary cur (registers: cf = first, p = last, cr = rho),
-// time-ordered by the build direction (trees.jl:135-141).  Returns turning; on return
-// cf/cr hold the merged summary's first momentum and ρ (its last momentum is still p).
-template <int NPL, bool FWD, int SRC>
-__device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const double* __restrict__ Ll,
-                                           const double* __restrict__ Lr, const double* __restrict__ m_lds,
-                                           int lane, double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
+// combine_turn_statistics (NUTS.jl:132-139) of two adjacent subtrees, time-ordered
+// (trees.jl:135-141): x = earlier in time, y = later, each given as accessors k -> slot k of
+// its (p₋, p₊, ρ).  nf(k) is what becomes the merged summary's build-order first momentum.
+// On return cf = nf, cr = ρ of the merge.  Returns turning.
+template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, class NF>
+__device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_,
+                                           const double* __restrict__ m_lds, int lane,
+                                           double (&cf)[NPL], double (&cr)[NPL]) {
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
-        const int e = lane + WAVE * k;
-        const double lf = Lf[e];
-        double ll, lr;
-        if constexpr (SRC == SRC_MEM) { ll = Ll[e]; lr = Lr[e]; }
-        else if constexpr (SRC == SRC_LDS_L1) { ll = Ll[e]; lr = lf + ll; }
-        else { ll = lf; lr = lf; }
-        const double mk = m_lds[e];
-        // x = earlier in time, y = later:  (p₋, p₊, ρ)
-        const double xm = FWD ? lf : p[k], xp = FWD ? ll : cf[k], xr = FWD ? lr : cr[k];
-        const double ym = FWD ? cf[k] : ll, yp = FWD ? p[k] : lf, yr = FWD ? cr[k] : lr;
+        const double xm = xm_(k), xp = xp_(k), xr = xr_(k);
+        const double ym = ym_(k), yp = yp_(k), yr = yr_(k);
+        const double nf = nf_(k);
+        const double mk = m_lds[lane + WAVE * k];
         const double s1 = xr + ym;      // x.ρ + y.p₋      (:134)
         const double s2 = xp + yr;      // x.p₊ + y.ρ      (:135)
         const double r = xr + yr;       // ρ               (:136)
@@ -212,31 +204,34 @@ __device__ __forceinline__ bool merge_turn(const double* __restrict__ Lf, const 
         acc[3] = __builtin_fma(d, s2, acc[3]);
         acc[4] = __builtin_fma(a, r, acc[4]);
         acc[5] = __builtin_fma(d, r, acc[5]);
-        cf[k] = lf;
+        cf[k] = nf;
         cr[k] = r;
     }
     wave_allreduce<6>(acc);
     return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
 }
 
-template <int NPL>
-__device__ __forceinline__ bool merge_turn_dispatch(bool fwd, int src, const double* Lf, const double* Ll,
-                                                    const double* Lr, const double* m_lds, int lane,
-                                                    double (&cf)[NPL], double (&cr)[NPL], const double (&p)[NPL]) {
-    if (fwd) {
-        switch (src) {
-        case SRC_MEM: return merge_turn<NPL, true, SRC_MEM>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-        case SRC_MEM_LEAF: return merge_turn<NPL, true, SRC_MEM_LEAF>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-        case SRC_LDS_L0: return merge_turn<NPL, true, SRC_LDS_L0>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-        default: return merge_turn<NPL, true, SRC_LDS_L1>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-        }
+// The same merge when BOTH subtrees are single leaves with momenta pa (suspended) and pb
+// (running): every (p₋, p₊, ρ) collapses to the leaf's p, the three sums of NUTS.jl:134-136 are
+// all pa + pb (IEEE addition commutes, so the build direction does not matter) and the six
+// dots are two distinct values, (M⁻¹pa)·ρ and (M⁻¹pb)·ρ, each appearing three times: the
+// result is bit-identical to merge_core.  Half of all merges of a tree are of this kind.
+template <int NPL, class PA>
+__device__ __forceinline__ bool merge_leaf_leaf(PA pa_, const double* __restrict__ m_lds, int lane,
+                                                double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL]) {
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const double pa = pa_(k);
+        const double mk = m_lds[lane + WAVE * k];
+        const double r = pa + pb[k];
+        acc[0] = __builtin_fma(mk * pa, r, acc[0]);
+        acc[1] = __builtin_fma(mk * pb[k], r, acc[1]);
+        cf[k] = pa;
+        cr[k] = r;
     }
-    switch (src) {
-    case SRC_MEM: return merge_turn<NPL, false, SRC_MEM>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-    case SRC_MEM_LEAF: return merge_turn<NPL, false, SRC_MEM_LEAF>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-    case SRC_LDS_L0: return merge_turn<NPL, false, SRC_LDS_L0>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-    default: return merge_turn<NPL, false, SRC_LDS_L1>(Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-    }
+    wave_allreduce<2>(acc);
+    return acc[0] < 0 || acc[1] < 0;
 }
 
 // Two logaddexp's in one pass: even lanes evaluate (a1, b1), odd lanes (a2, b2); the results
@@ -303,6 +298,9 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
     const int nslots = ws_nslots(max_depth);
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
+    double tpm[NPL], tpp[NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+    constexpr bool kL2Reg = DHMC_L2_REG != 0;
+    double l2f[kL2Reg ? NPL : 1], l2l[kL2Reg ? NPL : 1], l2r[kL2Reg ? NPL : 1];  // the level-2 suspended summary: first, last, ρ
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(P.st.g + row, lane, g);
     double lq_cur = P.st.lq[chain];
@@ -358,7 +356,8 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
             for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], m_lds[lane + WAVE * k] * p[k], kacc);
             pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
         }
-        stv<NPL>(wsv(ws_p0()), lane, p);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; trho[k] = p[k]; }   // leaf τ of z₀ (NUTS.jl:120-123)
         sl_lq[init_slot] = lq_cur;
         sl_pi[init_slot] = pi0;
 
@@ -380,9 +379,11 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
         };
 
         // ---- sample_trajectory (trees.jl:283-319) ---------------------------------------
-        // edges z₋ (0), z₊ (1): until a doubling has stored one, it is the initial point
-        bool stored0 = false, stored1 = false, rho_stored = false;
-        int reg_edge = 2;  // which edge the registers (q,p,g) hold: 0, 1 or 2 = both
+        // Edges z₋ (0), z₊ (1).  The registers (q,p,g) hold the edge being extended; the other
+        // edge's q (and ∇ℓ unless it is recomputed) is parked in the workspace only when the
+        // build direction switches; an edge that was never extended is still the initial point.
+        bool stored0 = false, stored1 = false;
+        int reg_edge = 2;  // which edge the registers hold: 0, 1 or 2 = both
         free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
         int zeta_top = init_slot;
         double omega_top = 0.0;
@@ -397,20 +398,27 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
             const bool fwd = (dirs & 1u) != 0;  // next_direction (trees.jl:31-34)
             dirs >>= 1;
             const int dir = fwd ? 1 : 0;
-            const bool stored_near = fwd ? stored1 : stored0;
-            const bool stored_far = fwd ? stored0 : stored1;
             if (reg_edge != 2 && reg_edge != dir) {
-                if (stored_near) {
-                    ldv<NPL>(wsv(ws_edge(dir, 0)), lane, q);
-                    ldv<NPL>(wsv(ws_edge(dir, 1)), lane, p);
-                    ldv<NPL>(wsv(ws_edge(dir, 2)), lane, g);
-                } else {  // this edge is still the initial point
-                    ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
-                    ldv<NPL>(wsv(ws_p0()), lane, p);
-                    if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-                    else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+                // park the edge we leave ...
+                stv<NPL>(wsv(ws_edge(reg_edge, 0)), lane, q);
+                if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_edge(reg_edge, 2)), lane, g);
+                if (reg_edge == 1) stored1 = true; else stored0 = true;
+                // ... and fetch the one we extend now
+                const bool have = fwd ? stored1 : stored0;
+                const int qsrc = have ? ws_edge(dir, 0) : ws_slot(max_depth, init_slot, 0);
+                const int gsrc = have ? ws_edge(dir, 2) : ws_slot(max_depth, init_slot, 1);
+                ldv<NPL>(wsv(qsrc), lane, q);
+                if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+                else ldv<NPL>(wsv(gsrc), lane, g);
+                if (fwd) {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) p[k] = tpp[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) p[k] = tpm[k];
                 }
             }
+            reg_edge = dir;
             int64_t i = fwd ? i_plus : i_minus;
             const int64_t di = fwd ? 1 : -1;
             const double eps_s = fwd ? eps : -eps;
@@ -435,31 +443,42 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
                     term_left = term_right = i;
                     invalid = true;
                 } else {
-#pragma unroll
-                    for (int k = 0; k < NPL; ++k) { cf[k] = p[k]; cr[k] = p[k]; }
                     double c_omega = delta;
                     int c_zeta = -1;  // -1: the proposal is the leaf held in registers
                     for (;;) {
                         const bool sub = ((j >> level) & 1u) != 0;
                         const bool top = !sub && (j == nleaf - 1) && (level == depth);
                         if (!sub && !top) break;
-                        const double *Lf, *Ll, *Lr;
-                        int src;
+                        // element accessors of the running summary (build order: cf, p, cr)
+                        auto a_cf = [&](int k) { return cf[k]; };
+                        auto a_p = [&](int k) { return p[k]; };
+                        auto a_cr = [&](int k) { return cr[k]; };
+                        bool turning;
                         if (sub) {
-                            if (level == 0) { Lf = Ll = Lr = l0_lds; src = SRC_LDS_L0; }
-                            else if (L1LDS && level == 1) { Lf = l1f_lds; Ll = l1l_lds; Lr = l1f_lds; src = SRC_LDS_L1; }
-                            else {
-                                Lf = wsv(ws_stack(level, 0)); Ll = wsv(ws_stack(level, 1)); Lr = wsv(ws_stack(level, 2));
-                                src = SRC_MEM;
+                            if (level == 0) {
+                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, m_lds, lane, cf, cr, p);
+                            } else if (L1LDS && level == 1) {
+                                auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
+                            } else if (kL2Reg && level == 2) {
+                                auto a_lf = [&](int k) { return l2f[kL2Reg ? k : 0]; };
+                                auto a_ll = [&](int k) { return l2l[kL2Reg ? k : 0]; };
+                                auto a_lr = [&](int k) { return l2r[kL2Reg ? k : 0]; };
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
+                            } else {
+                                const double* Lf = wsv(ws_stack(level, 0));
+                                const double* Ll = wsv(ws_stack(level, 1));
+                                const double* Lr = wsv(ws_stack(level, 2));
+                                auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
                             }
-                        } else {
-                            Lf = stored_far ? wsv(ws_edge(1 - dir, 1)) : wsv(ws_p0());
-                            Ll = stored_near ? wsv(ws_edge(dir, 1)) : wsv(ws_p0());
-                            Lr = rho_stored ? wsv(ws_rho_top()) : wsv(ws_p0());
-                            src = (depth == 0) ? SRC_MEM_LEAF : SRC_MEM;
-                        }
-                        const bool turning = merge_turn_dispatch<NPL>(fwd, src, Lf, Ll, Lr, m_lds, lane, cf, cr, p);
-                        if (sub) {
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
                             const double wl = lv_omega[level];
                             double w;
@@ -485,7 +504,17 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
                             c_omega = w;
                             level += 1;
                         } else {
-                            // top level (trees.jl:294-316)
+                            // top level (trees.jl:294-316): merge with τ of the whole trajectory, which is
+                            // time-ordered (tpm, tpp, trho) whatever the direction
+                            auto a_tm = [&](int k) { return tpm[k]; };
+                            auto a_tp = [&](int k) { return tpp[k]; };
+                            auto a_tr = [&](int k) { return trho[k]; };
+                            if (depth == 0) {
+                                turning = merge_leaf_leaf<NPL>(a_tr, m_lds, lane, cf, cr, p);
+                            } else {
+                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, m_lds, lane, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, m_lds, lane, cf, cr);
+                            }
                             double w;
                             logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
                             vtop_steps += v_steps;
@@ -506,15 +535,15 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
                                 term_right = i_plus;
                                 finished = true;
                             } else if (depth < max_depth) {
-                                // the new edge and Σp of the whole trajectory
-                                stv<NPL>(wsv(ws_edge(dir, 0)), lane, q);
-                                stv<NPL>(wsv(ws_edge(dir, 1)), lane, p);
-                                stv<NPL>(wsv(ws_edge(dir, 2)), lane, g);
-                                stv<NPL>(wsv(ws_rho_top()), lane, cr);
-                                if (fwd) stored1 = true; else stored0 = true;
-                                rho_stored = true;
+                                // τ of the doubled trajectory: the new edge momentum and Σp
+                                if (fwd) {
+#pragma unroll
+                                    for (int k = 0; k < NPL; ++k) { tpp[k] = p[k]; trho[k] = cr[k]; }
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; trho[k] = cr[k]; }
+                                }
                             }
-                            reg_edge = dir;
                             level = -1;  // handled
                             break;
                         }
@@ -527,6 +556,9 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
                         } else if (L1LDS && level == 1) {
                             stv<NPL>(l1f_lds, lane, cf);
                             stv<NPL>(l1l_lds, lane, p);
+                        } else if (kL2Reg && level == 2) {
+#pragma unroll
+                            for (int k = 0; k < (kL2Reg ? NPL : 0); ++k) { l2f[k] = cf[k]; l2l[k] = p[k]; l2r[k] = cr[k]; }
                         } else {
                             stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
                             stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
