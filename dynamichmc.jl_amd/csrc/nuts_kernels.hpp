@@ -113,22 +113,11 @@ __device__ __forceinline__ double joint_logdensity(double lq, double K) {  // ha
 // the full-step momentum computed from g.  Sets *pos_bad when the position has a non-finite
 // coordinate (the reference throws there, :203).
 template <class T, int NPL>
-__device__ __forceinline__ void eval_point(const T& tgt, const double* __restrict__ m_lds, int lane, int D,
-                                           const double (&q)[NPL], double (&g)[NPL], double& lpart_or_lq,
-                                           bool& pos_finite, bool& grad_finite) {
+__device__ __forceinline__ bool all_finite(const double (&v)[NPL]) {
     bool fin = true;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) fin = fin && dm_isfinite(q[k]);
-    pos_finite = wave_all(fin);
-    lpart_or_lq = tgt.eval(q, g, lane, D);
-    if constexpr (!T::kGradFiniteIfPosFinite) {
-        bool gf = true;
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) gf = gf && dm_isfinite(g[k]);
-        grad_finite = wave_all(gf);
-    } else {
-        grad_finite = true;
-    }
+    for (int k = 0; k < NPL; ++k) fin = fin && dm_isfinite(v[k]);
+    return wave_all(fin);
 }
 
 __device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool grad_finite) {
@@ -151,9 +140,7 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
         q[k] = q[k] + eps * t;                       // :278
         p[k] = pm;
     }
-    double lres;
-    bool gfin;
-    eval_point<T, NPL>(tgt, m_lds, lane, D, q, g, lres, pos_finite, gfin);   // :279
+    const double lres = tgt.eval(q, g, lane, D);     // :279 -> hamiltonian.jl:204
     double kacc = 0.0;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -171,6 +158,13 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
         lq = lres;
         K = wave_allreduce1(kacc) / 2.0;
     }
+    // evaluate_ℓ's checks (hamiltonian.jl:203-211).  Every shipped family has "ℓq finite =>
+    // all q finite" (kFiniteLqImpliesFiniteQ), so the coordinate scan runs only on the rare
+    // non-finite ℓq; the gradient scan only for families that need it.
+    pos_finite = true;
+    bool gfin = true;
+    if (!T::kFiniteLqImpliesFiniteQ || !dm_isfinite(lq)) pos_finite = all_finite<T, NPL>(q);
+    if constexpr (!T::kFiniteLqImpliesFiniteGrad) gfin = all_finite<T, NPL>(g);
     lq = demote_lq(lq, pos_finite, gfin);
     lq_out = uni_f64(lq);
     pi_out = uni_f64(joint_logdensity(lq, K));
@@ -677,9 +671,9 @@ __global__ __launch_bounds__(64) void init_kernel(InitParams P) {
             if (2 * kk + 1 < NPL) q[2 * kk + 1] = e1 < D ? u01_closed_open(r2) * 4 - 2 : 0.0;
         }
     }
-    double lres;
-    bool pfin, gfin;
-    eval_point<T, NPL>(tgt, nullptr, lane, D, q, g, lres, pfin, gfin);
+    const bool pfin = all_finite<T, NPL>(q);
+    const double lres = tgt.eval(q, g, lane, D);
+    const bool gfin = T::kFiniteLqImpliesFiniteGrad ? true : all_finite<T, NPL>(g);
     double lq = T::kDeferred ? tgt.finish(wave_allreduce1(lres)) : lres;
     uint32_t status = 0;
     if (!pfin) {

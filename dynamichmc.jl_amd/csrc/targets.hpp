@@ -11,8 +11,9 @@
 //                                calls finish()), or ℓ itself (kDeferred = false).
 //   kRecomputeGrad               ∇ℓ is cheap enough that a stored proposal keeps only q and the
 //                                gradient is re-evaluated when the proposal becomes the chain's position.
-//   kGradFiniteIfPosFinite       a finite position implies (ℓ finite or -Inf) and, when ℓ is
-//                                finite, a finite gradient: the ∇ℓ scan of evaluate_ℓ
+//   kFiniteLqImpliesFiniteQ      a finite ℓq is only possible at a finite position, so the position scan
+//                                of evaluate_ℓ (src/hamiltonian.jl:203) is needed only when ℓq is not finite.
+//   kFiniteLqImpliesFiniteGrad   a finite ℓq implies a finite gradient, so the ∇ℓ scan of evaluate_ℓ
 //                                (src/hamiltonian.jl:205) cannot change the outcome and is skipped.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,8 +30,9 @@ struct TargetParams {
 
 struct StdNormalT {
     static constexpr bool kDeferred = true;
-    static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit StdNormalT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int, int) const {
@@ -47,8 +49,9 @@ struct StdNormalT {
 
 struct DiagNormalT {
     static constexpr bool kDeferred = true;
-    static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* mu;
     const double* prec;
     __device__ explicit DiagNormalT(const TargetParams& p) : mu(p.a), prec(p.b) {}
@@ -70,8 +73,9 @@ struct DiagNormalT {
 // ℓ = -1/2 q'Pq, P symmetric tridiagonal: (Pq)_i = diag_i q_i + off_{i-1} q_{i-1} + off_i q_{i+1}
 struct TridiagNormalT {
     static constexpr bool kDeferred = true;
-    static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* diag;
     const double* off;
     __device__ explicit TridiagNormalT(const TargetParams& p) : diag(p.a), off(p.b) {}
@@ -103,8 +107,9 @@ struct TridiagNormalT {
 //   ℓ = -v²/18 - 1/2 e^{-v} Σ_{i>=1} q_i² - (D-1)/2 v
 struct FunnelT {
     static constexpr bool kDeferred = false;
-    static constexpr bool kGradFiniteIfPosFinite = false;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |e^{-v} q_i| <= max(e^{-v}, e^{-v} q_i^2)
     static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit FunnelT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
@@ -131,8 +136,9 @@ struct FunnelT {
 // The reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)
 struct AlwaysDivergentT {
     static constexpr bool kDeferred = false;
-    static constexpr bool kGradFiniteIfPosFinite = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit AlwaysDivergentT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {

@@ -31,6 +31,14 @@ __device__ __forceinline__ double dpp_f64(double x) {
     uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+// DPP move restricted to the rows of ROWMASK; the other rows receive +0.0.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_rows_f64(double x) {
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     uint64_t b = (uint64_t)__double_as_longlong(x);
     uint32_t lo = __builtin_amdgcn_readlane((uint32_t)b, lane);
@@ -42,8 +50,9 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 // value, made scalar) getting the same bits.  The pairing is the xor butterfly 1,2,4,8,16,32:
 // the ABI's summation order (include/dhmc.h; oracle/mathops.hpp wave_tree).  Steps 1-8 are
 // DPP (quad_perm, row_half_mirror, row_mirror: equal to xor 1,2,4,8 because the lanes of
-// each already-reduced group hold identical values); 16 and 32 go through readlane of the
-// four row totals, which also leaves the result in SGPRs.
+// each already-reduced group hold identical values); 16 and 32 are row_bcast15 / row_bcast31,
+// which leave (r3 + r2) + (r1 + r0) in lane 63 — the same bits as (r0 + r1) + (r2 + r3) since
+// IEEE addition commutes — read back as a scalar.
 template <int N>
 __device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
 #pragma unroll
@@ -55,11 +64,11 @@ __device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x140>(v[i]);  // row_mirror
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double r0 = readlane_f64(v[i], 0), r1 = readlane_f64(v[i], 16);
-        double r2 = readlane_f64(v[i], 32), r3 = readlane_f64(v[i], 48);
-        v[i] = (r0 + r1) + (r2 + r3);
-    }
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x142, 0xA>(v[i]);  // row_bcast15 -> rows 1,3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x143, 0xC>(v[i]);  // row_bcast31 -> rows 2,3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = readlane_f64(v[i], 63);  // (r3 + r2) + (r1 + r0), now scalar
 }
 __device__ __forceinline__ double wave_allreduce1(double x) {
     double v[1] = {x};
