@@ -1,0 +1,440 @@
+"""Host-side mirror of DynamicHMC.jl's calling surface for the many-chain HIP path.
+
+Same names, keyword arguments, defaults and result fields as the reference's `src/mcmc.jl`,
+`src/NUTS.jl`, `src/stepsize.jl` and `src/hamiltonian.jl`, with one addition: every array has
+a leading chain dimension (the reference runs one chain per call and leaves multi-chain runs
+to the caller, docs/src/worked_example.md:95-104).  All sampling work happens inside
+libdhmc_amd.so; this module only orchestrates stages, exactly as the reference's `_warmup`
+fold (mcmc.jl:450-457) does.
+
+The reference's host language is Julia, which is not installed in this environment, so the
+tested host wrapper is this Python twin; INTEGRATION.md shows the equivalent `ccall` shim.
+"""
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _abi as abi
+from .context import DeviceContext, DynamicHMCError
+
+__all__ = [
+    "NUTS", "InitialStepsizeSearch", "DualAveraging", "FixedStepsize", "TuningNUTS",
+    "default_warmup_stages", "fixed_stepsize_warmup_stages", "GaussianKineticEnergy",
+    "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
+    "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
+    "StandardNormal", "DiagNormal", "TridiagNormal", "Funnel", "AlwaysDivergent",
+    "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
+    "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
+]
+
+Diagonal = "Diagonal"
+Symmetric = "Symmetric"
+MAX_DIRECTIONS_DEPTH = 32          # trees.jl:10
+DEFAULT_MAX_TREE_DEPTH = 10        # NUTS.jl:166
+
+
+def _argcheck(cond, msg):
+    if not cond:
+        raise ValueError(f"ArgumentError: {msg}")   # the reference's @argcheck
+
+
+# ---- algorithm / adaptation parameter objects ------------------------------------------------
+
+@dataclass(frozen=True)
+class NUTS:
+    """NUTS(; max_depth, min_Δ, turn_statistic_configuration) — NUTS.jl:178-195."""
+    max_depth: int = DEFAULT_MAX_TREE_DEPTH
+    min_delta: float = -1000.0
+    turn_statistic_configuration: str = "generalized"
+
+    def __post_init__(self):
+        _argcheck(0 < self.max_depth <= MAX_DIRECTIONS_DEPTH, "0 < max_depth ≤ MAX_DIRECTIONS_DEPTH")
+        _argcheck(self.min_delta < 0, "min_Δ < 0")
+        _argcheck(self.turn_statistic_configuration == "generalized", "only Val(:generalized) is supported")
+
+
+@dataclass(frozen=True)
+class InitialStepsizeSearch:
+    """stepsize.jl:23-36."""
+    initial_eps: float = 0.1
+    log_threshold: float = math.log(0.8)
+    maxiter_crossing: int = 400
+
+    def __post_init__(self):
+        _argcheck(math.isfinite(self.log_threshold) and self.log_threshold < 0, "isfinite(log_threshold) && log_threshold < 0")
+        _argcheck(math.isfinite(self.initial_eps) and 0 < self.initial_eps, "isfinite(initial_ϵ) && 0 < initial_ϵ")
+        _argcheck(self.maxiter_crossing >= 50, "maxiter_crossing ≥ 50")
+
+
+@dataclass(frozen=True)
+class DualAveraging:
+    """stepsize.jl:98-118."""
+    delta: float = 0.8
+    gamma: float = 0.05
+    kappa: float = 0.75
+    t0: int = 10
+
+    def __post_init__(self):
+        _argcheck(0 < self.delta < 1, "0 < δ < 1")
+        _argcheck(self.gamma > 0, "γ > 0")
+        _argcheck(0.5 < self.kappa <= 1, "0.5 < κ ≤ 1")
+        _argcheck(self.t0 >= 0, "t₀ ≥ 0")
+
+
+@dataclass(frozen=True)
+class FixedStepsize:
+    """stepsize.jl:181-189."""
+
+
+@dataclass(frozen=True)
+class TuningNUTS:
+    """TuningNUTS{M}(N, stepsize_adaptation, λ = 5/N) — mcmc.jl:178-195.  M is None, Diagonal or Symmetric."""
+    N: int
+    stepsize_adaptation: Any = field(default_factory=DualAveraging)
+    M: Optional[str] = None
+    lam: Optional[float] = None
+
+    def __post_init__(self):
+        _argcheck(self.M in (None, Diagonal, Symmetric), "M <: Union{Nothing,Diagonal,Symmetric}")
+        _argcheck(self.N >= 20, "N ≥ 20")
+        if self.lam is None:
+            object.__setattr__(self, "lam", 5.0 / self.N)
+        _argcheck(self.lam >= 0, "λ ≥ 0")
+
+
+def _doubling_warmup_stages(M, stepsize_adaptation, middle_steps, doubling_stages):   # mcmc.jl:400-403
+    return tuple(TuningNUTS(middle_steps * 2 ** i, stepsize_adaptation, M) for i in range(doubling_stages))
+
+
+def default_warmup_stages(stepsize_search=InitialStepsizeSearch(), M=Diagonal, stepsize_adaptation=DualAveraging(),
+                          init_steps=75, middle_steps=25, doubling_stages=5, terminating_steps=50):
+    """mcmc.jl:415-425: 75 + 25·(1+2+4+8+16) + 50 = 900 transitions by default."""
+    _argcheck(M in (Diagonal, Symmetric), "M <: Union{Diagonal,Symmetric}")
+    return (stepsize_search, TuningNUTS(init_steps, stepsize_adaptation, None),
+            *_doubling_warmup_stages(M, stepsize_adaptation, middle_steps, doubling_stages),
+            TuningNUTS(terminating_steps, stepsize_adaptation, None))
+
+
+def fixed_stepsize_warmup_stages(M=Diagonal, middle_steps=25, doubling_stages=5):
+    """mcmc.jl:436-440."""
+    _argcheck(M in (Diagonal, Symmetric), "M <: Union{Diagonal,Symmetric}")
+    return _doubling_warmup_stages(M, FixedStepsize(), middle_steps, doubling_stages)
+
+
+# ---- kinetic energy, phase-space containers ----------------------------------------------------
+
+class GaussianKineticEnergy:
+    """hamiltonian.jl:56-87.  `GaussianKineticEnergy(N, m_inv=1.0)` (:87) or
+    `GaussianKineticEnergy(diag)` with the diagonal of M⁻¹ as [D] (shared) or [C][D] (:80)."""
+
+    def __init__(self, Minv, m_inv=1.0, dense=False):
+        if dense:
+            raise NotImplementedError("dense (Symmetric) M⁻¹ is not implemented in this build")
+        if isinstance(Minv, (int, np.integer)):
+            Minv = np.full(int(Minv), float(m_inv))
+        Minv = np.asarray(Minv, np.float64)
+        _argcheck(Minv.ndim in (1, 2), "diag(M⁻¹) is [D] (shared) or [C][D] (per chain)")
+        _argcheck(np.all(Minv > 0), "diagonal of M⁻¹ must be positive")
+        self.Minv = Minv
+        self.W = np.sqrt(1.0 / Minv)          # W such that W*W' = M (:80)
+
+    def size(self):
+        return self.Minv.shape[-1]
+
+    def __repr__(self):
+        return f"Gaussian kinetic energy (Diagonal), √diag(M⁻¹): {np.sqrt(self.Minv)}"   # hamiltonian.jl:89-91
+
+
+@dataclass
+class EvaluatedLogDensity:
+    """hamiltonian.jl:165-186, for C chains: q [C][D], ℓq [C], ∇ℓq [C][D]."""
+    q: np.ndarray
+    lq: np.ndarray
+    grad: np.ndarray
+
+
+@dataclass
+class WarmupState:
+    """mcmc.jl:72-79."""
+    Q: EvaluatedLogDensity
+    kappa: GaussianKineticEnergy
+    eps: Optional[np.ndarray]
+
+    def __repr__(self):
+        e = "unspecified" if self.eps is None else f"≈ {np.round(np.median(self.eps), 3)} (median over chains)"
+        return f"adapted sampling parameters: stepsize (ϵ) {e}, {self.kappa!r}"
+
+
+@dataclass
+class TreeStatisticsNUTS:
+    """NUTS.jl:208-221 as a structure of arrays, each [C][N]; `termination` is (left, right)
+    (trees.jl:180-202: left == right divergence, left < right turning, (1, 0) reached max depth)."""
+    pi: np.ndarray
+    depth: np.ndarray
+    termination_left: np.ndarray
+    termination_right: np.ndarray
+    acceptance_rate: np.ndarray
+    steps: np.ndarray
+    directions: np.ndarray
+
+    @property
+    def is_divergent(self):
+        return self.termination_left == self.termination_right
+
+
+# ---- log densities (the LogDensityProblems side of the boundary) -------------------------------
+
+class _Target:
+    family = None
+
+    def capabilities(self):      # LogDensityProblems.capabilities ≥ LogDensityOrder(1) (hamiltonian.jl:146)
+        return 1
+
+    def dimension(self):         # LogDensityProblems.dimension (hamiltonian.jl:147)
+        return self.D
+
+    def params(self):
+        return None
+
+
+class StandardNormal(_Target):
+    """ℓ(q) = -½ Σ q², ∇ℓ = -q."""
+    family = abi.TARGET_STD_NORMAL
+
+    def __init__(self, D):
+        self.D = int(D)
+
+
+class DiagNormal(_Target):
+    """ℓ(q) = -½ Σ prec_i (q_i - μ_i)²  (the reference tests' multivariate_normal(μ, I·v), test/utilities.jl:67)."""
+    family = abi.TARGET_DIAG_NORMAL
+
+    def __init__(self, mu, prec):
+        self.mu = np.asarray(mu, np.float64); self.prec = np.broadcast_to(np.asarray(prec, np.float64), self.mu.shape).copy()
+        self.D = self.mu.size
+
+    def params(self):
+        return np.concatenate([self.mu, self.prec])
+
+
+class TridiagNormal(_Target):
+    """ℓ(q) = -½ q'Pq with symmetric tridiagonal precision P (diag [D], off [D-1])."""
+    family = abi.TARGET_TRIDIAG_NORMAL
+
+    def __init__(self, diag, off):
+        self.diag = np.asarray(diag, np.float64); self.D = self.diag.size
+        self.off = np.zeros(self.D); self.off[:self.D - 1] = np.asarray(off, np.float64)[:self.D - 1]
+
+    def params(self):
+        return np.concatenate([self.diag, self.off])
+
+
+class Funnel(_Target):
+    """Neal's funnel: v = q₀ ~ N(0, 3²), q_i | v ~ N(0, eᵛ)."""
+    family = abi.TARGET_FUNNEL
+
+    def __init__(self, D):
+        self.D = int(D)
+
+
+class AlwaysDivergent(_Target):
+    """The reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)."""
+    family = abi.TARGET_ALWAYS_DIVERGENT
+
+    def __init__(self, K):
+        self.D = int(K)
+
+
+# ---- rng, reporters -----------------------------------------------------------------------------
+
+@dataclass
+class PhiloxRNG:
+    """Stands in for the reference's `rng::AbstractRNG` argument: the seed of the ABI's
+    counter-based stream (include/dhmc.h); chain c uses key (seed, chain_offset + c)."""
+    seed: int = 0x23EF614D
+    chain_offset: int = 0
+
+
+class NoProgressReport:
+    """reporting.jl:14."""
+
+    def report(self, *a, **k):
+        pass
+
+
+class LogProgressReport:
+    """reporting.jl:62-69, called once per stage / per batched sweep (not per draw)."""
+
+    def __init__(self, chain_id=None, step_interval=100, time_interval_s=1000.0, printer=print):
+        self.chain_id, self.step_interval, self.time_interval_s, self.printer = chain_id, step_interval, time_interval_s, printer
+        self._t0 = time.time()
+
+    def report(self, message, **meta):
+        extra = ", ".join(f"{k} = {v}" for k, v in meta.items())
+        self.printer(f"[ Info: {message}" + (f"  {extra}" if extra else ""))
+
+
+def default_reporter():
+    """reporting.jl:184-190: log when interactive, otherwise none."""
+    import sys
+    return LogProgressReport() if hasattr(sys, "ps1") else NoProgressReport()
+
+
+# ---- the driver ---------------------------------------------------------------------------------
+
+@dataclass
+class SamplingLogDensity:
+    """mcmc.jl:41-58 plus the device context that holds the chains."""
+    rng: PhiloxRNG
+    l: _Target
+    algorithm: NUTS
+    reporter: Any
+    ctx: DeviceContext
+
+
+def _as_rng(rng):
+    if isinstance(rng, PhiloxRNG):
+        return rng
+    if isinstance(rng, (int, np.integer)):
+        return PhiloxRNG(int(rng))
+    raise TypeError("rng must be a PhiloxRNG or an integer seed")
+
+
+def _collect(arrs):
+    ts = TreeStatisticsNUTS(arrs["pi"], arrs["depth"], arrs["term_left"], arrs["term_right"],
+                            arrs["acceptance_rate"], arrs["steps"], arrs["directions"])
+    return arrs["draws"], ts, arrs["logdensities"], arrs["eps"]
+
+
+def _state(ctx):
+    q, lq, g = ctx.position()
+    eps = ctx.stepsize()
+    kappa = GaussianKineticEnergy.__new__(GaussianKineticEnergy)
+    kappa.Minv = ctx.metric_diag(); kappa.W = np.sqrt(1.0 / kappa.Minv)
+    return WarmupState(EvaluatedLogDensity(q, lq, g), kappa, None if np.isnan(eps).all() else eps)
+
+
+def initialize_warmup_state(slogd, q=None, kappa=None, eps=None, **unknown):
+    """mcmc.jl:129-132: q default random_position (mcmc.jl:108), κ default unit metric, ϵ default nothing."""
+    for k in unknown:
+        if k not in ("κ", "ϵ"):
+            raise ValueError(f"ArgumentError: unknown initialization field {k}")
+    kappa = unknown.get("κ", kappa)
+    eps = unknown.get("ϵ", eps)
+    ctx = slogd.ctx
+    ctx.init(None if q is None else np.asarray(q, np.float64))
+    if kappa is not None:
+        _argcheck(kappa.size() == ctx.D, "dimension(ℓ) == size(κ, 1)")    # hamiltonian.jl:147
+        ctx.set_metric_diag(kappa.Minv)
+    if eps is not None:
+        ctx.set_stepsize(eps)
+    return _state(ctx)
+
+
+def warmup(slogd, stage, warmup_state):
+    """The three `warmup` methods of mcmc.jl:99,134-148,258-286.  Returns (results, warmup_state′)."""
+    ctx = slogd.ctx
+    if stage is None:                                         # mcmc.jl:99
+        return None, warmup_state
+    if isinstance(stage, InitialStepsizeSearch):              # mcmc.jl:134-148
+        _argcheck(warmup_state.eps is None, "stepsize ϵ manually specified, won't perform initial search")
+        ctx.find_initial_stepsize(stage.initial_eps, stage.log_threshold, stage.maxiter_crossing)
+        st = _state(ctx)
+        slogd.reporter.report("found initial stepsize", eps=float(np.median(st.eps)))
+        return None, st
+    if isinstance(stage, TuningNUTS):                         # mcmc.jl:258-286
+        if stage.M == Symmetric:
+            raise NotImplementedError("dense (Symmetric) metric adaptation is not implemented in this build")
+        _argcheck(warmup_state.eps is not None, "ϵ > 0")       # stepsize.jl:135
+        ad = stage.stepsize_adaptation
+        da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
+        draws, ts, lds, epss = _collect(ctx.run(stage.N, da=da))
+        if stage.M is not None:
+            ctx.update_metric_diag(draws, stage.lam)           # mcmc.jl:281-284
+            slogd.reporter.report("adaptation finished")
+        st = _state(ctx)
+        slogd.reporter.report("warmup stage finished", N=stage.N, eps=float(np.median(st.eps)))
+        return dict(posterior_matrix=draws, tree_statistics=ts, eps=epss, logdensities=lds), st
+    raise TypeError(f"unknown warmup stage {stage!r}")
+
+
+def _warmup(slogd, stages, initial_warmup_state):             # mcmc.jl:450-457
+    acc, st = [], initial_warmup_state
+    for stage in stages:
+        results, st = warmup(slogd, stage, st)
+        acc.append(dict(stage=stage, results=results, warmup_state=st))
+    return acc, st
+
+
+def mcmc(slogd, N, warmup_state):
+    """mcmc.jl:366-381."""
+    _argcheck(warmup_state.eps is not None, "ϵ > 0")
+    draws, ts, lds, _ = _collect(slogd.ctx.run(N))
+    slogd.reporter.report("inference finished", N=N)
+    return dict(posterior_matrix=draws, tree_statistics=ts, logdensities=lds)
+
+
+def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
+                     reporter=None, device=0):
+    """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU."""
+    warmup_stages = default_warmup_stages() if warmup_stages is None else warmup_stages
+    reporter = default_reporter() if reporter is None else reporter
+    rng = _as_rng(rng)
+    _argcheck(l.capabilities() >= 1, "capabilities(ℓ) ≥ LogDensityOrder(1)")   # hamiltonian.jl:146
+    ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
+                        max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
+                        chain_offset=rng.chain_offset, device=device)
+    slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx)
+    initial = initialize_warmup_state(slogd, **dict(initialization))
+    wu, final = _warmup(slogd, warmup_stages, initial)
+    inference = mcmc(slogd, N, final)
+    return dict(initial_warmup_state=initial, warmup=wu, final_warmup_state=final, inference=inference,
+                sampling_logdensity=slogd)
+
+
+def mcmc_with_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
+                     reporter=None, device=0):
+    """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C]."""
+    r = mcmc_keep_warmup(rng, l, N, chains=chains, initialization=initialization, warmup_stages=warmup_stages,
+                         algorithm=algorithm, reporter=reporter, device=device)
+    out = dict(r["inference"])
+    out["kappa"] = r["final_warmup_state"].kappa
+    out["eps"] = r["final_warmup_state"].eps
+    r["sampling_logdensity"].ctx.close()
+    return out
+
+
+@dataclass
+class MCMCSteps:
+    """mcmc.jl:295-300, bound to the context that holds the chains."""
+    slogd: SamplingLogDensity
+
+
+def mcmc_steps(sampling_logdensity, warmup_state=None):
+    """mcmc.jl:335-340 (constructor 2: from `mcmc_keep_warmup` results)."""
+    return MCMCSteps(sampling_logdensity)
+
+
+def mcmc_next_step(steps, Q=None):
+    """mcmc.jl:348-351: one transition of every chain; returns (Q′, tree statistics of that transition)."""
+    ctx = steps.slogd.ctx
+    draws, ts, lds, _ = _collect(ctx.run(1))
+    q, lq, g = ctx.position()
+    return EvaluatedLogDensity(q, lq, g), ts
+
+
+def stack_posterior_matrices(results):
+    """mcmc.jl:602-604: [draw, chain, parameter].  Accepts one multi-chain result or a list of results."""
+    rs = results if isinstance(results, (list, tuple)) else [results]
+    pm = np.concatenate([np.asarray(r["posterior_matrix"]) for r in rs], axis=0)   # [C][N][D]
+    return np.transpose(pm, (1, 0, 2))
+
+
+def pool_posterior_matrices(results):
+    """mcmc.jl:615-617: [parameter, pooled draw]."""
+    rs = results if isinstance(results, (list, tuple)) else [results]
+    pm = np.concatenate([np.asarray(r["posterior_matrix"]) for r in rs], axis=0)
+    return pm.reshape(-1, pm.shape[-1]).T

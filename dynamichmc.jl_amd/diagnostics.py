@@ -1,0 +1,56 @@
+"""Post-hoc NUTS diagnostics over the SoA tree statistics, after DynamicHMC.Diagnostics
+(src/diagnostics.jl) — cold path, host side, per chain."""
+from collections import Counter
+
+import numpy as np
+
+ACCEPTANCE_QUANTILES = [0.05, 0.25, 0.5, 0.75, 0.95]      # diagnostics.jl:35
+
+
+def EBFMI(tree_statistics):
+    """Energy Bayesian fraction of missing information (diagnostics.jl:29): mean(abs2, diff(π)) / var(π), per chain."""
+    pi = np.asarray(tree_statistics.pi)
+    return (np.diff(pi, axis=1) ** 2).mean(axis=1) / pi.var(axis=1, ddof=1)
+
+
+def count_terminations(tree_statistics):
+    """diagnostics.jl:65-82: counts of divergence / max depth / turning, pooled over chains."""
+    l, r = np.asarray(tree_statistics.termination_left), np.asarray(tree_statistics.termination_right)
+    maxd = (l == 1) & (r == 0)
+    div = (l == r)
+    return dict(max_depth=int(maxd.sum()), divergence=int(div.sum()), turning=int((~maxd & ~div).sum()))
+
+
+def count_depths(tree_statistics):
+    """diagnostics.jl:87-95."""
+    return dict(sorted(Counter(np.asarray(tree_statistics.depth).ravel().tolist()).items()))
+
+
+def summarize_tree_statistics(tree_statistics):
+    """diagnostics.jl:100-106."""
+    a = np.asarray(tree_statistics.acceptance_rate)
+    return dict(N=a.size, a_mean=float(a.mean()), a_quantiles=np.quantile(a, ACCEPTANCE_QUANTILES).tolist(),
+                termination_counts=count_terminations(tree_statistics), depth_counts=count_depths(tree_statistics))
+
+
+def ess_rhat(x):
+    """Multi-chain bulk ESS and R-hat of one scalar, x [C][N] (Vehtari et al. 2021 estimator with
+    Geyer's initial monotone sequence; no rank normalisation).  The reference's tests use
+    MCMCDiagnosticTools.ess_rhat (test/sample-correctness_utilities.jl:40-43), not vendored."""
+    x = np.asarray(x, np.float64)
+    C, N = x.shape
+    xm = x - x.mean(axis=1, keepdims=True)
+    nfft = 1 << (2 * N - 1).bit_length()
+    f = np.fft.rfft(xm, n=nfft, axis=1)
+    acov = np.fft.irfft(f * np.conj(f), n=nfft, axis=1)[:, :N] / N
+    W = (acov[:, 0] * N / (N - 1)).mean()
+    B = x.mean(axis=1).var(ddof=1) * N if C > 1 else 0.0
+    var_plus = W * (N - 1) / N + B / N
+    rho = 1 - (W - acov.mean(axis=0)) / var_plus
+    rho[0] = 1
+    T = N // 2
+    pair = rho[0:2 * T:2] + rho[1:2 * T:2]
+    k = np.argmax(pair <= 0) if (pair <= 0).any() else len(pair)
+    pair = np.minimum.accumulate(np.clip(pair[:k], 0, None))
+    tau = max(-1 + 2 * pair.sum(), 1 / np.log10(C * N))
+    return C * N / tau, float(np.sqrt(var_plus / W))

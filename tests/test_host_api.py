@@ -1,0 +1,117 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/dhmc.h declares,
+fails loudly without a GPU, and the host wrapper mirrors the reference's parameter objects,
+@argcheck rules and default warmup schedule.  No compute calls here (no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "dhmc.h")).read()
+    declared = set(re.findall(r"\b(dhmc_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = pkg.abi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dhmc.h but not exported"
+    assert declared == set(pkg.abi.SYMBOLS)
+    assert b"gfx950" in lib.dhmc_version()
+
+
+def test_struct_layouts_match_header(pkg):
+    import ctypes as C
+    # sizes implied by include/dhmc.h on LP64
+    assert C.sizeof(pkg.abi.Config) == 64
+    assert C.sizeof(pkg.abi.StepsizeSearch) == 24
+    assert C.sizeof(pkg.abi.DualAveragingABI) == 40
+    assert C.sizeof(pkg.abi.Outputs) == 8 + 10 * 8
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.DeviceContext(10, 2)
+
+
+def test_argchecks_mirror_reference(pkg):
+    with pytest.raises(ValueError): pkg.NUTS(max_depth=0)                     # NUTS.jl:190
+    with pytest.raises(ValueError): pkg.NUTS(max_depth=33)
+    with pytest.raises(ValueError): pkg.NUTS(min_delta=0.5)                   # NUTS.jl:191
+    with pytest.raises(ValueError): pkg.InitialStepsizeSearch(log_threshold=float("nan"))   # test_stepsize.jl:13
+    with pytest.raises(ValueError): pkg.InitialStepsizeSearch(log_threshold=1.0)            # :14
+    with pytest.raises(ValueError): pkg.InitialStepsizeSearch(initial_eps=-0.5)             # :15
+    with pytest.raises(ValueError): pkg.InitialStepsizeSearch(maxiter_crossing=2)           # :16
+    with pytest.raises(ValueError): pkg.DualAveraging(delta=1.0)              # stepsize.jl:108
+    with pytest.raises(ValueError): pkg.DualAveraging(gamma=0.0)
+    with pytest.raises(ValueError): pkg.DualAveraging(kappa=0.5)
+    with pytest.raises(ValueError): pkg.DualAveraging(t0=-1)
+    with pytest.raises(ValueError): pkg.TuningNUTS(19)                        # mcmc.jl:191
+    with pytest.raises(ValueError): pkg.TuningNUTS(50, lam=-1.0)              # mcmc.jl:192
+    assert pkg.TuningNUTS(50).lam == 0.1                                      # λ = 5/N
+    d = pkg.DualAveraging()
+    assert (d.delta, d.gamma, d.kappa, d.t0) == (0.8, 0.05, 0.75, 10)         # stepsize.jl:116
+    n = pkg.NUTS()
+    assert (n.max_depth, n.min_delta) == (10, -1000.0)                        # NUTS.jl:166,188
+
+
+def test_default_warmup_stages(pkg):   # mcmc.jl:415-425
+    st = pkg.default_warmup_stages()
+    assert isinstance(st[0], pkg.InitialStepsizeSearch)
+    assert [s.N for s in st[1:]] == [75, 25, 50, 100, 200, 400, 50]
+    assert [s.M for s in st[1:]] == [None] + [pkg.Diagonal] * 5 + [None]
+    assert sum(s.N for s in st[1:]) == 900
+    fs = pkg.fixed_stepsize_warmup_stages()                                   # mcmc.jl:436-440
+    assert [s.N for s in fs] == [25, 50, 100, 200, 400]
+    assert all(isinstance(s.stepsize_adaptation, pkg.FixedStepsize) for s in fs)
+    st2 = pkg.default_warmup_stages(stepsize_search=None, M=pkg.Symmetric, doubling_stages=2)
+    assert st2[0] is None and [s.M for s in st2[1:]] == [None, pkg.Symmetric, pkg.Symmetric, None]
+
+
+def test_kinetic_energy_and_targets(pkg):
+    k = pkg.GaussianKineticEnergy(np.array([1.0, 4.0]))
+    assert repr(k) == "Gaussian kinetic energy (Diagonal), √diag(M⁻¹): [1. 2.]"   # test_hamiltonian.jl:204-206
+    assert np.allclose(k.Minv * k.W * k.W, 1.0)                                # M⁻¹ W Wᵀ = I (test_hamiltonian.jl:42)
+    assert pkg.GaussianKineticEnergy(5, 0.1).Minv.tolist() == [0.1] * 5       # hamiltonian.jl:87
+    t = pkg.DiagNormal(np.ones(5), 1.0)
+    assert t.dimension() == 5 and t.capabilities() >= 1 and t.params().shape == (10,)
+    assert pkg.StandardNormal(7).params() is None
+
+
+def test_posterior_matrix_helpers(pkg):   # mcmc.jl:602-617; test_mcmc.jl:74-80
+    C, N, D = 3, 11, 4
+    pm = np.arange(C * N * D, dtype=float).reshape(C, N, D)
+    stacked = pkg.stack_posterior_matrices({"posterior_matrix": pm})
+    assert stacked.shape == (N, C, D) and stacked[5, 2, 1] == pm[2, 5, 1]
+    pooled = pkg.pool_posterior_matrices([{"posterior_matrix": pm[:2]}, {"posterior_matrix": pm[2:]}])
+    assert pooled.shape == (D, N * C) and pooled[3, N + 2] == pm[1, 2, 3]
+
+
+def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8, 2.2]
+    rng = np.random.default_rng(1)
+    ts = pkg.TreeStatisticsNUTS(pi=rng.normal(size=(4, 5000)), depth=rng.integers(0, 5, (4, 5000)),
+                                termination_left=np.where(rng.random((4, 5000)) < 0.1, 3, -3), termination_right=np.full((4, 5000), 3),
+                                acceptance_rate=rng.random((4, 5000)), steps=np.ones((4, 5000), int), directions=np.zeros((4, 5000), np.uint32))
+    e = pkg.diagnostics.EBFMI(ts)
+    assert ((1.8 < e) & (e < 2.2)).all()
+    s = pkg.diagnostics.summarize_tree_statistics(ts)
+    assert s["N"] == 20000 and sum(s["termination_counts"].values()) == 20000 and sum(s["depth_counts"].values()) == 20000
+    ess, rhat = pkg.diagnostics.ess_rhat(rng.normal(size=(4, 2000)))
+    assert 6000 < ess < 10000 and abs(rhat - 1) < 0.01
+
+
+def test_shard_chains(pkg):
+    for total, world in ((4096, 8), (10, 4), (3, 8), (32768, 8)):
+        blocks = [pkg.sharding.shard_chains(total, world, r) for r in range(world)]
+        assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
+        for (o1, c1), (o2, _) in zip(blocks, blocks[1:]):
+            assert o1 + c1 == o2
