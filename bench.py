@@ -32,6 +32,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_LEAPFROG = 48 * D   # read q,p,∇ℓ + write q',p',∇ℓ' in fp64
 
 
+ALL_RUN_LEAPFROGS = [0]   # every dhmc_run of this process (setup + warmup + timed + ESS), for the PMC summaries
+
+
+def _run(ctx, n, arrays, **kw):
+    ctx.run_into(n, arrays, **kw)
+    ALL_RUN_LEAPFROGS[0] += ctx.last_run_leapfrogs()
+
+
+def measured_traffic_per_leapfrog():
+    """HBM bytes per leapfrog from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate runs; tools/profile.sh -> profiles/*traffic.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        return json.load(fh).get("hbm_bytes_per_leapfrog"), os.path.basename(files[-1])
+
+
 def setup_context(pkg, torch, rank, chains, seed, short):
     stream = torch.cuda.current_stream().cuda_stream
     ctx = pkg.DeviceContext(D, chains, seed=seed, chain_offset=rank * chains, device=torch.cuda.current_device(),
@@ -42,7 +61,7 @@ def setup_context(pkg, torch, rank, chains, seed, short):
     stages = [(20, False), (25, True), (20, False)] if short else [(75, False), (25, True), (50, True), (100, True), (50, False)]
     for n, metric in stages:
         draws = torch.empty((chains, n, D), dtype=torch.float64, device="cuda") if metric else None
-        ctx.run_into(n, {"draws": draws} if metric else {}, da={})
+        _run(ctx, n, {"draws": draws} if metric else {}, da={})
         if metric:
             ctx.update_metric_diag(draws)
         del draws
@@ -143,12 +162,12 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(Wn):
-        ctx.run_into(T, out)
+        _run(ctx, T, out)
     sync()
     kernel_ms, leapfrogs = [], 0
     t0 = time.perf_counter()
     for _ in range(K):
-        ctx.run_into(T, out)
+        _run(ctx, T, out)
         kernel_ms.append(ctx.last_run_kernel_ms())
         leapfrogs += ctx.last_run_leapfrogs()
     sync()
@@ -163,7 +182,7 @@ def main():
     ess_T = 100
     ess_draws = torch.empty((C, ess_T, D), dtype=torch.float64, device="cuda")
     e0 = time.perf_counter()
-    ctx.run_into(ess_T, {"draws": ess_draws})
+    _run(ctx, ess_T, {"draws": ess_draws})
     torch.cuda.synchronize()
     ess_dt = time.perf_counter() - e0
     ess = bulk_ess_min(torch, ess_draws)
@@ -186,6 +205,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         per_launch = leapfrogs / K
         achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
+        tpl, tsrc = measured_traffic_per_leapfrog()
         line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",
             "value": total_leapfrogs / t_max,
@@ -204,10 +224,14 @@ def main():
             "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
                      "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if tpl is None else tpl * per_launch, "traffic_source": tsrc,
                          "kernel": "nuts_run_kernel<StdNormalT,16>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_leapfrog": ALGO_BYTES_PER_LEAPFROG,
-                         "leapfrogs_per_launch": per_launch},
+                         "leapfrogs_per_launch": per_launch,
+                         "note": "state is register/LDS-resident, so achieved (algorithmic bytes / time) can exceed "
+                                 "the HBM peak; traffic = real HBM bytes per launch from the PMC passes"},
+            "all_run_leapfrogs": ALL_RUN_LEAPFROGS[0],
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_transitions, os.cpu_count() or 1)

@@ -161,12 +161,18 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
     // evaluate_ℓ's checks (hamiltonian.jl:203-211).  Every shipped family has "ℓq finite =>
     // all q finite" (kFiniteLqImpliesFiniteQ), so the coordinate scan runs only on the rare
     // non-finite ℓq; the gradient scan only for families that need it.
+    lq = uni_f64(lq);
     pos_finite = true;
     bool gfin = true;
-    if (!T::kFiniteLqImpliesFiniteQ || !dm_isfinite(lq)) pos_finite = all_finite<T, NPL>(q);
+    if (!T::kFiniteLqImpliesFiniteQ || !dm_isfinite(lq)) {
+        double t[NPL];                               // opaque copies: the scan cannot be hoisted into the hot path
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) asm volatile("" : "=v"(t[k]) : "0"(q[k]));
+        pos_finite = all_finite<T, NPL>(t);
+    }
     if constexpr (!T::kFiniteLqImpliesFiniteGrad) gfin = all_finite<T, NPL>(g);
     lq = demote_lq(lq, pos_finite, gfin);
-    lq_out = uni_f64(lq);
+    lq_out = lq;
     pi_out = uni_f64(joint_logdensity(lq, K));
 }
 
