@@ -16,7 +16,7 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_L
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc3.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- python $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc4.err
 cd $REPO
-python tools/summarize_prof.py $OUT > $KEEP/summary.txt 2>&1
+find $OUT -name "*.csv" > $KEEP/files.txt; python tools/summarize_prof.py $OUT > $KEEP/summary.txt 2>&1
 cp $OUT/bench_trace.json $OUT/traffic.json $KEEP/ 2>/dev/null
 for f in $(find $OUT -name '*kernel_stats.csv' -o -name '*agent_info.csv' | head -4); do cp $f $KEEP/; done
 for e in $OUT/*.err; do echo "--- $e"; tail -3 $e; done

@@ -21,6 +21,17 @@ for f in find("*kernel_stats.csv"):
         name = r.get("Name", "")[:70]
         print(f"  {name:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
 
+for f in find("*kernel_trace.csv"):
+    print("== per-dispatch durations of nuts_run_kernel (ms), in launch order:", os.path.relpath(f, out))
+    with open(f) as fh:
+        rows = [r for r in csv.DictReader(fh) if "nuts_run_kernel" in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    print("  ", " ".join(f"{x:.3f}" for x in d))
+    print("   (bench.py --steps 3 --warmup 1: 3 adaptive setup launches of 20/25/20 transitions, then 1 warmup + 3 timed"
+          " launches of 20 transitions — compare these four with roofline.kernel_ms in bench_trace.json — then one"
+          " 100-transition ESS launch)")
+
 for f in find("*counter_collection.csv"):
     print("== counters", os.path.relpath(f, out))
     agg = defaultdict(lambda: defaultdict(list))
