@@ -131,11 +131,19 @@ class GaussianKineticEnergy:
     `GaussianKineticEnergy(diag)` with the diagonal of M⁻¹ as [D] (shared) or [C][D] (:80)."""
 
     def __init__(self, Minv, m_inv=1.0, dense=False):
-        if dense:
-            raise NotImplementedError("dense (Symmetric) M⁻¹ is not implemented in this build")
         if isinstance(Minv, (int, np.integer)):
             Minv = np.full(int(Minv), float(m_inv))
         Minv = np.asarray(Minv, np.float64)
+        self.dense = bool(dense)
+        if self.dense:                           # GaussianKineticEnergy(M⁻¹::AbstractMatrix) (:73), shared by all chains
+            _argcheck(Minv.ndim == 2 and Minv.shape[0] == Minv.shape[1], "checksquare(M⁻¹)")
+            S = np.triu(Minv) + np.triu(Minv, 1).T      # Symmetric(M⁻¹)
+            try:
+                self.W = np.linalg.cholesky(np.linalg.inv(S))
+            except np.linalg.LinAlgError:
+                raise ValueError("ArgumentError: M⁻¹ is not positive definite")
+            self.Minv = S
+            return
         _argcheck(Minv.ndim in (1, 2), "diag(M⁻¹) is [D] (shared) or [C][D] (per chain)")
         _argcheck(np.all(Minv > 0), "diagonal of M⁻¹ must be positive")
         self.Minv = Minv
@@ -144,8 +152,10 @@ class GaussianKineticEnergy:
     def size(self):
         return self.Minv.shape[-1]
 
-    def __repr__(self):
-        return f"Gaussian kinetic energy (Diagonal), √diag(M⁻¹): {np.sqrt(self.Minv)}"   # hamiltonian.jl:89-91
+    def __repr__(self):                           # hamiltonian.jl:89-91
+        if self.dense:
+            return f"Gaussian kinetic energy (Symmetric), √diag(M⁻¹): {np.sqrt(np.diag(self.Minv))}"
+        return f"Gaussian kinetic energy (Diagonal), √diag(M⁻¹): {np.sqrt(self.Minv)}"
 
 
 @dataclass
@@ -313,7 +323,11 @@ def _state(ctx):
     q, lq, g = ctx.position()
     eps = ctx.stepsize()
     kappa = GaussianKineticEnergy.__new__(GaussianKineticEnergy)
-    kappa.Minv = ctx.metric_diag(); kappa.W = np.sqrt(1.0 / kappa.Minv)
+    kappa.dense = ctx.cfg.metric == abi.METRIC_DENSE
+    if kappa.dense:
+        kappa.Minv, kappa.W = ctx.metric_dense()
+    else:
+        kappa.Minv = ctx.metric_diag(); kappa.W = np.sqrt(1.0 / kappa.Minv)
     return WarmupState(EvaluatedLogDensity(q, lq, g), kappa, None if np.isnan(eps).all() else eps)
 
 
@@ -328,7 +342,10 @@ def initialize_warmup_state(slogd, q=None, kappa=None, eps=None, **unknown):
     ctx.init(None if q is None else np.asarray(q, np.float64))
     if kappa is not None:
         _argcheck(kappa.size() == ctx.D, "dimension(ℓ) == size(κ, 1)")    # hamiltonian.jl:147
-        ctx.set_metric_diag(kappa.Minv)
+        if kappa.dense:
+            ctx.set_metric_dense(kappa.Minv)
+        else:
+            ctx.set_metric_diag(kappa.Minv)
     if eps is not None:
         ctx.set_stepsize(eps)
     return _state(ctx)
@@ -353,6 +370,8 @@ def warmup(slogd, stage, warmup_state):
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
         draws, ts, lds, epss = _collect(ctx.run(stage.N, da=da))
         if stage.M is not None:
+            if ctx.cfg.metric != abi.METRIC_DIAG:
+                raise NotImplementedError("metric adaptation with a dense κ is not implemented in this build")
             ctx.update_metric_diag(draws, stage.lam)           # mcmc.jl:281-284
             slogd.reporter.report("adaptation finished")
         st = _state(ctx)
@@ -384,9 +403,12 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     reporter = default_reporter() if reporter is None else reporter
     rng = _as_rng(rng)
     _argcheck(l.capabilities() >= 1, "capabilities(ℓ) ≥ LogDensityOrder(1)")   # hamiltonian.jl:146
+    init = dict(initialization)
+    k0 = init.get("κ", init.get("kappa"))
+    metric = abi.METRIC_DENSE if (k0 is not None and k0.dense) else abi.METRIC_DIAG
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
-                        chain_offset=rng.chain_offset, device=device)
+                        chain_offset=rng.chain_offset, device=device, metric=metric)
     slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx)
     initial = initialize_warmup_state(slogd, **dict(initialization))
     wu, final = _warmup(slogd, warmup_stages, initial)

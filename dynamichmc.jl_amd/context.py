@@ -121,6 +121,16 @@ class DeviceContext:
         self._chk(abi.lib().dhmc_get_metric_diag(self.h, _ptr(m), 0), "dhmc_get_metric_diag")
         return m
 
+    def set_metric_dense(self, minv):
+        """GaussianKineticEnergy(M⁻¹) with a full matrix shared by all chains (hamiltonian.jl:73)."""
+        minv = np.ascontiguousarray(minv, np.float64)
+        self._chk(abi.lib().dhmc_set_metric_dense(self.h, _ptr(minv), 0), "dhmc_set_metric_dense")
+
+    def metric_dense(self):
+        m = np.zeros((self.D, self.D)); W = np.zeros((self.D, self.D))
+        self._chk(abi.lib().dhmc_get_metric_dense(self.h, _ptr(m), _ptr(W)), "dhmc_get_metric_dense")
+        return m, W
+
     def set_stepsize(self, eps):
         eps = np.ascontiguousarray(np.atleast_1d(eps), np.float64)
         self._chk(abi.lib().dhmc_set_stepsize(self.h, _ptr(eps), int(eps.size == self.C), 0), "dhmc_set_stepsize")

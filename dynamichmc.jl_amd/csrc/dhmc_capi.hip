@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../include/dhmc.h"
+#include "dense_metric.hpp"
+#include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
 
 using namespace dhmc;
@@ -31,6 +33,9 @@ struct dhmc_ctx {
     double last_ms = 0.0;
     unsigned long long last_leapfrogs = 0;
     int l1_in_lds = 1;
+    DenseMetric dm{};          // DHMC_METRIC_DENSE only
+    double* d_Minv = nullptr;
+    double* d_WT = nullptr;
     uint64_t ws_bytes = 0;
     std::string err;
     std::vector<void*> allocs;
@@ -88,10 +93,21 @@ void launch_search(const SearchParams& P, hipStream_t s) {
     hipLaunchKernelGGL((stepsize_search_kernel<T, NPL>), dim3(P.C), dim3(WAVE), sizeof(double) * P.Dpad, s, P);
 }
 
+template <class T, int NPL>
+void launch_run_dense(const RunParams& P, const DenseMetric& M, hipStream_t s) {
+    hipLaunchKernelGGL((nuts_run_dense_kernel<T, NPL>), dim3(P.C), dim3(WAVE), lds_bytes_dense(), s, P, M);
+}
+template <class T, int NPL>
+void launch_search_dense(const SearchParams& P, const DenseMetric& M, hipStream_t s) {
+    hipLaunchKernelGGL((stepsize_search_dense_kernel<T, NPL>), dim3(P.C), dim3(WAVE), 0, s, P, M);
+}
+
 enum class Op { Run, Init, Search };
 
 template <class T, int NPL>
-void dispatch_op(Op op, const void* P, hipStream_t s) {
+void dispatch_op(Op op, const void* P, hipStream_t s, const DenseMetric* M) {
+    if (M && op == Op::Run) { launch_run_dense<T, NPL>(*(const RunParams*)P, *M, s); return; }
+    if (M && op == Op::Search) { launch_search_dense<T, NPL>(*(const SearchParams*)P, *M, s); return; }
     switch (op) {
     case Op::Run: launch_run<T, NPL>(*(const RunParams*)P, s); break;
     case Op::Init: launch_init<T, NPL>(*(const InitParams*)P, s); break;
@@ -99,25 +115,42 @@ void dispatch_op(Op op, const void* P, hipStream_t s) {
     }
 }
 template <class T>
-int dispatch_npl(int npl, Op op, const void* P, hipStream_t s) {
+int dispatch_npl(int npl, Op op, const void* P, hipStream_t s, const DenseMetric* M) {
     switch (npl) {
-    case 1: dispatch_op<T, 1>(op, P, s); return DHMC_OK;
-    case 2: dispatch_op<T, 2>(op, P, s); return DHMC_OK;
-    case 4: dispatch_op<T, 4>(op, P, s); return DHMC_OK;
-    case 8: dispatch_op<T, 8>(op, P, s); return DHMC_OK;
-    case 16: dispatch_op<T, 16>(op, P, s); return DHMC_OK;
+    case 1: dispatch_op<T, 1>(op, P, s, M); return DHMC_OK;
+    case 2: dispatch_op<T, 2>(op, P, s, M); return DHMC_OK;
+    case 4: dispatch_op<T, 4>(op, P, s, M); return DHMC_OK;
+    case 8: dispatch_op<T, 8>(op, P, s, M); return DHMC_OK;
+    case 16: dispatch_op<T, 16>(op, P, s, M); return DHMC_OK;
     default: return DHMC_ERR_UNSUPPORTED;
     }
 }
 int dispatch(const dhmc_ctx* c, Op op, const void* P) {
+    const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
     switch (c->cfg.target) {
-    case DHMC_TARGET_STD_NORMAL: return dispatch_npl<StdNormalT>(c->NPL, op, P, c->stream);
-    case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, c->stream);
-    case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, c->stream);
-    case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, c->stream);
-    case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, c->stream);
+    case DHMC_TARGET_STD_NORMAL: return dispatch_npl<StdNormalT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, c->stream, M);
     default: return DHMC_ERR_UNSUPPORTED;
     }
+}
+
+// upload S (symmetric M⁻¹) and Wᵀ padded to [Dpad][Dpad]
+int upload_dense_metric(dhmc_ctx* c, const std::vector<double>& S, const std::vector<double>& W) {
+    const int D = c->cfg.dim;
+    const size_t Dp = c->Dpad;
+    std::vector<double> a(Dp * Dp, 0.0), b(Dp * Dp, 0.0);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            a[(size_t)i * Dp + j] = S[(size_t)i * D + j];
+            b[(size_t)j * Dp + i] = W[(size_t)i * D + j];   // transpose: WT[k][i] = W[i][k]
+        }
+    HIP_TRY(c, hipMemcpyAsync(c->d_Minv, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_WT, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DHMC_OK;
 }
 void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
     int D = c->cfg.dim, Dp = c->Dpad, C = c->cfg.chains;
@@ -199,7 +232,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (cfg->dim <= 0 || cfg->chains <= 0 || cfg->chain_offset < 0) return DHMC_ERR_INVALID_ARGUMENT;
     if (!(0 < cfg->max_depth && cfg->max_depth <= 32)) return DHMC_ERR_INVALID_ARGUMENT;  // NUTS.jl:190
     if (!(cfg->min_delta < 0)) return DHMC_ERR_INVALID_ARGUMENT;                           // NUTS.jl:191
-    if (cfg->metric != DHMC_METRIC_DIAG) return DHMC_ERR_UNSUPPORTED;
+    if (cfg->metric != DHMC_METRIC_DIAG && cfg->metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
     const int D = cfg->dim;
     switch (cfg->target) {
     case DHMC_TARGET_STD_NORMAL: case DHMC_TARGET_ALWAYS_DIVERGENT: break;
@@ -218,7 +251,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->NPL = npl_for_dim(D);
     if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
     c->Dpad = c->NPL * WAVE;
-    c->nvec = ws_nvec(cfg->max_depth);
+    c->nvec = cfg->metric == DHMC_METRIC_DENSE ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
@@ -252,6 +285,14 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemcpy(db, b.data(), Dp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         c->tp.a = da;
         c->tp.b = db;
+    }
+    if (cfg->metric == DHMC_METRIC_DENSE) {   // GaussianKineticEnergy(N) as a dense identity
+        if ((rc = dev_alloc(c, &c->d_Minv, Dp * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_WT, Dp * Dp))) return fail(rc);
+        c->dm = DenseMetric{c->d_Minv, c->d_WT};
+        std::vector<double> I((size_t)D * D, 0.0);
+        for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
+        if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
     // unit metric, ε unspecified
@@ -311,7 +352,7 @@ int dhmc_get_position(dhmc_ctx* c, double* q, double* lq, double* grad, int on_d
 }
 
 int dhmc_set_metric_diag(dhmc_ctx* c, const double* minv, int per_chain, int on_device) {
-    if (!c || !minv) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!c || !minv || c->cfg.metric != DHMC_METRIC_DIAG) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int D = c->cfg.dim, C = c->cfg.chains;
     const size_t n = per_chain ? (size_t)C * D : (size_t)D;
@@ -336,9 +377,39 @@ int dhmc_get_metric_diag(dhmc_ctx* c, double* minv, int on_device) {
     return copy_out_padded(c, c->st.minv, minv, on_device);
 }
 
-int dhmc_set_metric_dense(dhmc_ctx* c, const double*, int) {
-    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
-    return DHMC_ERR_UNSUPPORTED;
+int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
+    if (!c || !minv || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int D = c->cfg.dim;
+    std::vector<double> h((size_t)D * D);
+    if (on_device) {
+        HIP_TRY(c, hipMemcpyAsync(h.data(), minv, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::memcpy(h.data(), minv, h.size() * sizeof(double));
+    }
+    for (double v : h)
+        if (!std::isfinite(v)) return DHMC_ERR_INVALID_ARGUMENT;
+    std::vector<double> S, W;
+    if (!host_dense_metric(h.data(), D, S, W)) return DHMC_ERR_INVALID_ARGUMENT;   // not positive definite
+    return upload_dense_metric(c, S, W);
+}
+
+int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int D = c->cfg.dim;
+    const size_t Dp = c->Dpad;
+    std::vector<double> a(Dp * Dp), b(Dp * Dp);
+    HIP_TRY(c, hipMemcpyAsync(a.data(), c->d_Minv, a.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b.data(), c->d_WT, b.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            if (minv) minv[(size_t)i * D + j] = a[(size_t)i * Dp + j];
+            if (W) W[(size_t)i * D + j] = b[(size_t)j * Dp + i];
+        }
+    return DHMC_OK;
 }
 
 int dhmc_set_stepsize(dhmc_ctx* c, const double* eps, int per_chain, int on_device) {
@@ -478,7 +549,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
 }
 
 int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
-    if (!c || !draws) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!c || !draws || c->cfg.metric != DHMC_METRIC_DIAG) return DHMC_ERR_INVALID_ARGUMENT;
     if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192 (N >= 20 is the host wrapper's check)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     Staged s;

@@ -155,8 +155,13 @@ int dhmc_get_position(dhmc_ctx* ctx, double* q, double* lq, double* grad, int on
 /* GaussianKineticEnergy(Diagonal(minv)) (hamiltonian.jl:80): minv [C][D] if per_chain else [D]. */
 int dhmc_set_metric_diag(dhmc_ctx* ctx, const double* minv, int per_chain, int on_device);
 int dhmc_get_metric_diag(dhmc_ctx* ctx, double* minv, int on_device); /* [C][D] */
-/* GaussianKineticEnergy(M⁻¹) dense (hamiltonian.jl:73): minv [D][D] symmetric, shared. */
+/* GaussianKineticEnergy(M⁻¹) dense (hamiltonian.jl:73), contexts created with DHMC_METRIC_DENSE only:
+ * minv [D][D], read as Symmetric(minv) from its upper triangle, shared by all chains;
+ * W = cholesky(inv(M⁻¹)).L is built by the library (unblocked Cholesky, order fixed by the ABI).
+ * Returns DHMC_ERR_INVALID_ARGUMENT if the matrix is not positive definite. */
 int dhmc_set_metric_dense(dhmc_ctx* ctx, const double* minv, int on_device);
+/* host [D][D] each, either may be NULL: the symmetrised M⁻¹ and the lower-triangular W (W Wᵀ = M). */
+int dhmc_get_metric_dense(dhmc_ctx* ctx, double* minv, double* W);
 /* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */
 int dhmc_set_stepsize(dhmc_ctx* ctx, const double* eps, int per_chain, int on_device);
 int dhmc_get_stepsize(dhmc_ctx* ctx, double* eps, int on_device); /* [C] */

@@ -44,7 +44,7 @@ inline void initialize_warmup_state(Chain& c, const Target& target, const MathOp
                                     const double* q0) {
     int D = target.D;
     VecP q = q0 ? std::make_shared<const Vec>(q0, q0 + D) : random_position(c.stream, D);
-    c.kappa = GaussianKineticEnergy::unit(D);
+    if (!c.kappa.dense) c.kappa = GaussianKineticEnergy::unit(D);   // dense contexts keep their (shared) metric
     c.status = 0;
     c.transition = 0;
     Hamiltonian H{&c.kappa, &target, M, &c.status};

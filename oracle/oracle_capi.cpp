@@ -13,6 +13,7 @@
 #include "../include/dhmc.h"
 #include "dummy.hpp"
 #include "mcmc.hpp"
+#include "metric.hpp"
 
 using namespace oracle;
 
@@ -49,7 +50,7 @@ int oracle_create(const dhmc_config* cfg, int det_math, oracle_ctx** out) {
     if (cfg->dim <= 0 || cfg->chains <= 0) return DHMC_ERR_INVALID_ARGUMENT;
     if (!(0 < cfg->max_depth && cfg->max_depth <= MAX_DIRECTIONS_DEPTH)) return DHMC_ERR_INVALID_ARGUMENT;  // NUTS.jl:190
     if (!(cfg->min_delta < 0)) return DHMC_ERR_INVALID_ARGUMENT;                                            // NUTS.jl:191
-    if (cfg->metric != DHMC_METRIC_DIAG) return DHMC_ERR_UNSUPPORTED;
+    if (cfg->metric != DHMC_METRIC_DIAG && cfg->metric != DHMC_METRIC_DENSE) return DHMC_ERR_UNSUPPORTED;
     auto c = std::make_unique<oracle_ctx>();
     c->cfg = *cfg;
     c->M.det = det_math != 0;
@@ -62,6 +63,12 @@ int oracle_create(const dhmc_config* cfg, int det_math, oracle_ctx** out) {
     for (int i = 0; i < cfg->chains; ++i) {
         c->chains[i].stream = ChainStream{cfg->seed, (uint32_t)(cfg->chain_offset + i)};
         c->chains[i].kappa = GaussianKineticEnergy::unit(cfg->dim);
+    }
+    if (cfg->metric == DHMC_METRIC_DENSE) {
+        std::vector<double> I((size_t)cfg->dim * cfg->dim, 0.0);
+        for (int i = 0; i < cfg->dim; ++i) I[(size_t)i * cfg->dim + i] = 1.0;
+        GaussianKineticEnergy k = GaussianKineticEnergy::dense_from(I.data(), cfg->dim);
+        for (auto& ch : c->chains) ch.kappa = k;
     }
     *out = c.release();
     return DHMC_OK;
@@ -97,6 +104,20 @@ int oracle_set_metric_diag(oracle_ctx* c, const double* minv, int per_chain) {
         if (!(minv[per_chain ? i : i % D] > 0)) return DHMC_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < C; ++i)
         c->chains[i].kappa = GaussianKineticEnergy::diagonal(per_chain ? minv + (size_t)i * D : minv, D);
+    return DHMC_OK;
+}
+int oracle_set_metric_dense(oracle_ctx* c, const double* minv) {
+    if (c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+    GaussianKineticEnergy k = GaussianKineticEnergy::dense_from(minv, c->cfg.dim);
+    if (k.D != c->cfg.dim) return DHMC_ERR_INVALID_ARGUMENT;  // not positive definite
+    for (auto& ch : c->chains) ch.kappa = k;
+    return DHMC_OK;
+}
+// W (lower triangular, row-major D×D) of chain 0's dense metric
+int oracle_get_metric_dense_W(oracle_ctx* c, double* W) {
+    const auto& k = c->chains[0].kappa;
+    if (!k.dense) return DHMC_ERR_INVALID_ARGUMENT;
+    std::memcpy(W, k.W.data(), sizeof(double) * k.W.size());
     return DHMC_OK;
 }
 int oracle_get_metric_diag(oracle_ctx* c, double* minv) {
@@ -345,6 +366,19 @@ uint32_t oracle_unit_leapfrog(const dhmc_config* cfg, int det, const double* min
         lqs[i] = z->Q.lq;
     }
     return st;
+}
+// n momentum draws p = W z from a dense kinetic energy built from minv [D][D] (rand_p,
+// hamiltonian.jl:124; test_hamiltonian.jl:29-30): transitions 0..n-1 of chain 0; also returns W.
+int oracle_unit_rand_p_dense(int D, const double* minv, uint64_t seed, int n, double* out, double* W) {
+    GaussianKineticEnergy k = GaussianKineticEnergy::dense_from(minv, D);
+    if (k.D != D) return 1;
+    ChainStream s{seed, 0};
+    for (int t = 0; t < n; ++t) {
+        VecP p = rand_p(MathOps{}, k, s, PURPOSE_MOMENTUM, (uint32_t)t);
+        std::memcpy(out + (size_t)t * D, p->data(), sizeof(double) * D);
+    }
+    std::memcpy(W, k.W.data(), sizeof(double) * (size_t)D * D);
+    return 0;
 }
 // find_initial_stepsize with A(ϵ) = slope*ϵ + intercept (test_stepsize.jl:9-25); returns 0 on
 // success, 1 where the reference throws

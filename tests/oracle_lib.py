@@ -158,7 +158,7 @@ class Oracle:
         lib().oracle_set_threads(self.h, threads)
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().oracle_destroy(self.h)
             self.h = None
 
@@ -182,6 +182,15 @@ class Oracle:
     def set_metric_diag(self, minv):
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(lib().oracle_set_metric_diag(self.h, _p(minv), int(minv.ndim == 2)))
+
+    def set_metric_dense(self, minv):
+        minv = np.ascontiguousarray(minv, np.float64)
+        self._chk(lib().oracle_set_metric_dense(self.h, _p(minv)))
+
+    def metric_dense_W(self):
+        W = np.zeros((self.D, self.D))
+        self._chk(lib().oracle_get_metric_dense_W(self.h, _p(W)))
+        return W
 
     def metric_diag(self):
         m = np.zeros((self.C, self.D))
@@ -328,3 +337,12 @@ def da_adapt(st, a, delta=0.8, gamma=0.05, kappa=0.75, t0=10, det=True):
     st = np.array(st, np.float64)
     lib().oracle_unit_da_adapt(int(det), C.c_double(delta), C.c_double(gamma), C.c_double(kappa), t0, _p(st), C.c_double(a))
     return st
+
+
+def rand_p_dense(minv, n, seed=1):
+    minv = np.ascontiguousarray(minv, np.float64); D = minv.shape[0]
+    out = np.zeros((n, D)); W = np.zeros((D, D))
+    rc = lib().oracle_unit_rand_p_dense(D, _p(minv), C.c_uint64(seed), n, _p(out), _p(W))
+    if rc:
+        raise ValueError("not positive definite")
+    return out, W

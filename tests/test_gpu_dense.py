@@ -1,0 +1,87 @@
+"""GPU: dense (Symmetric) Gaussian kinetic energy — GaussianKineticEnergy(M⁻¹) with
+W = cholesky(inv(M⁻¹)).L (hamiltonian.jl:73) — through the C ABI, bit for bit against the oracle,
+plus the reference's own dense tests (test_hamiltonian.jl:20-32, test_NUTS.jl:87-111)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(0x3C574111)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def rand_sigma(n):  # test/utilities.jl:6-9
+    A = RNG.normal(size=(n, n))
+    return A.T @ A + 0.01
+
+
+def pair(pkg, D, C, **kw):
+    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, **kw)
+    ora = ol.Oracle(D, C, metric=ol.METRIC_DENSE, threads=8, **kw)
+    return dev, ora
+
+
+def same(a, b, what):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{what}: {k}"
+
+
+def test_dense_kinetic_energy_construction(pkg):  # test_hamiltonian.jl:20-32
+    for K in (2, 5, 10, 70):
+        S = rand_sigma(K)
+        dev, ora = pair(pkg, K, 2)
+        dev.set_metric_dense(np.linalg.inv(S)); ora.set_metric_dense(np.linalg.inv(S))
+        minv, W = dev.metric_dense()
+        assert np.array_equal(W, ora.metric_dense_W())
+        assert np.allclose(np.triu(W, 1), 0)                       # W isa LowerTriangular
+        assert np.allclose(minv @ W @ W.T, np.eye(K), atol=1e-8)   # M⁻¹ W Wᵀ ≈ I
+    with pytest.raises(ValueError):                                # not positive definite
+        dev.set_metric_dense(-np.eye(70))
+    with pytest.raises(ValueError):                                # diagonal context refuses a dense metric
+        pkg.DeviceContext(5, 1).set_metric_dense(np.eye(5))
+
+
+@pytest.mark.parametrize("K", [2, 3, 8, 33, 100])
+def test_dense_parity_random_metric(pkg, K):
+    """Random dense metric unrelated to the target (as rand_Hz, test/utilities.jl:85-96)."""
+    mu = RNG.normal(size=K); prec = 1 / (RNG.normal(size=K) ** 2 + 0.1)
+    params = np.concatenate([mu, prec])
+    dev = pkg.DeviceContext(K, 5, metric=ol.METRIC_DENSE, target=ol.TARGET_DIAG_NORMAL, target_params=params, seed=K)
+    ora2 = ol.Oracle(K, 5, metric=ol.METRIC_DENSE, target=ol.TARGET_DIAG_NORMAL, params=params, seed=K, threads=8)
+    Minv = np.linalg.inv(rand_sigma(K))
+    dev.set_metric_dense(Minv); ora2.set_metric_dense(Minv)
+    dev.init(); ora2.init()
+    dev.find_initial_stepsize(); ora2.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora2.stepsize())
+    same(dev.run(15, da={}), ora2.run(15, da={}), f"K={K} adaptive")
+    same(dev.run(10), ora2.run(10), f"K={K} fixed")
+
+
+def test_perfect_metric_correlated_normal(pkg):
+    """test_NUTS.jl:87-111 in BASELINE config 3's form: correlated MVN (tridiagonal precision) with
+    the perfect dense metric M⁻¹ = Σ, fixed ϵ = 0.5: mean and covariance are recovered."""
+    K, C, N = 8, 16, 2500
+    rho = 0.6
+    diag = np.full(K, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
+    off = np.full(K, -rho / (1 - rho ** 2))
+    P = np.diag(diag) + np.diag(off[:K - 1], 1) + np.diag(off[:K - 1], -1)
+    Sigma = np.linalg.inv(P)
+    params = np.concatenate([diag, off])
+    dev = pkg.DeviceContext(K, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=2)
+    ora = ol.Oracle(K, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=2, threads=8)
+    for e in (dev, ora):
+        e.set_metric_dense(Sigma); e.init(); e.set_stepsize(0.5)
+    a, b = dev.run(N, fields=["draws", "depth", "acceptance_rate"]), ora.run(N, fields=["draws", "depth", "acceptance_rate"])
+    same(a, b, "perfect metric")
+    q = a["draws"].reshape(-1, K)
+    Cov = np.cov(q.T)
+    tol = np.diag(Cov).max() / 50 * 4          # 40000 pooled draws of 16 chains; reference uses 1e4 of one chain
+    assert np.abs(q.mean(0)).sum() < tol * K
+    assert np.allclose(Cov, Sigma, atol=0.1, rtol=0.1)
+    assert a["depth"].mean() < 3.5             # a perfect metric decorrelates: short trees

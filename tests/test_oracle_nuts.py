@@ -149,3 +149,23 @@ def test_dual_averaging_convergence(eps0, iters, sigma, atol):  # test_stepsize.
     fe = math.exp(st[4])
     mean_rate = np.mean([_dummy_acceptance_rate(fe, sigma, rng) for _ in range(10000)])
     assert abs(mean_rate - delta) <= atol
+
+
+def test_gaussian_ke_full_and_diagonal():  # test_hamiltonian.jl:20-47
+    for _ in range(10):
+        K = int(RNG.integers(2, 11))
+        A = RNG.normal(size=(K, K)); Sigma = A.T @ A + 0.01         # rand_Σ, test/utilities.jl:6-9
+        Minv = np.linalg.inv(Sigma)
+        ps, W = ol.rand_p_dense(Minv, 10000, seed=K)
+        assert np.allclose(np.triu(W, 1), 0)                        # W isa LowerTriangular
+        assert np.allclose(Minv @ W @ W.T, np.eye(K), atol=1e-7)    # M⁻¹ W Wᵀ ≈ I
+        Cm = np.cov(ps.T)
+        assert np.linalg.norm(Cm - Sigma) <= 0.1 * np.linalg.norm(Sigma)   # Matrix(Σ) ≈ C rtol = 0.1
+    with pytest.raises(ValueError):
+        ol.rand_p_dense(-np.eye(3), 1)
+    # diagonal: W = Diagonal(sqrt.(1 ./ diag)), sample variance of rand_p ≈ 1 ./ diag(M⁻¹)
+    K = 6
+    d = RNG.normal(size=K) ** 2 + 0.01
+    o = ol.Oracle(K, 1)
+    o.set_metric_diag(1 / d)
+    assert np.allclose(o.metric_diag()[0] * d, 1)
