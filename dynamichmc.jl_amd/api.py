@@ -25,7 +25,7 @@ __all__ = [
     "default_warmup_stages", "fixed_stepsize_warmup_stages", "GaussianKineticEnergy",
     "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
-    "StandardNormal", "DiagNormal", "TridiagNormal", "Funnel", "AlwaysDivergent",
+    "StandardNormal", "DiagNormal", "TridiagNormal", "Funnel", "LogisticRegression", "AlwaysDivergent",
     "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
     "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
 ]
@@ -248,6 +248,20 @@ class Funnel(_Target):
 
     def __init__(self, D):
         self.D = int(D)
+
+
+class LogisticRegression(_Target):
+    """Bernoulli-logit regression, β ~ N(0, I):  ℓ(β) = Σ_n [y_n x_n·β - log(1 + e^{x_n·β})] - ½ β·β.
+    X [N][D] and y [N] are copied to the GPU once and shared by all chains."""
+    family = abi.TARGET_LOGISTIC
+
+    def __init__(self, X, y):
+        self.X = np.ascontiguousarray(X, np.float64); self.y = np.ascontiguousarray(y, np.float64)
+        _argcheck(self.X.ndim == 2 and self.y.shape == (self.X.shape[0],), "X is [N][D], y is [N]")
+        self.D = self.X.shape[1]
+
+    def params(self):
+        return np.concatenate([np.array([self.X.shape[0]], np.int64).view(np.float64), self.X.ravel(), self.y])
 
 
 class AlwaysDivergent(_Target):

@@ -132,6 +132,7 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P) {
     case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, c->stream, M);
     case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, c->stream, M);
     case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_LOGISTIC: return dispatch_npl<LogisticT>(c->NPL, op, P, c->stream, M);
     case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, c->stream, M);
     default: return DHMC_ERR_UNSUPPORTED;
     }
@@ -240,6 +241,13 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     case DHMC_TARGET_DIAG_NORMAL: case DHMC_TARGET_TRIDIAG_NORMAL:
         if (!cfg->target_params || cfg->target_params_bytes != sizeof(double) * 2 * (size_t)D) return DHMC_ERR_INVALID_ARGUMENT;
         break;
+    case DHMC_TARGET_LOGISTIC: {
+        if (!cfg->target_params || cfg->target_params_bytes < 8) return DHMC_ERR_INVALID_ARGUMENT;
+        int64_t n;
+        std::memcpy(&n, cfg->target_params, 8);
+        if (n <= 0 || cfg->target_params_bytes != 8 + sizeof(double) * (uint64_t)n * (D + 1)) return DHMC_ERR_INVALID_ARGUMENT;
+        break;
+    }
     default: return DHMC_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -293,6 +301,28 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
+    }
+    if (cfg->target == DHMC_TARGET_LOGISTIC) {
+        int64_t n;
+        std::memcpy(&n, cfg->target_params, 8);
+        const double* X = (const double*)((const char*)cfg->target_params + 8);
+        const double* y = X + (size_t)n * D;
+        const size_t npad = ((size_t)n + WAVE - 1) / WAVE * WAVE;
+        std::vector<double> xp((size_t)n * Dp, 0.0), xt((size_t)D * npad, 0.0), yp(npad, 0.0);
+        for (int64_t i = 0; i < n; ++i)
+            for (int d = 0; d < D; ++d) {
+                xp[(size_t)i * Dp + d] = X[(size_t)i * D + d];
+                xt[(size_t)d * npad + i] = X[(size_t)i * D + d];
+            }
+        for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
+        double *dx = nullptr, *dxt = nullptr, *dy = nullptr;
+        if ((rc = dev_alloc(c, &dx, xp.size()))) return fail(rc);
+        if ((rc = dev_alloc(c, &dxt, xt.size()))) return fail(rc);
+        if ((rc = dev_alloc(c, &dy, yp.size()))) return fail(rc);
+        if (hipMemcpy(dx, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(dxt, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(dy, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        c->tp.a = dx; c->tp.b = dxt; c->tp.c = dy; c->tp.n = n; c->tp.npad = (int64_t)npad; c->tp.Dpad = (int32_t)Dp;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
     // unit metric, ε unspecified

@@ -23,9 +23,13 @@
 namespace dhmc {
 
 struct TargetParams {
-    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      (padded to Dpad, device)
-    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off
-    int64_t n;
+    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      LOGISTIC: X  [n][Dpad]     (padded, device)
+    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off       LOGISTIC: Xᵀ [D][npad]
+    const double* c;  //                                          LOGISTIC: y  [npad]
+    int64_t n;        //                                          LOGISTIC: observations
+    int64_t npad;     //                                          LOGISTIC: n rounded up to 64
+    int32_t Dpad;
+    int32_t pad_;
 };
 
 struct StdNormalT {
@@ -129,6 +133,67 @@ struct FunnelT {
         for (int k = 0; k < NPL; ++k) g[k] = -(ev * q[k]);
         if (lane == 0) g[0] = ((-v / 9.0) + hes) - hd;
         return lq;
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+
+// Bernoulli-logit regression with a N(0, I) prior (BASELINE config 5's model), X resident in HBM and
+// shared by all chains:  η_n = x_n·β,  ℓ = Σ_n [y_n η_n - log(1+e^{η_n})] - 1/2 β·β,  ∇ℓ = Xᵀ(y-σ(η)) - β.
+// Round-1 form: one wave per chain walks the observations 64 at a time — lane = observation for the
+// η pass (reads Xᵀ coalesced, β_d broadcast by readlane), lane = coordinate for the Xᵀr pass (reads
+// X rows coalesced, r_n broadcast).  Every chain re-reads X, so this is cache-bandwidth bound; the
+// production form shares X tiles across a workgroup's chains and contracts with fp64 MFMA.
+struct LogisticT {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |y - σ| <= 1, β finite when β·β is
+    static constexpr bool kRecomputeGrad = false;              // the gradient is the expensive part: keep it with proposals
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    const double* X;
+    const double* XT;
+    const double* y;
+    int64_t N, Npad;
+    int Dpad;
+    __device__ explicit LogisticT(const TargetParams& p) : X(p.a), XT(p.b), y(p.c), N(p.n), Npad(p.npad), Dpad(p.Dpad) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] = 0.0;
+        double lpart = 0.0;
+        for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) {
+            const int64_t n = n0 + lane;
+            double eta = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < NPL; ++s2) {
+                const int kcount = (D - WAVE * s2) < WAVE ? (D - WAVE * s2) : WAVE;
+                for (int l2 = 0; l2 < kcount; ++l2) {
+                    const double bd = readlane_f64(q[s2], l2);
+                    eta = __builtin_fma(XT[(size_t)(WAVE * s2 + l2) * Npad + n], bd, eta);
+                }
+            }
+            const double t = det_exp(-__builtin_fabs(eta));
+            const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+            const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
+            const bool valid = n < N;
+            const double yn = y[n];
+            const double r = valid ? yn - sig : 0.0;
+            lpart = lpart + (valid ? yn * eta - l1pe : 0.0);
+            const int rows = (N - n0) < WAVE ? (int)(N - n0) : WAVE;
+            for (int l2 = 0; l2 < rows; ++l2) {
+                const double rn = readlane_f64(r, l2);
+                const double* __restrict__ xrow = X + (size_t)(n0 + l2) * Dpad;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) g[k] = __builtin_fma(xrow[lane + WAVE * k], rn, g[k]);
+            }
+        }
+        double qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            qq = __builtin_fma(q[k], q[k], qq);
+            g[k] = g[k] - q[k];
+        }
+        double red[2] = {lpart, qq};
+        wave_allreduce<2>(red);
+        return red[0] - 0.5 * red[1];
     }
     __device__ __forceinline__ double finish(double s) const { return s; }
 };

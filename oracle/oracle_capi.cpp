@@ -38,6 +38,14 @@ static std::unique_ptr<Target> make_target(const dhmc_config& cfg) {
         if (cfg.target_params_bytes != sizeof(double) * 2 * (size_t)D) return nullptr;
         return std::make_unique<TridiagNormal>(D, pd, pd + D);
     case DHMC_TARGET_FUNNEL: return D >= 2 ? std::make_unique<Funnel>(D) : nullptr;
+    case DHMC_TARGET_LOGISTIC: {
+        if (!cfg.target_params || cfg.target_params_bytes < 8) return nullptr;
+        int64_t n;
+        std::memcpy(&n, cfg.target_params, 8);
+        if (n <= 0 || cfg.target_params_bytes != 8 + sizeof(double) * (uint64_t)n * (D + 1)) return nullptr;
+        const double* x = (const double*)((const char*)cfg.target_params + 8);
+        return std::make_unique<Logistic>(D, n, x, x + (size_t)n * D);
+    }
     case DHMC_TARGET_ALWAYS_DIVERGENT: return std::make_unique<AlwaysDivergent>(D);
     default: return nullptr;
     }

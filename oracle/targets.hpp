@@ -84,6 +84,40 @@ struct Funnel : Target {
     }
 };
 
+// DHMC_TARGET_LOGISTIC: Bernoulli-logit regression with a N(0, I) prior on β = q
+//   η_n = x_n·β,  ℓ = Σ_n [y_n η_n - log(1 + e^{η_n})] - 1/2 β·β,  ∇ℓ = Xᵀ(y - σ(η)) - β
+// Order: η_n is one fma chain over d ascending; with t = exp(-|η|): σ = η >= 0 ? 1/(1+t) : t/(1+t),
+// log1pexp(η) = max(η, 0) + log1p(t); the sum over observations is in wave order (64 interleaved
+// partial sums of plain adds + butterfly); (Xᵀr)_d is one fma chain over n ascending.
+struct Logistic : Target {
+    int64_t N;
+    std::vector<double> X, y;   // X row-major [N][D]
+    Logistic(int d, int64_t n, const double* x, const double* yy) : N(n), X(x, x + n * d), y(yy, yy + n) { D = d; }
+    void eval(const MathOps& M, const double* q, double& lq, double* g) const override {
+        std::vector<double> r(N);
+        double partial[64];
+        for (int l = 0; l < 64; ++l) partial[l] = 0.0;
+        for (int64_t n = 0; n < N; ++n) {
+            const double* xn = &X[(size_t)n * D];
+            double eta = 0.0;
+            for (int d = 0; d < D; ++d) eta = __builtin_fma(xn[d], q[d], eta);
+            double t = M.exp(-std::fabs(eta));
+            double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+            double l1pe = (eta > 0 ? eta : 0.0) + (M.det ? dhmc::det_log1p_nonneg(t) : std::log1p(t));
+            r[n] = y[n] - sig;
+            partial[n % 64] = partial[n % 64] + (y[n] * eta - l1pe);
+        }
+        double S1 = wave_tree(partial);
+        double S2 = wave_dot(q, q, D);
+        lq = S1 - 0.5 * S2;
+        for (int d = 0; d < D; ++d) {
+            double acc = 0.0;
+            for (int64_t n = 0; n < N; ++n) acc = __builtin_fma(X[(size_t)n * D + d], r[n], acc);
+            g[d] = acc - q[d];
+        }
+    }
+};
+
 // DHMC_TARGET_ALWAYS_DIVERGENT: the reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)
 struct AlwaysDivergent : Target {
     explicit AlwaysDivergent(int d) { D = d; }

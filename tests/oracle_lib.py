@@ -103,6 +103,9 @@ def target_params_blob(target, D, **kw):
         o = np.asarray(kw["off"], np.float64)
         off[:len(o)] = o
         return np.concatenate([np.asarray(kw["diag"], np.float64), off])
+    if target == TARGET_LOGISTIC:
+        X = np.ascontiguousarray(kw["X"], np.float64); y = np.ascontiguousarray(kw["y"], np.float64)
+        return np.concatenate([np.array([X.shape[0]], np.int64).view(np.float64), X.ravel(), y])
     return None
 
 

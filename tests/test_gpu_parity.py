@@ -195,3 +195,32 @@ def test_state_export_import_resumes_exactly(pkg):
     ra, rb = a.run(8), b.run(8)
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+
+
+def _logistic_problem(N, D, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, D)) / np.sqrt(D)
+    beta = rng.normal(size=D)
+    y = (rng.random(N) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    return X, y
+
+
+@pytest.mark.parametrize("N,D", [(100, 3), (333, 40), (500, 256)])
+def test_logistic_regression_target(pkg, N, D):
+    """BASELINE config 5's model (device-side ∇log π over a resident design matrix), small sizes.
+    Also the only family that keeps ∇ℓ with stored proposals instead of recomputing it."""
+    X, y = _logistic_problem(N, D, N + D)
+    params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
+    dev, ora = make_pair(pkg, D, 4, target=ol.TARGET_LOGISTIC, params=params, seed=17)
+    dev.init(); ora.init()
+    for x, z in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, z)
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora.stepsize())
+    a, b = dev.run(12, da={}), ora.run(12, da={})
+    assert_same(a, b, f"logistic N={N} D={D} warmup")
+    dev.update_metric_diag(a["draws"]); ora.update_metric_diag(b["draws"])
+    a, b = dev.run(8), ora.run(8)
+    assert_same(a, b, f"logistic N={N} D={D}")
+    for x, z in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, z)            # ∇ℓ carried with the proposal == ∇ℓ re-evaluated
