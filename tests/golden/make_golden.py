@@ -27,14 +27,31 @@ CASES = {
                     [(25, True, False), (10, False, False)]),
     "funnel_d30": (30, 6, ol.TARGET_FUNNEL, {}, 4, 10, [(40, True, False), (25, True, True), (25, False, False)]),
     "shallow_d20_maxdepth3": (20, 3, ol.TARGET_STD_NORMAL, {}, 9, 3, [(20, True, False), (10, False, False)]),
+    "logistic_n150_d6": (6, 3, ol.TARGET_LOGISTIC, "logistic", 21, 10, [(25, True, True), (15, False, False)]),
+    # dense metric: correlated normal (tridiagonal precision, rho = 0.5) with the perfect metric M⁻¹ = Σ
+    "dense_tridiag_d12": (12, 3, ol.TARGET_TRIDIAG_NORMAL, dict(diag=np.r_[4 / 3.0, np.full(10, 5 / 3.0), 4 / 3.0], off=np.full(12, -2 / 3.0)),
+                          13, 10, [(25, True, False), (15, False, False)], "dense"),
 }
 
 
+def _logistic_data():
+    rng = np.random.default_rng(2024)
+    X = rng.normal(size=(150, 6)) / 2
+    y = (rng.random(150) < 1 / (1 + np.exp(-X @ rng.normal(size=6)))).astype(float)
+    return dict(X=X, y=y)
+
+
 def run_case(engine_factory, spec):
-    D, C, target, tkw, seed, max_depth, stages = spec
+    D, C, target, tkw, seed, max_depth, stages = spec[:7]
+    dense = len(spec) > 7
+    if tkw == "logistic":
+        tkw = _logistic_data()
     params = ol.target_params_blob(target, D, **tkw)
-    eng = engine_factory(D, C, target, params, seed, max_depth)
+    eng = engine_factory(D, C, target, params, seed, max_depth, ol.METRIC_DENSE if dense else ol.METRIC_DIAG)
     out = {}
+    if dense:
+        P = np.diag(tkw["diag"]) + np.diag(tkw["off"][:D - 1], 1) + np.diag(tkw["off"][:D - 1], -1)
+        eng.set_metric_dense(np.linalg.inv(P))
     eng.init()
     q, lq, g = eng.position()
     out["init_q"], out["init_lq"], out["init_grad"] = q, lq, g
@@ -45,14 +62,14 @@ def run_case(engine_factory, spec):
         for k, v in r.items():
             out[f"s{si}_{k}"] = v
         out[f"s{si}_eps_after"] = eng.stepsize()
-        if metric:
+        if metric and not dense:
             eng.update_metric_diag(r["draws"])
             out[f"s{si}_metric_after"] = eng.metric_diag()
     return out
 
 
-def oracle_factory(D, C, target, params, seed, max_depth):
-    return ol.Oracle(D, C, target=target, params=params, seed=seed, max_depth=max_depth)
+def oracle_factory(D, C, target, params, seed, max_depth, metric):
+    return ol.Oracle(D, C, target=target, params=params, seed=seed, max_depth=max_depth, metric=metric)
 
 
 if __name__ == "__main__":
