@@ -58,7 +58,7 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_set_metric_dense", "dhmc_get_metric_dense", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_state_bytes",
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
-           "dhmc_last_run_leapfrogs", "dhmc_workspace_bytes"]
+           "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes"]
 
 _lib = None
 
@@ -82,10 +82,11 @@ def lib():
         L.dhmc_version.restype = C.c_char_p
         L.dhmc_last_run_kernel_ms.restype = C.c_double
         L.dhmc_last_run_leapfrogs.restype = C.c_uint64
+        L.dhmc_last_run_rounds.restype = C.c_uint64
         L.dhmc_workspace_bytes.restype = C.c_uint64
         for name in SYMBOLS:
             if name.startswith("dhmc_") and name not in ("dhmc_last_error", "dhmc_version", "dhmc_last_run_kernel_ms",
-                                                         "dhmc_last_run_leapfrogs", "dhmc_workspace_bytes"):
+                                                         "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib

@@ -207,5 +207,8 @@ class DeviceContext:
     def last_run_leapfrogs(self):
         return int(abi.lib().dhmc_last_run_leapfrogs(self.h))
 
+    def last_run_rounds(self):
+        return int(abi.lib().dhmc_last_run_rounds(self.h))
+
     def workspace_bytes(self):
         return int(abi.lib().dhmc_workspace_bytes(self.h))

@@ -15,6 +15,7 @@
 
 #include "../../include/dhmc.h"
 #include "dense_metric.hpp"
+#include "dense_rounds.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
 
@@ -36,6 +37,9 @@ struct dhmc_ctx {
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
+    RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
+    int dense_rounds = 1;
+    unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
     std::string err;
     std::vector<void*> allocs;
@@ -102,16 +106,35 @@ void launch_search_dense(const SearchParams& P, const DenseMetric& M, hipStream_
     hipLaunchKernelGGL((stepsize_search_dense_kernel<T, NPL>), dim3(P.C), dim3(WAVE), 0, s, P, M);
 }
 
-enum class Op { Run, Init, Search };
+struct RoundArgs {
+    RunParams P;
+    RoundBuffers R;
+};
+template <class T, int NPL>
+void launch_round_op(int which, const RoundArgs& a, hipStream_t s) {
+    switch (which) {
+    case 0: hipLaunchKernelGGL((rounds_start_kernel<NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
+    case 1: hipLaunchKernelGGL((rounds_k0_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
+    case 2: hipLaunchKernelGGL((rounds_k2_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
+    default: hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
+    }
+}
+
+enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3 };
 
 template <class T, int NPL>
 void dispatch_op(Op op, const void* P, hipStream_t s, const DenseMetric* M) {
+    if (op == Op::RoundStart || op == Op::RoundK0 || op == Op::RoundK2 || op == Op::RoundK3) {
+        launch_round_op<T, NPL>((int)op - (int)Op::RoundStart, *(const RoundArgs*)P, s);
+        return;
+    }
     if (M && op == Op::Run) { launch_run_dense<T, NPL>(*(const RunParams*)P, *M, s); return; }
     if (M && op == Op::Search) { launch_search_dense<T, NPL>(*(const SearchParams*)P, *M, s); return; }
     switch (op) {
     case Op::Run: launch_run<T, NPL>(*(const RunParams*)P, s); break;
     case Op::Init: launch_init<T, NPL>(*(const InitParams*)P, s); break;
     case Op::Search: launch_search<T, NPL>(*(const SearchParams*)P, s); break;
+    default: break;
     }
 }
 template <class T>
@@ -298,6 +321,18 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->d_Minv, Dp * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_WT, Dp * Dp))) return fail(rc);
         c->dm = DenseMetric{c->d_Minv, c->d_WT};
+        if ((rc = dev_alloc(c, &c->rb.cp, C * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.cps, C * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.ts, C))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.list, C))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.list_count, 2))) return fail(rc);
+        c->rb.done_count = c->rb.list_count + 1;
+        if (hipMemset(c->rb.ts, 0, C * sizeof(TreeState)) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemset(c->rb.cp, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemset(c->rb.cps, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemset(c->rb.tbuf, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
@@ -555,7 +590,31 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
+        // round-based dense engine: every round is one leapfrog for every chain (dense_rounds.hpp)
+        RoundArgs ra{P, c->rb};
+        const int ld = c->Dpad;
+        e = hipMemsetAsync(c->rb.list_count, 0, 2 * sizeof(int), c->stream);
+        if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
+        unsigned long long rounds = 0;
+        int done = 0;
+        while (e == hipSuccess && done < C) {
+            for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
+                launch_gemm_rows(c->rb.cp, c->d_WT, c->rb.tbuf, ld, C, c->rb.list, c->rb.list_count, c->stream);     // p₀ = z·Wᵀ
+                launch_gemm_rows(c->rb.tbuf, c->d_Minv, c->rb.cps, ld, C, c->rb.list, c->rb.list_count, c->stream);  // p♯₀
+                dispatch(c, Op::RoundK0, &ra);
+                e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
+                launch_gemm_rows(c->rb.cp, c->d_Minv, c->rb.tbuf, ld, C, nullptr, nullptr, c->stream);               // M⁻¹pₘ
+                dispatch(c, Op::RoundK2, &ra);
+                launch_gemm_rows(c->rb.cp, c->d_Minv, c->rb.cps, ld, C, nullptr, nullptr, c->stream);                // p♯
+                dispatch(c, Op::RoundK3, &ra);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        c->last_rounds = rounds;
+    } else if (e == hipSuccess) {
         rc = dispatch(c, Op::Run, &P);
         if (rc) { cleanup(); return rc; }
         e = hipGetLastError();
@@ -647,6 +706,7 @@ int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
 }
 
 double dhmc_last_run_kernel_ms(const dhmc_ctx* c) { return c ? c->last_ms : 0.0; }
+uint64_t dhmc_last_run_rounds(const dhmc_ctx* c) { return c ? c->last_rounds : 0; }
 uint64_t dhmc_last_run_leapfrogs(const dhmc_ctx* c) { return c ? c->last_leapfrogs : 0; }
 uint64_t dhmc_workspace_bytes(const dhmc_ctx* c) { return c ? c->ws_bytes : 0; }
 

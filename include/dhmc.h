@@ -190,6 +190,8 @@ int dhmc_import_state(dhmc_ctx* ctx, const void* host_blob, uint64_t nbytes);
 double dhmc_last_run_kernel_ms(const dhmc_ctx* ctx);
 /* total leapfrog steps (= gradient evaluations, Σ TreeStatisticsNUTS.steps) of the last dhmc_run */
 uint64_t dhmc_last_run_leapfrogs(const dhmc_ctx* ctx);
+/* dense contexts: number of leapfrog rounds (one fp64-MFMA GEMM pair each) the last dhmc_run took */
+uint64_t dhmc_last_run_rounds(const dhmc_ctx* ctx);
 /* bytes of device workspace the context holds (sizing for 288 GB HBM) */
 uint64_t dhmc_workspace_bytes(const dhmc_ctx* ctx);
 
