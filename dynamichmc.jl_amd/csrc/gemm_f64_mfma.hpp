@@ -52,11 +52,12 @@ __global__ __launch_bounds__(256) void gemm_rows_f64_kernel(const double* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 
+    // software pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied
+    double2 a01 = *reinterpret_cast<const double2*>(a_src);
+    double2 a23 = *reinterpret_cast<const double2*>(a_src + 2);
+    double2 b01 = *reinterpret_cast<const double2*>(b_src);
+    double2 b23 = *reinterpret_cast<const double2*>(b_src + 2);
     for (int k0 = 0; k0 < K; k0 += GEMM_TK) {
-        const double2 a01 = *reinterpret_cast<const double2*>(a_src + k0);
-        const double2 a23 = *reinterpret_cast<const double2*>(a_src + k0 + 2);
-        const double2 b01 = *reinterpret_cast<const double2*>(b_src + (size_t)k0 * ld);
-        const double2 b23 = *reinterpret_cast<const double2*>(b_src + (size_t)k0 * ld + 2);
         __syncthreads();   // previous tile fully consumed
         As[(a_k + 0) * GEMM_LDS_STRIDE + a_row] = a01.x;
         As[(a_k + 1) * GEMM_LDS_STRIDE + a_row] = a01.y;
@@ -65,6 +66,12 @@ __global__ __launch_bounds__(256) void gemm_rows_f64_kernel(const double* __rest
         *reinterpret_cast<double2*>(&Bs[b_k * GEMM_LDS_STRIDE + b_c]) = b01;
         *reinterpret_cast<double2*>(&Bs[b_k * GEMM_LDS_STRIDE + b_c + 2]) = b23;
         __syncthreads();
+        if (k0 + GEMM_TK < K) {
+            a01 = *reinterpret_cast<const double2*>(a_src + k0 + GEMM_TK);
+            a23 = *reinterpret_cast<const double2*>(a_src + k0 + GEMM_TK + 2);
+            b01 = *reinterpret_cast<const double2*>(b_src + (size_t)(k0 + GEMM_TK) * ld);
+            b23 = *reinterpret_cast<const double2*>(b_src + (size_t)(k0 + GEMM_TK) * ld + 2);
+        }
 #pragma unroll
         for (int kk = 0; kk < GEMM_TK; kk += 4) {
             const int kr = (kk + (lane >> 4)) * GEMM_LDS_STRIDE;
