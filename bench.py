@@ -114,8 +114,63 @@ def cpu_baseline(transitions, threads):
                       f"{nsteps} leapfrog steps in {dt:.1f} s (C++ oracle, -O3, one chain per thread)"}
 
 
+def bench_config3(args, pkg, torch):
+    """BASELINE.json configs[2]: 1000-dim correlated MVN (tridiagonal precision), dense M⁻¹ = Σ shared by all
+    chains, 4096 chains, sampling at a fixed per-chain ϵ found by dual averaging.  Not the driver's line (that is
+    configs[1]); run with --config 3 for the MFMA roofline of the dense path."""
+    import oracle_lib as ol
+    Dd, C, T, K = 1000, args.chains, args.transitions, args.steps
+    rho = 0.5
+    sig = np.logspace(-1, 1, Dd)
+    Pc = np.zeros(Dd) + (1 + rho ** 2) / (1 - rho ** 2); Pc[0] = Pc[-1] = 1 / (1 - rho ** 2)
+    diag = Pc / sig ** 2
+    off = np.zeros(Dd); off[:Dd - 1] = -rho / (1 - rho ** 2) / (sig[:-1] * sig[1:])
+    idx = np.arange(Dd)
+    Sigma = np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
+    ctx = pkg.DeviceContext(Dd, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL,
+                            target_params=np.concatenate([diag, off]), seed=args.seed,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    ctx.set_metric_dense(Sigma)
+    ctx.init(np.random.default_rng(5).normal(size=(C, Dd)) * sig)
+    ctx.find_initial_stepsize()
+    ctx.run_into(40, {}, da={})
+    out = {"draws": torch.empty((C, T, Dd), dtype=torch.float64, device="cuda"),
+           "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
+           "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
+           "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
+    for _ in range(args.warmup):
+        ctx.run_into(T, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); lf = 0; rounds = 0; kms = []
+    for _ in range(K):
+        ctx.run_into(T, out)
+        lf += ctx.last_run_leapfrogs(); rounds += ctx.last_run_rounds(); kms.append(ctx.last_run_kernel_ms())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = rounds * 2 * 2.0 * C * 1024 * 1024           # two [C×1024]·[1024×1024] contractions per round
+    peak = 78.6                                           # MI355X fp64 matrix peak, TFLOP/s
+    ach = flops / (sum(kms) * 1e-3) / 1e12
+    q = out["draws"]
+    print(json.dumps({
+        "metric": "leapfrog-steps/sec (all chains), 1000-dim correlated MVN, dense M^-1, @4096 chains",
+        "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "1000-dim correlated MVN (rho=0.5, sigma log-spaced 0.1..10), dense M^-1 = Sigma shared, "
+                               "4096 chains (BASELINE.json configs[2])", "transitions_per_step": T},
+        "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
+                 "mean_acceptance": float(out["acceptance_rate"].mean()),
+                 "scaled_draw_var": float((q / torch.tensor(sig, device="cuda")).var())},
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                     "kernel": "gemm_rows_f64_kernel (v_mfma_f64_16x16x4_f64), share of whole round time",
+                     "note": "flops of the two M^-1 contractions per leapfrog round / total kernel time of the rounds "
+                             "(tree-logic kernels included); the GEMM launches alone reach ~53 TFLOP/s (profiles/)",
+                     "rounds": rounds}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (default, diagonal metric) or 3 (dense metric)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -144,6 +199,8 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    if args.config == 3:
+        return bench_config3(args, pkg, torch)
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
     ctx = setup_context(pkg, torch, rank, C, args.seed, not args.full_warmup)
     out = {
