@@ -290,7 +290,7 @@ def main():
                                  "the HBM peak; traffic = real HBM bytes per launch from the PMC passes"},
             "all_run_leapfrogs": ALL_RUN_LEAPFROGS[0],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_transitions, os.cpu_count() or 1)
         print(json.dumps(line))
     if dist is not None:

@@ -224,3 +224,29 @@ def test_logistic_regression_target(pkg, N, D):
     assert_same(a, b, f"logistic N={N} D={D}")
     for x, z in zip(dev.position(), ora.position()):
         assert np.array_equal(x, z)            # ∇ℓ carried with the proposal == ∇ℓ re-evaluated
+
+
+@pytest.mark.parametrize("D", [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024])
+def test_ragged_dimensions_at_slot_boundaries(pkg, D):
+    """Every boundary of the lane/slot layout (Dpad = 64·NPL, NPL ∈ {1,2,4,8,16}), single and few chains."""
+    for C in (1, 3):
+        dev, ora = make_pair(pkg, D, C, seed=1000 + D)
+        dev.init(); ora.init()
+        dev.find_initial_stepsize(); ora.find_initial_stepsize()
+        a, b = dev.run(6, da={}), ora.run(6, da={})
+        assert_same(a, b, f"D={D} C={C}")
+        dev.update_metric_diag(a["draws"]); ora.update_metric_diag(b["draws"])
+        assert np.array_equal(dev.metric_diag(), ora.metric_diag())
+        assert_same(dev.run(4), ora.run(4), f"D={D} C={C} fixed")
+
+
+def test_empty_and_unrecorded_runs(pkg):
+    dev, ora = make_pair(pkg, 10, 2, seed=3)
+    dev.init(); ora.init(); dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    assert dev.run(0)["draws"].shape == (2, 0, 10)                 # N = 0 is a no-op
+    dev.run(5, fields=[]); ora.run(5, fields=[])                   # nothing recorded: state still advances identically
+    assert np.array_equal(dev.position()[0], ora.position()[0])
+    with pytest.raises(RuntimeError, match="unsupported"):
+        pkg.DeviceContext(1025, 1)                                 # D > 1024 is outside this build (DHMC_ERR_UNSUPPORTED)
+    with pytest.raises(ValueError):
+        dev.run(-1)
