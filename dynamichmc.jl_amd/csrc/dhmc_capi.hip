@@ -16,6 +16,7 @@
 #include "../../include/dhmc.h"
 #include "dense_metric.hpp"
 #include "dense_rounds.hpp"
+#include "logistic_rounds.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
 
@@ -39,6 +40,8 @@ struct dhmc_ctx {
     double* d_WT = nullptr;
     RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
     int dense_rounds = 1;
+    int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
+    LogisticRound lr{};
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
     std::string err;
@@ -118,6 +121,25 @@ void launch_round_op(int which, const RoundArgs& a, hipStream_t s) {
     case 2: hipLaunchKernelGGL((rounds_k2_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     default: hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     }
+}
+
+void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRound& L, hipStream_t s) {
+    const dim3 g(a.P.C), b(WAVE);
+#define DHMC_NPL_SWITCH(KERNEL, ...)                                                              \
+    switch (npl) {                                                                                \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), g, b, 0, s, __VA_ARGS__); break;                      \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), g, b, 0, s, __VA_ARGS__); break;                      \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), g, b, 0, s, __VA_ARGS__); break;                      \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), g, b, 0, s, __VA_ARGS__); break;                      \
+    default: hipLaunchKernelGGL((KERNEL<16>), g, b, 0, s, __VA_ARGS__); break;                    \
+    }
+    switch (which) {
+    case 0: DHMC_NPL_SWITCH(rounds_momentum_diag_kernel, a.P, a.R) break;
+    case 1: DHMC_NPL_SWITCH(rounds_k1_diag_kernel, a.P, a.R) break;
+    case 2: hipLaunchKernelGGL(logistic_residual_kernel, g, b, 0, s, a.P, a.R, L); break;
+    default: DHMC_NPL_SWITCH(rounds_k2_logistic_kernel, a.P, a.R, L) break;
+    }
+#undef DHMC_NPL_SWITCH
 }
 
 enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3 };
@@ -282,7 +304,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->NPL = npl_for_dim(D);
     if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
     c->Dpad = c->NPL * WAVE;
-    c->nvec = cfg->metric == DHMC_METRIC_DENSE ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
+    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG;
+    if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS")) c->logistic_rounds = c->logistic_rounds && std::atoi(e) != 0;
+    c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
@@ -321,6 +345,12 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->d_Minv, Dp * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_WT, Dp * Dp))) return fail(rc);
         c->dm = DenseMetric{c->d_Minv, c->d_WT};
+        if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
+        std::vector<double> I((size_t)D * D, 0.0);
+        for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
+        if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
+    }
+    if (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) {   // buffers of the round engines
         if ((rc = dev_alloc(c, &c->rb.cp, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.cps, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
@@ -332,18 +362,16 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemset(c->rb.cp, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cps, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.tbuf, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
-        if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
-        std::vector<double> I((size_t)D * D, 0.0);
-        for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
-        if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
     }
     if (cfg->target == DHMC_TARGET_LOGISTIC) {
+        // X [npad][Dpad] row-major and Xᵀ [Dpad][npad], zero padded (GEMM operands of the round engine; the
+        // wave-per-chain functor reads the same arrays), y [npad]
         int64_t n;
         std::memcpy(&n, cfg->target_params, 8);
         const double* X = (const double*)((const char*)cfg->target_params + 8);
         const double* y = X + (size_t)n * D;
         const size_t npad = ((size_t)n + WAVE - 1) / WAVE * WAVE;
-        std::vector<double> xp((size_t)n * Dp, 0.0), xt((size_t)D * npad, 0.0), yp(npad, 0.0);
+        std::vector<double> xp(npad * Dp, 0.0), xt(Dp * npad, 0.0), yp(npad, 0.0);
         for (int64_t i = 0; i < n; ++i)
             for (int d = 0; d < D; ++d) {
                 xp[(size_t)i * Dp + d] = X[(size_t)i * D + d];
@@ -358,6 +386,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemcpy(dxt, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemcpy(dy, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         c->tp.a = dx; c->tp.b = dxt; c->tp.c = dy; c->tp.n = n; c->tp.npad = (int64_t)npad; c->tp.Dpad = (int32_t)Dp;
+        if (c->logistic_rounds) {
+            if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
+            if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
+        }
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
     // unit metric, ε unspecified
@@ -590,7 +622,33 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
-    if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
+    if (e == hipSuccess && c->logistic_rounds) {
+        // GEMM-gradient round engine (logistic_rounds.hpp)
+        RoundArgs ra{P, c->rb};
+        const int ld = c->Dpad;
+        const int npad = (int)c->tp.npad;
+        e = hipMemsetAsync(c->rb.list_count, 0, 2 * sizeof(int), c->stream);
+        if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
+        unsigned long long rounds = 0;
+        int done = 0;
+        while (e == hipSuccess && done < C) {
+            for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
+                launch_logistic_op(0, c->NPL, ra, c->lr, c->stream);                                   // p = W∘z, p♯
+                dispatch(c, Op::RoundK0, &ra);
+                e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
+                launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
+                launch_gemm(c->st.q, ld, c->tp.b, npad, c->lr.H, npad, C, ld, npad, c->stream);        // η = Q′·Xᵀ
+                launch_logistic_op(2, c->NPL, ra, c->lr, c->stream);                                   // r, S₁
+                launch_gemm(c->lr.H, npad, c->tp.a, ld, c->rb.tbuf, ld, C, npad, ld, c->stream);       // Xᵀr = R·X
+                launch_logistic_op(3, c->NPL, ra, c->lr, c->stream);                                   // ∇ℓ, ℓ, p′, p♯
+                dispatch(c, Op::RoundK3, &ra);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        c->last_rounds = rounds;
+    } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
         // round-based dense engine: every round is one leapfrog for every chain (dense_rounds.hpp)
         RoundArgs ra{P, c->rb};
         const int ld = c->Dpad;

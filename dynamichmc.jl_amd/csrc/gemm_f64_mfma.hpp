@@ -8,7 +8,8 @@
 // tools/experiments/mfma_f64_numerics.hip), and this kernel walks k in ascending order without split-K,
 // so OUT[r][i] = fma(A[r][K-1], B[K-1][i], … fma(A[r][0], B[0][i], 0)) — bit for bit the oracle's chain.
 //
-// Tiling: 256-thread workgroup (4 waves) -> 64 rows × 64 columns; each wave a 32×32 block as 2×2 MFMA
+// Tiling: 256-thread workgroup (4 waves) -> 64 rows × 64 columns (or one wave -> 32×32 for skinny
+// products); each wave a 32×32 block as 2×2 MFMA
 // tiles (16 accumulator VGPR pairs); K advances 16 at a time through LDS (A tile stored k-major so both
 // operand fragments are conflict-free ds_read_b64: row stride 80 doubles puts the four k-rows of one
 // fragment on disjoint bank halves).
@@ -20,31 +21,40 @@ namespace dhmc {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int GEMM_TM = 64, GEMM_TN = 64, GEMM_TK = 16, GEMM_LDS_STRIDE = 80;
+constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;
 
-// row_list == nullptr: rows 0..nrows-1.  Otherwise rows row_list[0..*row_count-1] (device-side count).
-__global__ __launch_bounds__(256) void gemm_rows_f64_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                            double* __restrict__ OUT, int ld, int K, int nrows,
-                                                            const int* __restrict__ row_list,
-                                                            const int* __restrict__ row_count) {
+// OUT[r][0..N) = Σ_k A[r][k] · B[k][0..N), k = 0..K-1 ascending, for rows r = 0..nrows-1 or the gathered rows
+// row_list[0..*row_count-1].  A is [*][lda], B is [K][ldb], OUT is [*][ldo]; K a multiple of 16, N a multiple of
+// the column tile.  WT = waves per side: WT = 2 -> 64×64 tile (4 waves, each 32×32 = 2×2 MFMA tiles);
+// WT = 1 -> 32×32 tile (1 wave... the skinny products launch many small tiles to fill the chip).
+template <int WT>
+__global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const double* __restrict__ A, int lda,
+                                                                   const double* __restrict__ B, int ldb,
+                                                                   double* __restrict__ OUT, int ldo, int K, int nrows,
+                                                                   const int* __restrict__ row_list,
+                                                                   const int* __restrict__ row_count) {
+    constexpr int TM = 32 * WT, TN = 32 * WT, NT = 64 * WT * WT;
     const int count = row_list ? *row_count : nrows;
-    const int row0 = blockIdx.y * GEMM_TM;
+    const int row0 = blockIdx.y * TM;
     if (row0 >= count) return;
-    const int col0 = blockIdx.x * GEMM_TN;
+    const int col0 = blockIdx.x * TN;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WT, wc = w % WT;
 
     __shared__ double As[GEMM_TK * GEMM_LDS_STRIDE];   // As[k][row]
     __shared__ double Bs[GEMM_TK * GEMM_LDS_STRIDE];   // Bs[k][col]
 
-    // global -> LDS assignment
-    const int a_row = t >> 2, a_k = (t & 3) * 4;        // 4 consecutive k of one row
+    // global -> LDS assignment: A tile TM×16 and B tile 16×TN, (TM*16)/NT doubles per thread each
+    constexpr int PER = (TM * GEMM_TK) / NT;            // 4 for WT=2 (256 thr), 8 for WT=1 (64 thr)
+    constexpr int A_TPR = GEMM_TK / PER;                // threads per A row
+    const int a_row = t / A_TPR, a_k = (t % A_TPR) * PER;
     int a_grow = row0 + a_row;
-    a_grow = a_grow < count ? a_grow : count - 1;       // clamp (results of clamped rows are not stored)
+    a_grow = a_grow < count ? a_grow : count - 1;       // clamp (clamped rows are not stored)
     if (row_list) a_grow = row_list[a_grow];
-    const double* a_src = A + (size_t)a_grow * ld + a_k;
-    const int b_k = t >> 4, b_c = (t & 15) * 4;         // 4 consecutive columns of one k
-    const double* b_src = B + (size_t)b_k * ld + col0 + b_c;
+    const double* a_src = A + (size_t)a_grow * lda + a_k;
+    constexpr int B_TPR = TN / PER;                     // threads per B row (one k)
+    const int b_k = t / B_TPR, b_c = (t % B_TPR) * PER;
+    const double* b_src = B + (size_t)b_k * ldb + col0 + b_c;
 
     mfma_d4 acc[2][2];
 #pragma unroll
@@ -53,24 +63,23 @@ __global__ __launch_bounds__(256) void gemm_rows_f64_kernel(const double* __rest
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 
     // software pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied
-    double2 a01 = *reinterpret_cast<const double2*>(a_src);
-    double2 a23 = *reinterpret_cast<const double2*>(a_src + 2);
-    double2 b01 = *reinterpret_cast<const double2*>(b_src);
-    double2 b23 = *reinterpret_cast<const double2*>(b_src + 2);
+    double av[PER], bv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { av[i] = a_src[i]; bv[i] = b_src[i]; }
     for (int k0 = 0; k0 < K; k0 += GEMM_TK) {
         __syncthreads();   // previous tile fully consumed
-        As[(a_k + 0) * GEMM_LDS_STRIDE + a_row] = a01.x;
-        As[(a_k + 1) * GEMM_LDS_STRIDE + a_row] = a01.y;
-        As[(a_k + 2) * GEMM_LDS_STRIDE + a_row] = a23.x;
-        As[(a_k + 3) * GEMM_LDS_STRIDE + a_row] = a23.y;
-        *reinterpret_cast<double2*>(&Bs[b_k * GEMM_LDS_STRIDE + b_c]) = b01;
-        *reinterpret_cast<double2*>(&Bs[b_k * GEMM_LDS_STRIDE + b_c + 2]) = b23;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            As[(a_k + i) * GEMM_LDS_STRIDE + a_row] = av[i];
+            Bs[b_k * GEMM_LDS_STRIDE + b_c + i] = bv[i];
+        }
         __syncthreads();
         if (k0 + GEMM_TK < K) {
-            a01 = *reinterpret_cast<const double2*>(a_src + k0 + GEMM_TK);
-            a23 = *reinterpret_cast<const double2*>(a_src + k0 + GEMM_TK + 2);
-            b01 = *reinterpret_cast<const double2*>(b_src + (size_t)(k0 + GEMM_TK) * ld);
-            b23 = *reinterpret_cast<const double2*>(b_src + (size_t)(k0 + GEMM_TK) * ld + 2);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                av[i] = a_src[k0 + GEMM_TK + i];
+                bv[i] = b_src[(size_t)(k0 + GEMM_TK) * ldb + i];
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < GEMM_TK; kk += 4) {
@@ -93,18 +102,31 @@ __global__ __launch_bounds__(256) void gemm_rows_f64_kernel(const double* __rest
             const int lrow = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
             if (lrow < count) {
                 const int grow = row_list ? row_list[lrow] : lrow;
-                double* o = OUT + (size_t)grow * ld + col0 + wc * 32 + (lane & 15);
+                double* o = OUT + (size_t)grow * ldo + col0 + wc * 32 + (lane & 15);
                 o[0] = acc[i][0][r];
                 o[16] = acc[i][1][r];
             }
         }
 }
 
-// host launcher: OUT rows <- A rows · B  (K = ld = Dpad, a multiple of 64)
+// host launchers.  Square metric products: OUT rows <- A rows · B with K = N = ld = Dpad.
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
-    dim3 grid(ld / GEMM_TN, (nrows + GEMM_TM - 1) / GEMM_TM);
-    hipLaunchKernelGGL(gemm_rows_f64_kernel, grid, dim3(256), 0, s, A, B, OUT, ld, ld, nrows, row_list, row_count);
+    dim3 grid(ld / 64, (nrows + 63) / 64);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+}
+// General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16); small tiles when the 64×64 grid
+// would not fill the chip.
+inline void launch_gemm(const double* A, int lda, const double* B, int ldb, double* OUT, int ldo, int M, int K, int N,
+                        hipStream_t s) {
+    const long tiles64 = (long)((M + 63) / 64) * (N / 64);
+    if (N % 64 == 0 && tiles64 >= 512) {
+        dim3 grid(N / 64, (M + 63) / 64);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+    } else {
+        dim3 grid(N / 32, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<1>), grid, dim3(64), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+    }
 }
 
 }  // namespace dhmc

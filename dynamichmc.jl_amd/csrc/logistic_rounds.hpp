@@ -1,0 +1,114 @@
+// Round engine for GEMM-shaped gradients: the logistic-regression family (BASELINE config 5's model) with a
+// per-chain diagonal metric.  Same rounds as dense_rounds.hpp — every round is one leapfrog for every chain —
+// but here the expensive part is the user's ∇log π (reference src/hamiltonian.jl:204,279), not M⁻¹:
+//
+//      K0<diag>   chains beginning a transition: p = W∘z, p♯ = M⁻¹∘p, π₀, τ₀, first half step
+//      K1         q′ = q + ϵ·(M⁻¹∘pₘ)                                            (hamiltonian.jl:278)
+//      G_eta      H  = Q′ · Xᵀ     [C×Dpad]·[Dpad×Npad]   fp64 MFMA GEMM  (η_n = x_n·β, one k-ordered chain over d)
+//      K_r        r_n = y_n − σ(η_n),  Σ_n [y_n η_n − log(1+e^{η_n})] in wave order;  H ← R
+//      G_g        G  = R · X       [C×Npad]·[Npad×Dpad]   fp64 MFMA GEMM  ((Xᵀr)_d, one chain over n ascending)
+//      K2         ∇ℓ = G − q′,  ℓ = S₁ − ½ q′·q′,  p′ = pₘ + ϵ/2 ∇ℓ,  p♯ = M⁻¹∘p′  (:279-280)
+//      K3         the leaf and what follows (dense_rounds.hpp: identical code; p♯ is simply M⁻¹∘p here)
+//
+// X is read once per round for ALL chains instead of twice per chain per leapfrog.  Every number is the one
+// the wave-per-chain functor (targets.hpp LogisticT) and the oracle compute: the GEMM accumulations are the
+// same ascending fma chains, pads contribute fma(0, 0, acc) = acc.
+#pragma once
+#include "dense_rounds.hpp"
+
+namespace dhmc {
+
+struct LogisticRound {
+    double* H;    // [C][Npad]  η, then r
+    double* S1;   // [C]        Σ_n [y_n η_n − log1pexp(η_n)]
+};
+
+// K0 for a diagonal metric: z (in cp) -> p = W∘z, p♯ = M⁻¹∘p in the places K0 reads them from.
+template <int NPL>
+__global__ __launch_bounds__(64) void rounds_momentum_diag_kernel(RunParams P, RoundBuffers R) {
+    if ((int)blockIdx.x >= *R.list_count) return;
+    const int chain = R.list[blockIdx.x], lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double p = P.st.W[row + e] * R.cp[row + e];       // rand_p, diagonal W (hamiltonian.jl:80,124)
+        R.tbuf[row + e] = p;
+        R.cps[row + e] = P.st.minv[row + e] * p;
+    }
+}
+
+// K1: q′ = q + ϵ·(M⁻¹∘pₘ)
+template <int NPL>
+__global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBuffers R) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const TreeState& S = R.ts[chain];
+    if (S.phase != PH_LEAF) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    const double eps_s = S.eps_s;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double t = P.st.minv[row + e] * R.cp[row + e];
+        P.st.q[row + e] = P.st.q[row + e] + eps_s * t;
+    }
+}
+
+// K_r: per-observation link, residual and log-likelihood terms of one chain (one wave per chain).
+__global__ __launch_bounds__(64) void logistic_residual_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (R.ts[chain].phase != PH_LEAF) return;
+    const int64_t N = P.tp.n, Npad = P.tp.npad;
+    double* h = L.H + (size_t)chain * Npad;
+    const double* y = P.tp.c;
+    double lpart = 0.0;
+    for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) {
+        const int64_t n = n0 + lane;
+        const double eta = h[n];
+        const double t = det_exp(-__builtin_fabs(eta));
+        const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+        const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
+        const bool valid = n < N;
+        const double yn = y[n];
+        h[n] = valid ? yn - sig : 0.0;
+        lpart = lpart + (valid ? yn * eta - l1pe : 0.0);
+    }
+    const double s1 = wave_allreduce1(lpart);
+    if (lane == 0) L.S1[chain] = s1;
+}
+
+// K2: gradient, log density, second half step, p♯
+template <int NPL>
+__global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    TreeState& S = R.ts[chain];
+    if (S.phase != PH_LEAF) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    const double h = S.eps_s / 2;
+    double q[NPL], g[NPL], p[NPL];
+    ldv<NPL>(P.st.q + row, lane, q);
+    ldv<NPL>(R.tbuf + row, lane, g);     // (Xᵀ r)
+    ldv<NPL>(R.cp + row, lane, p);
+    double qq = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        qq = __builtin_fma(q[k], q[k], qq);
+        g[k] = g[k] - q[k];
+    }
+    double lq = uni_f64(L.S1[chain] - 0.5 * wave_allreduce1(qq));
+    bool pos_finite = true;
+    if (!dm_isfinite(lq)) pos_finite = all_finite<LogisticT, NPL>(q);
+    lq = demote_lq(lq, pos_finite, true);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];
+    stv<NPL>(P.st.g + row, lane, g);
+    stv<NPL>(R.cp + row, lane, p);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) R.cps[row + lane + WAVE * k] = P.st.minv[row + lane + WAVE * k] * p[k];
+    if (lane == 0) {
+        S.lq_leaf = lq;
+        if (!pos_finite) S.status |= DHMC_ST_NONFINITE_POSITION;
+    }
+}
+
+}  // namespace dhmc
