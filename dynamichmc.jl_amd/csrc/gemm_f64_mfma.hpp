@@ -25,15 +25,16 @@ constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;
 
 // OUT[r][0..N) = Σ_k A[r][k] · B[k][0..N), k = 0..K-1 ascending, for rows r = 0..nrows-1 or the gathered rows
 // row_list[0..*row_count-1].  A is [*][lda], B is [K][ldb], OUT is [*][ldo]; K a multiple of 16, N a multiple of
-// the column tile.  WT = waves per side: WT = 2 -> 64×64 tile (4 waves, each 32×32 = 2×2 MFMA tiles);
-// WT = 1 -> 32×32 tile (1 wave... the skinny products launch many small tiles to fill the chip).
-template <int WT>
+// the column tile.  WT = waves per side, FR = 16×16 MFMA tiles per wave side: <2,2> -> 64×64 tile (4 waves,
+// each 32×32); <2,1> -> 32×32 tile (4 waves, each one MFMA tile) for skinny products.
+template <int WT, int FR>
 __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const double* __restrict__ A, int lda,
                                                                    const double* __restrict__ B, int ldb,
                                                                    double* __restrict__ OUT, int ldo, int K, int nrows,
                                                                    const int* __restrict__ row_list,
                                                                    const int* __restrict__ row_count) {
-    constexpr int TM = 32 * WT, TN = 32 * WT, NT = 64 * WT * WT;
+    constexpr int WS = 16 * FR;                       // rows/cols per wave
+    constexpr int TM = WS * WT, TN = WS * WT, NT = 64 * WT * WT;
     const int count = row_list ? *row_count : nrows;
     const int row0 = blockIdx.y * TM;
     if (row0 >= count) return;
@@ -56,11 +57,11 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     const int b_k = t / B_TPR, b_c = (t % B_TPR) * PER;
     const double* b_src = B + (size_t)b_k * ldb + col0 + b_c;
 
-    mfma_d4 acc[2][2];
+    mfma_d4 acc[FR][FR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < FR; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 
     // software pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied
     double av[PER], bv[PER];
@@ -84,27 +85,30 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
 #pragma unroll
         for (int kk = 0; kk < GEMM_TK; kk += 4) {
             const int kr = (kk + (lane >> 4)) * GEMM_LDS_STRIDE;
-            const double a0 = As[kr + wr * 32 + (lane & 15)];
-            const double a1 = As[kr + wr * 32 + 16 + (lane & 15)];
-            const double b0 = Bs[kr + wc * 32 + (lane & 15)];
-            const double b1 = Bs[kr + wc * 32 + 16 + (lane & 15)];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            double a[FR], b[FR];
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                a[i] = As[kr + wr * WS + 16 * i + (lane & 15)];
+                b[i] = Bs[kr + wc * WS + 16 * i + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < FR; ++i)
+#pragma unroll
+                for (int j = 0; j < FR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int lrow = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+            const int lrow = row0 + wr * WS + i * 16 + (lane >> 4) + 4 * r;
             if (lrow < count) {
                 const int grow = row_list ? row_list[lrow] : lrow;
-                double* o = OUT + (size_t)grow * ldo + col0 + wc * 32 + (lane & 15);
-                o[0] = acc[i][0][r];
-                o[16] = acc[i][1][r];
+                double* o = OUT + (size_t)grow * ldo + col0 + wc * WS + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < FR; ++j) o[16 * j] = acc[i][j][r];
             }
         }
 }
@@ -113,19 +117,20 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
     dim3 grid(ld / 64, (nrows + 63) / 64);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
 }
-// General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16); small tiles when the 64×64 grid
-// would not fill the chip.
+// General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16).  64×64 tiles (4 waves × 32×32)
+// when that grid fills the chip; otherwise 32×32 tiles worked by 4 waves of one 16×16 MFMA tile each, so a
+// skinny product (e.g. R·X: 1024 × 10⁵ × 256) still puts a wave on every SIMD.
 inline void launch_gemm(const double* A, int lda, const double* B, int ldb, double* OUT, int ldo, int M, int K, int N,
                         hipStream_t s) {
     const long tiles64 = (long)((M + 63) / 64) * (N / 64);
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     } else {
         dim3 grid(N / 32, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<1>), grid, dim3(64), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 1>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     }
 }
 
