@@ -377,15 +377,17 @@ def warmup(slogd, stage, warmup_state):
         slogd.reporter.report("found initial stepsize", eps=float(np.median(st.eps)))
         return None, st
     if isinstance(stage, TuningNUTS):                         # mcmc.jl:258-286
-        if stage.M == Symmetric:
-            raise NotImplementedError("dense (Symmetric) metric adaptation is not implemented in this build")
+        if stage.M == Symmetric and ctx.cfg.metric != abi.METRIC_DENSE:
+            raise ValueError("ArgumentError: a Symmetric metric stage needs a context with a dense κ")
+        if stage.M == Diagonal and ctx.cfg.metric != abi.METRIC_DIAG:
+            raise ValueError("ArgumentError: a Diagonal metric stage needs a context with a diagonal κ")
         _argcheck(warmup_state.eps is not None, "ϵ > 0")       # stepsize.jl:135
         ad = stage.stepsize_adaptation
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
         draws, ts, lds, epss = _collect(ctx.run(stage.N, da=da))
-        if stage.M is not None:
-            if ctx.cfg.metric != abi.METRIC_DIAG:
-                raise NotImplementedError("metric adaptation with a dense κ is not implemented in this build")
+        if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210),
+            ctx.update_metric_dense(draws, stage.lam)          # pooled over the context's chains (shared dense M⁻¹)
+        elif stage.M == Diagonal:
             ctx.update_metric_diag(draws, stage.lam)           # mcmc.jl:281-284
             slogd.reporter.report("adaptation finished")
         st = _state(ctx)
@@ -419,7 +421,8 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     _argcheck(l.capabilities() >= 1, "capabilities(ℓ) ≥ LogDensityOrder(1)")   # hamiltonian.jl:146
     init = dict(initialization)
     k0 = init.get("κ", init.get("kappa"))
-    metric = abi.METRIC_DENSE if (k0 is not None and k0.dense) else abi.METRIC_DIAG
+    wants_dense = any(isinstance(s, TuningNUTS) and s.M == Symmetric for s in warmup_stages)
+    metric = abi.METRIC_DENSE if ((k0 is not None and k0.dense) or wants_dense) else abi.METRIC_DIAG
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
                         chain_offset=rng.chain_offset, device=device, metric=metric)

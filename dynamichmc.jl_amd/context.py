@@ -188,6 +188,13 @@ class DeviceContext:
         self._chk(abi.lib().dhmc_update_metric_diag(self.h, _ptr(draws), C.c_int64(n), C.c_double(lam), int(_is_device(draws))),
                   "dhmc_update_metric_diag")
 
+    def update_metric_dense(self, draws, lam):
+        """Pooled dense estimate: κ := GaussianKineticEnergy(regularize(Symmetric(cov(draws)), λ)) (mcmc.jl:210,218-222)."""
+        if isinstance(draws, np.ndarray):
+            draws = np.ascontiguousarray(draws, np.float64)
+        self._chk(abi.lib().dhmc_update_metric_dense(self.h, _ptr(draws), C.c_int64(draws.shape[1]), C.c_double(lam), int(_is_device(draws))),
+                  "dhmc_update_metric_dense")
+
     # ---- resume ----------------------------------------------------------------------------
     def export_state(self):
         n = C.c_uint64()

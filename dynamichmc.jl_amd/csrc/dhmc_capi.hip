@@ -17,6 +17,7 @@
 #include "dense_metric.hpp"
 #include "dense_rounds.hpp"
 #include "logistic_rounds.hpp"
+#include "metric_dense_adapt.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
 
@@ -706,6 +707,35 @@ int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double 
     HIP_TRY(c, hipGetLastError());
     stage_free(c, &s);
     return DHMC_OK;
+}
+
+int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
+    if (!c || !draws || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+    if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int D = c->cfg.dim, ld = c->Dpad;
+    const int64_t J = (int64_t)c->cfg.chains * n;
+    Staged s;
+    int rc = stage_in(c, draws, sizeof(double) * (size_t)J * D, on_device, &s);
+    if (rc) return rc;
+    double *mean = nullptr, *S = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&mean, sizeof(double) * ld));
+    HIP_TRY(c, hipMalloc((void**)&S, sizeof(double) * (size_t)ld * ld));
+    hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean);
+    hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean, S, ld);
+    hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
+    std::vector<double> hp((size_t)ld * ld), h((size_t)D * D);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), S, hp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(mean); (void)hipFree(S);
+    stage_free(c, &s);
+    if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) h[(size_t)i * D + k] = hp[(size_t)i * ld + k];
+    std::vector<double> Sy, W;
+    if (!host_dense_metric(h.data(), D, Sy, W)) return DHMC_ERR_INVALID_ARGUMENT;   // estimate not positive definite
+    return upload_dense_metric(c, Sy, W);
 }
 
 // ---- resume blob: header + raw images of the per-chain arrays -------------------------------

@@ -181,6 +181,13 @@ int dhmc_run(dhmc_ctx* ctx, int64_t n_transitions, const dhmc_dual_averaging* da
 int dhmc_update_metric_diag(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda,
                             int on_device);
 
+/* Dense counterpart (contexts created with DHMC_METRIC_DENSE): κ := GaussianKineticEnergy(regularize_M⁻¹(
+ * Symmetric(cov(pm; dims=2)), λ)) (mcmc.jl:210,218-222).  The reference estimates one matrix per chain; the
+ * dense M⁻¹ of a context is shared, so the draws of all chains are pooled (J = C·n rows, chain-major) — with
+ * chains == 1 this is the reference's estimator.  Returns DHMC_ERR_INVALID_ARGUMENT if the estimate is not
+ * positive definite (e.g. J <= D with λ = 0). */
+int dhmc_update_metric_dense(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda, int on_device);
+
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);
 int dhmc_export_state(dhmc_ctx* ctx, void* host_blob, uint64_t nbytes);

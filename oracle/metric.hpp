@@ -69,4 +69,25 @@ inline GaussianKineticEnergy GaussianKineticEnergy::dense_from(const double* min
     return k;
 }
 
+// Pooled dense metric estimate (see dynamichmc.jl_amd/csrc/metric_dense_adapt.hpp): draws [J][D], J = C·N rows.
+// sample_M⁻¹(Symmetric, ·) (mcmc.jl:210) then regularize_M⁻¹ (mcmc.jl:218-222).  Returns D×D row-major.
+inline std::vector<double> pooled_regularized_cov(const double* X, int64_t J, int D, double lambda) {
+    std::vector<double> mean(D), S((size_t)D * D);
+    for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+        for (int64_t j = 0; j < J; ++j) s = s + X[(size_t)j * D + i];
+        mean[i] = s / (double)J;
+    }
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            double acc = 0.0;
+            for (int64_t j = 0; j < J; ++j) acc = __builtin_fma(X[(size_t)j * D + i] - mean[i], X[(size_t)j * D + k] - mean[k], acc);
+            double s = acc / (double)(J - 1);
+            double v = (1 - lambda) * s;
+            if (i == k) v = v + lambda * s;
+            S[(size_t)i * D + k] = v;
+        }
+    return S;
+}
+
 }  // namespace oracle

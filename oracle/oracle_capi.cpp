@@ -121,6 +121,20 @@ int oracle_set_metric_dense(oracle_ctx* c, const double* minv) {
     for (auto& ch : c->chains) ch.kappa = k;
     return DHMC_OK;
 }
+int oracle_update_metric_dense(oracle_ctx* c, const double* draws, int64_t N, double lambda) {
+    if (c->cfg.metric != DHMC_METRIC_DENSE || N < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;
+    std::vector<double> S = pooled_regularized_cov(draws, (int64_t)c->cfg.chains * N, c->cfg.dim, lambda);
+    GaussianKineticEnergy k = GaussianKineticEnergy::dense_from(S.data(), c->cfg.dim);
+    if (k.D != c->cfg.dim) return DHMC_ERR_INVALID_ARGUMENT;
+    for (auto& ch : c->chains) ch.kappa = k;
+    return DHMC_OK;
+}
+int oracle_get_metric_dense_Minv(oracle_ctx* c, double* M) {
+    const auto& k = c->chains[0].kappa;
+    if (!k.dense) return DHMC_ERR_INVALID_ARGUMENT;
+    std::memcpy(M, k.Minv.data(), sizeof(double) * k.Minv.size());
+    return DHMC_OK;
+}
 // W (lower triangular, row-major D×D) of chain 0's dense metric
 int oracle_get_metric_dense_W(oracle_ctx* c, double* W) {
     const auto& k = c->chains[0].kappa;

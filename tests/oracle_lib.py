@@ -190,6 +190,15 @@ class Oracle:
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(lib().oracle_set_metric_dense(self.h, _p(minv)))
 
+    def update_metric_dense(self, draws, lam):
+        draws = np.ascontiguousarray(draws, np.float64)
+        self._chk(lib().oracle_update_metric_dense(self.h, _p(draws), C.c_int64(draws.shape[1]), C.c_double(lam)))
+
+    def metric_dense(self):
+        M = np.zeros((self.D, self.D))
+        self._chk(lib().oracle_get_metric_dense_Minv(self.h, _p(M)))
+        return M, self.metric_dense_W()
+
     def metric_dense_W(self):
         W = np.zeros((self.D, self.D))
         self._chk(lib().oracle_get_metric_dense_W(self.h, _p(W)))

@@ -85,3 +85,45 @@ def test_perfect_metric_correlated_normal(pkg):
     assert np.abs(q.mean(0)).sum() < tol * K
     assert np.allclose(Cov, Sigma, atol=0.1, rtol=0.1)
     assert a["depth"].mean() < 3.5             # a perfect metric decorrelates: short trees
+
+
+def test_dense_metric_adaptation_pooled(pkg):
+    """TuningNUTS{Symmetric}: κ := GaussianKineticEnergy(regularize(Symmetric(cov(pm)), λ)) (mcmc.jl:210,218-222,
+    281-284), pooled over the chains that share the dense M⁻¹; device (MFMA covariance) == oracle, bit for bit,
+    and the estimate approaches the target's covariance."""
+    K, C = 12, 16
+    rho = 0.6
+    diag = np.full(K, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
+    off = np.full(K, -rho / (1 - rho ** 2))
+    P = np.diag(diag) + np.diag(off[:K - 1], 1) + np.diag(off[:K - 1], -1)
+    params = np.concatenate([diag, off])
+    dev = pkg.DeviceContext(K, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=6)
+    ora = ol.Oracle(K, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=6, threads=8)
+    for e in (dev, ora):
+        e.init(); e.find_initial_stepsize()
+    for n in (40, 75, 150):
+        a, b = dev.run(n, da={}), ora.run(n, da={})
+        same(a, b, f"stage {n}")
+        lam = 5.0 / n
+        dev.update_metric_dense(a["draws"], lam); ora.update_metric_dense(b["draws"], lam)
+        md, Wd = dev.metric_dense(); mo, Wo = ora.metric_dense()
+        assert np.array_equal(md, mo) and np.array_equal(Wd, Wo)
+    same(dev.run(30), ora.run(30), "after adaptation")
+    assert np.allclose(md, np.linalg.inv(P), atol=0.35, rtol=0.3)      # 2400 pooled draws
+
+
+def test_default_warmup_with_symmetric_metric(pkg):
+    """mcmc_with_warmup(...; warmup_stages = default_warmup_stages(; M = Symmetric)) (mcmc.jl docstring :566-569)."""
+    K = 6
+    rho = 0.7
+    diag = np.full(K, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
+    off = np.full(K - 1, -rho / (1 - rho ** 2))
+    l = pkg.TridiagNormal(diag, off)
+    r = pkg.mcmc_with_warmup(5, l, 1500, chains=8, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric),
+                             reporter=pkg.NoProgressReport())
+    assert r["kappa"].dense and r["kappa"].Minv.shape == (K, K)
+    P = np.diag(diag) + np.diag(off, 1) + np.diag(off, -1)
+    q = r["posterior_matrix"].reshape(-1, K)
+    assert np.allclose(np.cov(q.T), np.linalg.inv(P), atol=0.15, rtol=0.15)
+    assert np.allclose(r["kappa"].Minv, np.linalg.inv(P), atol=0.3, rtol=0.3)
+    assert r["tree_statistics"].acceptance_rate.mean() >= 0.7
