@@ -68,30 +68,11 @@ def setup_context(pkg, torch, rank, chains, seed, short):
     return ctx
 
 
-def bulk_ess_min(torch, draws, ncoord=16):
-    """Rank-normalisation-free bulk ESS (Vehtari et al. 2021 multi-chain estimator with Geyer's
-    initial positive sequence), min over a spread of `ncoord` coordinates.  draws: [C][N][D]."""
-    C, N, Dd = draws.shape
-    idx = torch.linspace(0, Dd - 1, ncoord, device=draws.device).long()
-    x = draws[:, :, idx].permute(2, 0, 1).contiguous()            # [k][C][N]
-    xm = x - x.mean(dim=2, keepdim=True)
-    nfft = 1 << (2 * N - 1).bit_length()
-    f = torch.fft.rfft(xm, n=nfft, dim=2)
-    acov = torch.fft.irfft(f * f.conj(), n=nfft, dim=2)[:, :, :N] / N   # biased autocovariance per chain
-    chain_var = acov[:, :, 0] * N / (N - 1)
-    W = chain_var.mean(dim=1)
-    B = x.mean(dim=2).var(dim=1, unbiased=True) * N if C > 1 else torch.zeros_like(W)
-    var_plus = W * (N - 1) / N + B / N
-    rho = 1 - (W[:, None] - acov.mean(dim=1)) / var_plus[:, None]      # [k][N]
-    rho[:, 0] = 1
-    T = N // 2
-    pair = rho[:, 0:2 * T:2] + rho[:, 1:2 * T:2]                        # Geyer pairs
-    pos = (pair > 0).to(pair.dtype)
-    keep = torch.cumprod(pos, dim=1)
-    pair = torch.cummin(pair.clamp(min=0) * keep + (1 - keep) * 0, dim=1).values * keep
-    tau = -1 + 2 * pair.sum(dim=1)
-    tau = torch.maximum(tau, torch.tensor(1.0 / np.log10(C * N), device=tau.device, dtype=tau.dtype))
-    return float((C * N / tau).min())
+def bulk_ess_min(pkg, torch, draws, ncoord=16):
+    """min bulk ESS over a spread of `ncoord` coordinates, computed on the GPU (diagnostics.ess_bulk_device)."""
+    idx = torch.linspace(0, draws.shape[2] - 1, ncoord, device=draws.device).long()
+    ess, _ = pkg.diagnostics.ess_bulk_device(draws, idx)
+    return float(ess.min())
 
 
 def cpu_baseline(transitions, threads):
@@ -242,7 +223,7 @@ def main():
     _run(ctx, ess_T, {"draws": ess_draws})
     torch.cuda.synchronize()
     ess_dt = time.perf_counter() - e0
-    ess = bulk_ess_min(torch, ess_draws)
+    ess = bulk_ess_min(pkg, torch, ess_draws)
     del ess_draws
 
     t_max, total_leapfrogs, ess_rate = dt, leapfrogs, ess / ess_dt

@@ -54,3 +54,28 @@ def ess_rhat(x):
     pair = np.minimum.accumulate(np.clip(pair[:k], 0, None))
     tau = max(-1 + 2 * pair.sum(), 1 / np.log10(C * N))
     return C * N / tau, float(np.sqrt(var_plus / W))
+
+
+def ess_bulk_device(draws, coords=None):
+    """Bulk ESS per coordinate on the GPU for draws [C][N][D] held in a CUDA torch tensor (same estimator as
+    ess_rhat above: multi-chain autocorrelation by FFT, Geyer's initial monotone sequence), so ESS/s can be
+    reported without shipping the draws to the host.  Returns (ess [k], rhat [k])."""
+    import torch
+    C, N, D = draws.shape
+    idx = torch.arange(D, device=draws.device) if coords is None else torch.as_tensor(coords, device=draws.device)
+    x = draws[:, :, idx].permute(2, 0, 1).contiguous()                  # [k][C][N]
+    xm = x - x.mean(dim=2, keepdim=True)
+    nfft = 1 << (2 * N - 1).bit_length()
+    f = torch.fft.rfft(xm, n=nfft, dim=2)
+    acov = torch.fft.irfft(f * f.conj(), n=nfft, dim=2)[:, :, :N] / N
+    W = (acov[:, :, 0] * N / (N - 1)).mean(dim=1)
+    B = x.mean(dim=2).var(dim=1, unbiased=True) * N if C > 1 else torch.zeros_like(W)
+    var_plus = W * (N - 1) / N + B / N
+    rho = 1 - (W[:, None] - acov.mean(dim=1)) / var_plus[:, None]
+    rho[:, 0] = 1
+    T = N // 2
+    pair = rho[:, 0:2 * T:2] + rho[:, 1:2 * T:2]
+    keep = torch.cumprod((pair > 0).to(pair.dtype), dim=1)
+    pair = torch.cummin(pair.clamp(min=0) * keep, dim=1).values * keep
+    tau = torch.clamp(-1 + 2 * pair.sum(dim=1), min=1.0 / np.log10(C * N))
+    return C * N / tau, torch.sqrt(var_plus / W)

@@ -105,8 +105,12 @@ def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8,
     assert ((1.8 < e) & (e < 2.2)).all()
     s = pkg.diagnostics.summarize_tree_statistics(ts)
     assert s["N"] == 20000 and sum(s["termination_counts"].values()) == 20000 and sum(s["depth_counts"].values()) == 20000
-    ess, rhat = pkg.diagnostics.ess_rhat(rng.normal(size=(4, 2000)))
+    x = rng.normal(size=(4, 2000))
+    ess, rhat = pkg.diagnostics.ess_rhat(x)
     assert 6000 < ess < 10000 and abs(rhat - 1) < 0.01
+    import torch
+    e2, r2 = pkg.diagnostics.ess_bulk_device(torch.from_numpy(x)[:, :, None])     # same estimator, torch flavour
+    assert abs(float(e2[0]) - ess) / ess < 1e-6 and abs(float(r2[0]) - rhat) < 1e-9
 
 
 def test_shard_chains(pkg):
