@@ -75,7 +75,7 @@ __device__ __forceinline__ void begin_transition_request(const RunParams& P, con
 // Start of dhmc_run: load the chain's scalars into its TreeState and ask for the first momentum.
 template <int NPL>
 __global__ __launch_bounds__(64) void rounds_start_kernel(RunParams P, RoundBuffers R) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     TreeState& S = R.ts[chain];
     const uint32_t tr0 = P.st.transition[chain];
     if (lane == 0) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
 // K2: q′ = q + ϵ·(M⁻¹pₘ), (ℓq′, ∇ℓq′) = evaluate_ℓ(q′), p′ = pₘ + ϵ/2 ∇ℓq′   (hamiltonian.jl:278-280)
 template <class T, int NPL>
 __global__ __launch_bounds__(64) void rounds_k2_kernel(RunParams P, RoundBuffers R) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     TreeState& S = R.ts[chain];
     if (S.phase != PH_LEAF) return;
     const T tgt(P.tp);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void rounds_k2_kernel(RunParams P, RoundBuffers
 // K3: the leaf that the last leapfrog produced, and whatever follows it.
 template <class T, int NPL>
 __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers R) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     if (R.ts[chain].phase != PH_LEAF) return;
     __shared__ TreeState S;   // the chain's state, worked on in LDS, written back at the end
     {

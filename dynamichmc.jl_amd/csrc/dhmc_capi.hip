@@ -40,6 +40,9 @@ struct dhmc_ctx {
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
     RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
+    RoundBuffers rb2{};        // second half-batch: own list and counters, same vectors
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int dense_rounds = 1;
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     LogisticRound lr{};
@@ -171,15 +174,16 @@ int dispatch_npl(int npl, Op op, const void* P, hipStream_t s, const DenseMetric
     default: return DHMC_ERR_UNSUPPORTED;
     }
 }
-int dispatch(const dhmc_ctx* c, Op op, const void* P) {
+int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false) {
+    hipStream_t cs = use_override ? stream_override : c->stream;
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
     switch (c->cfg.target) {
-    case DHMC_TARGET_STD_NORMAL: return dispatch_npl<StdNormalT>(c->NPL, op, P, c->stream, M);
-    case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, c->stream, M);
-    case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, c->stream, M);
-    case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, c->stream, M);
-    case DHMC_TARGET_LOGISTIC: return dispatch_npl<LogisticT>(c->NPL, op, P, c->stream, M);
-    case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, c->stream, M);
+    case DHMC_TARGET_STD_NORMAL: return dispatch_npl<StdNormalT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_DIAG_NORMAL: return dispatch_npl<DiagNormalT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_LOGISTIC: return dispatch_npl<LogisticT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, cs, M);
     default: return DHMC_ERR_UNSUPPORTED;
     }
 }
@@ -357,8 +361,15 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.ts, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list, C))) return fail(rc);
-        if ((rc = dev_alloc(c, &c->rb.list_count, 2))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.list_count, 4))) return fail(rc);
         c->rb.done_count = c->rb.list_count + 1;
+        c->rb2 = c->rb;
+        c->rb2.list = c->rb.list + C / 2;
+        c->rb2.list_count = c->rb.list_count + 2;
+        c->rb2.done_count = c->rb.list_count + 3;
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.ts, 0, C * sizeof(TreeState)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cp, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cps, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -411,6 +422,9 @@ int dhmc_destroy(dhmc_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -650,26 +664,46 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         }
         c->last_rounds = rounds;
     } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
-        // round-based dense engine: every round is one leapfrog for every chain (dense_rounds.hpp)
-        RoundArgs ra{P, c->rb};
+        // Round-based dense engine (dense_rounds.hpp): every round is one leapfrog for every chain.  The chains
+        // run as two half-batches on two streams so that one half's HBM-bound tree kernel overlaps the other
+        // half's MFMA-bound contractions.
         const int ld = c->Dpad;
-        e = hipMemsetAsync(c->rb.list_count, 0, 2 * sizeof(int), c->stream);
-        if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
+        const int nh = (C >= 256 && C % 2 == 0) ? 2 : 1;
+        struct Half { RoundArgs ra; hipStream_t s; int base, count; } H[2];
+        for (int h = 0; h < nh; ++h) {
+            H[h].base = h * (C / nh);
+            H[h].count = (h == nh - 1) ? C - H[h].base : C / nh;
+            H[h].ra = RoundArgs{P, h == 0 ? c->rb : c->rb2};
+            H[h].ra.P.chain_base = H[h].base;
+            H[h].ra.P.C = H[h].count;
+            H[h].s = h == 0 ? c->stream : c->stream2;
+        }
+        e = hipMemsetAsync(c->rb.list_count, 0, 4 * sizeof(int), c->stream);
+        if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
+        if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+        for (int h = 0; h < nh && e == hipSuccess; ++h) dispatch(c, Op::RoundStart, &H[h].ra, H[h].s, true);
         unsigned long long rounds = 0;
-        int done = 0;
-        while (e == hipSuccess && done < C) {
+        int done[4] = {0, 0, 0, 0};
+        while (e == hipSuccess && done[1] + done[3] < C) {
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
-                launch_gemm_rows(c->rb.cp, c->d_WT, c->rb.tbuf, ld, C, c->rb.list, c->rb.list_count, c->stream);     // p₀ = z·Wᵀ
-                launch_gemm_rows(c->rb.tbuf, c->d_Minv, c->rb.cps, ld, C, c->rb.list, c->rb.list_count, c->stream);  // p♯₀
-                dispatch(c, Op::RoundK0, &ra);
-                e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
-                launch_gemm_rows(c->rb.cp, c->d_Minv, c->rb.tbuf, ld, C, nullptr, nullptr, c->stream);               // M⁻¹pₘ
-                dispatch(c, Op::RoundK2, &ra);
-                launch_gemm_rows(c->rb.cp, c->d_Minv, c->rb.cps, ld, C, nullptr, nullptr, c->stream);                // p♯
-                dispatch(c, Op::RoundK3, &ra);
+                for (int h = 0; h < nh && e == hipSuccess; ++h) {
+                    const RoundBuffers& R = H[h].ra.R;
+                    const size_t off = (size_t)H[h].base * ld;
+                    hipStream_t s = H[h].s;
+                    launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, H[h].count, R.list, R.list_count, s);               // p₀ = z·Wᵀ
+                    launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, H[h].count, R.list, R.list_count, s);            // p♯₀
+                    dispatch(c, Op::RoundK0, &H[h].ra, s, true);
+                    e = hipMemsetAsync(R.list_count, 0, sizeof(int), s);
+                    launch_gemm_rows(R.cp + off, c->d_Minv, R.tbuf + off, ld, H[h].count, nullptr, nullptr, s);     // M⁻¹pₘ
+                    dispatch(c, Op::RoundK2, &H[h].ra, s, true);
+                    launch_gemm_rows(R.cp + off, c->d_Minv, R.cps + off, ld, H[h].count, nullptr, nullptr, s);      // p♯
+                    dispatch(c, Op::RoundK3, &H[h].ra, s, true);
+                }
             }
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_join, c->stream2);
+            if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(done, c->rb.list_count, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
         c->last_rounds = rounds;

@@ -21,13 +21,13 @@ namespace dhmc {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;
+constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;   // metric_dense_adapt.hpp's covariance kernel uses these
 
 // OUT[r][0..N) = Σ_k A[r][k] · B[k][0..N), k = 0..K-1 ascending, for rows r = 0..nrows-1 or the gathered rows
-// row_list[0..*row_count-1].  A is [*][lda], B is [K][ldb], OUT is [*][ldo]; K a multiple of 16, N a multiple of
+// row_list[0..*row_count-1].  A is [*][lda], B is [K][ldb], OUT is [*][ldo]; K a multiple of TK, N a multiple of
 // the column tile.  WT = waves per side, FR = 16×16 MFMA tiles per wave side: <2,2> -> 64×64 tile (4 waves,
 // each 32×32); <2,1> -> 32×32 tile (4 waves, each one MFMA tile) for skinny products.
-template <int WT, int FR>
+template <int WT, int FR, int TK>
 __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const double* __restrict__ A, int lda,
                                                                    const double* __restrict__ B, int ldb,
                                                                    double* __restrict__ OUT, int ldo, int K, int nrows,
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
                                                                    const int* __restrict__ row_count) {
     constexpr int WS = 16 * FR;                       // rows/cols per wave
     constexpr int TM = WS * WT, TN = WS * WT, NT = 64 * WT * WT;
+    constexpr int LS = TN + 16;                       // LDS row stride: the 4 k-rows of a fragment land on disjoint bank halves
     const int count = row_list ? *row_count : nrows;
     const int row0 = blockIdx.y * TM;
     if (row0 >= count) return;
@@ -42,12 +43,12 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w / WT, wc = w % WT;
 
-    __shared__ double As[GEMM_TK * GEMM_LDS_STRIDE];   // As[k][row]
-    __shared__ double Bs[GEMM_TK * GEMM_LDS_STRIDE];   // Bs[k][col]
+    __shared__ double As[TK * LS];   // As[k][row]
+    __shared__ double Bs[TK * LS];   // Bs[k][col]
 
-    // global -> LDS assignment: A tile TM×16 and B tile 16×TN, (TM*16)/NT doubles per thread each
-    constexpr int PER = (TM * GEMM_TK) / NT;            // 4 for WT=2 (256 thr), 8 for WT=1 (64 thr)
-    constexpr int A_TPR = GEMM_TK / PER;                // threads per A row
+    // global -> LDS assignment: A tile TM×TK and B tile TK×TN, (TM*TK)/NT doubles per thread each
+    constexpr int PER = (TM * TK) / NT;
+    constexpr int A_TPR = TK / PER;                     // threads per A row
     const int a_row = t / A_TPR, a_k = (t % A_TPR) * PER;
     int a_grow = row0 + a_row;
     a_grow = a_grow < count ? a_grow : count - 1;       // clamp (clamped rows are not stored)
@@ -67,24 +68,24 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     double av[PER], bv[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) { av[i] = a_src[i]; bv[i] = b_src[i]; }
-    for (int k0 = 0; k0 < K; k0 += GEMM_TK) {
+    for (int k0 = 0; k0 < K; k0 += TK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            As[(a_k + i) * GEMM_LDS_STRIDE + a_row] = av[i];
-            Bs[b_k * GEMM_LDS_STRIDE + b_c + i] = bv[i];
+            As[(a_k + i) * LS + a_row] = av[i];
+            Bs[b_k * LS + b_c + i] = bv[i];
         }
         __syncthreads();
-        if (k0 + GEMM_TK < K) {
+        if (k0 + TK < K) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                av[i] = a_src[k0 + GEMM_TK + i];
-                bv[i] = b_src[(size_t)(k0 + GEMM_TK) * ldb + i];
+                av[i] = a_src[k0 + TK + i];
+                bv[i] = b_src[(size_t)(k0 + TK) * ldb + i];
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < GEMM_TK; kk += 4) {
-            const int kr = (kk + (lane >> 4)) * GEMM_LDS_STRIDE;
+        for (int kk = 0; kk < TK; kk += 4) {
+            const int kr = (kk + (lane >> 4)) * LS;
             double a[FR], b[FR];
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
     dim3 grid(ld / 64, (nrows + 63) / 64);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
 }
 // General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16).  64×64 tiles (4 waves × 32×32)
 // when that grid fills the chip; otherwise 32×32 tiles worked by 4 waves of one 16×16 MFMA tile each, so a
@@ -127,10 +128,10 @@ inline void launch_gemm(const double* A, int lda, const double* B, int ldb, doub
     const long tiles64 = (long)((M + 63) / 64) * (N / 64);
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     } else {
         dim3 grid(N / 32, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 1>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 1, 64>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     }
 }
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void rounds_momentum_diag_kernel(RunParams P, R
 // K1: q′ = q + ϵ·(M⁻¹∘pₘ)
 template <int NPL>
 __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBuffers R) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     const TreeState& S = R.ts[chain];
     if (S.phase != PH_LEAF) return;
     const size_t row = (size_t)chain * P.Dpad;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBu
 
 // K_r: per-observation link, residual and log-likelihood terms of one chain (one wave per chain).
 __global__ __launch_bounds__(64) void logistic_residual_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     if (R.ts[chain].phase != PH_LEAF) return;
     const int64_t N = P.tp.n, Npad = P.tp.npad;
     double* h = L.H + (size_t)chain * Npad;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void logistic_residual_kernel(RunParams P, Roun
 // K2: gradient, log density, second half step, p♯
 template <int NPL>
 __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     TreeState& S = R.ts[chain];
     if (S.phase != PH_LEAF) return;
     const size_t row = (size_t)chain * P.Dpad;

@@ -73,7 +73,7 @@ struct ChainArrays {
 
 struct RunParams {
     int D, Dpad, C, chain_offset, max_depth, nvec;
-    int l1_in_lds, pad_;
+    int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
     double min_delta;
     uint64_t seed;
     int64_t N;
