@@ -20,6 +20,7 @@ namespace dhmc {
 
 struct LogisticRound {
     double* H;    // [C][Npad]  η, then r
+    double* T;    // [C][Npad]  per-observation log-likelihood terms
     double* S1;   // [C]        Σ_n [y_n η_n − log1pexp(η_n)]
 };
 
@@ -54,25 +55,34 @@ __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBu
     }
 }
 
-// K_r: per-observation link, residual and log-likelihood terms of one chain (one wave per chain).
-__global__ __launch_bounds__(64) void logistic_residual_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
-    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
+// K_r, part 1: per-observation link, residual and log-likelihood term — elementwise over [C][Npad], any order:
+// H <- r, T <- y η − log(1+e^η)  (0 for the padding observations).
+__global__ __launch_bounds__(256) void logistic_link_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+    const int chain = P.chain_base + blockIdx.y;
     if (R.ts[chain].phase != PH_LEAF) return;
     const int64_t N = P.tp.n, Npad = P.tp.npad;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Npad) return;
     double* h = L.H + (size_t)chain * Npad;
-    const double* y = P.tp.c;
+    double* tt = L.T + (size_t)chain * Npad;
+    const double eta = h[n];
+    const double t = det_exp(-__builtin_fabs(eta));
+    const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+    const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
+    const bool valid = n < N;
+    const double yn = P.tp.c[n];
+    h[n] = valid ? yn - sig : 0.0;
+    tt[n] = valid ? yn * eta - l1pe : 0.0;
+}
+
+// K_r, part 2: S₁ = Σ_n T[n] in the ABI's wave order (lane l accumulates n = l, l+64, … ascending; butterfly).
+__global__ __launch_bounds__(64) void logistic_sum_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
+    if (R.ts[chain].phase != PH_LEAF) return;
+    const int64_t Npad = P.tp.npad;
+    const double* tt = L.T + (size_t)chain * Npad;
     double lpart = 0.0;
-    for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) {
-        const int64_t n = n0 + lane;
-        const double eta = h[n];
-        const double t = det_exp(-__builtin_fabs(eta));
-        const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-        const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
-        const bool valid = n < N;
-        const double yn = y[n];
-        h[n] = valid ? yn - sig : 0.0;
-        lpart = lpart + (valid ? yn * eta - l1pe : 0.0);
-    }
+    for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) lpart = lpart + tt[n0 + lane];
     const double s1 = wave_allreduce1(lpart);
     if (lane == 0) L.S1[chain] = s1;
 }
