@@ -30,10 +30,6 @@
 #include "targets.hpp"
 #include "wave.hpp"
 
-#ifndef DHMC_L2_REG
-#define DHMC_L2_REG 0
-#endif
-
 namespace dhmc {
 
 // DualAveragingState (stepsize.jl:121-127)
@@ -265,7 +261,7 @@ __device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t pu
 // 4 Dpad-rows of LDS per wave, i.e. one wave per SIMD at Dpad = 1024).
 // ------------------------------------------------------------------------------------------
 template <class T, int NPL, bool L1LDS>
-__global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P) {
+__global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kernel(RunParams P) {
     const int chain = blockIdx.x;
     const int lane = threadIdx.x;
     const int D = P.D, Dpad = P.Dpad;
@@ -299,8 +295,10 @@ __global__ __launch_bounds__(64, L1LDS ? 1 : 2) void nuts_run_kernel(RunParams P
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
     double tpm[NPL], tpp[NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
-    constexpr bool kL2Reg = DHMC_L2_REG != 0;
-    double l2f[kL2Reg ? NPL : 1], l2l[kL2Reg ? NPL : 1], l2r[kL2Reg ? NPL : 1];  // the level-2 suspended summary: first, last, ρ
+    // the level-2 suspended summary (first, last, ρ) also stays in registers when vectors are short enough
+    // (from NPL = 4 up the three extra vectors would spill; there level 2 goes to the HBM workspace)
+    constexpr bool kL2Reg = NPL <= 2;
+    double l2f[kL2Reg ? NPL : 1], l2l[kL2Reg ? NPL : 1], l2r[kL2Reg ? NPL : 1];
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(P.st.g + row, lane, g);
     double lq_cur = P.st.lq[chain];
