@@ -2,9 +2,9 @@
 """bench.py — leapfrog-steps/sec (all chains) + ESS/sec of the many-chain NUTS hot path.
 
 Workload (BASELINE.json configs[1]): 1000-dim standard MVN, diagonal mass matrix, 4096 chains
-per MI355X.  Untimed setup reproduces the reference's warmup shape in short form (random
-positions mcmc.jl:108, initial step size search, dual-averaging stages with per-chain diagonal
-metric updates, mcmc.jl:415-425) so the timed region runs at adapted per-chain ϵ and M⁻¹.
+per MI355X.  Untimed setup is the reference's default warmup (random positions mcmc.jl:108, initial
+step size search, 900 dual-averaging transitions with per-chain diagonal metric updates after the
+25/50/100/200/400 windows, mcmc.jl:415-425) so the timed region runs at adapted per-chain ϵ and M⁻¹.
 
 One "step" = one dhmc_run call = one pass of the per-draw loop (mcmc.jl:374-379) of
 `--transitions` NUTS transitions for every chain, draws and tree statistics written to
@@ -57,8 +57,9 @@ def setup_context(pkg, torch, rank, chains, seed, short):
                             stream=stream)
     ctx.init()
     ctx.find_initial_stepsize()
-    # shortened default_warmup_stages (mcmc.jl:415-425): stepsize-only, two metric windows, stepsize-only
-    stages = [(20, False), (25, True), (20, False)] if short else [(75, False), (25, True), (50, True), (100, True), (50, False)]
+    # default_warmup_stages (mcmc.jl:415-425): 75 stepsize-only, metric windows 25/50/100/200/400, 50 stepsize-only
+    stages = [(20, False), (25, True), (20, False)] if short else \
+        [(75, False), (25, True), (50, True), (100, True), (200, True), (400, True), (50, False)]
     for n, metric in stages:
         draws = torch.empty((chains, n, D), dtype=torch.float64, device="cuda") if metric else None
         _run(ctx, n, {"draws": draws} if metric else {}, da={})
@@ -157,7 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--transitions", type=int, default=20, help="NUTS transitions per chain per step")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
-    ap.add_argument("--full-warmup", action="store_true", help="300-transition adaptive setup instead of 65")
+    ap.add_argument("--short-warmup", action="store_true", help="65-transition adaptive setup instead of the reference's 900")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-transitions", type=int, default=150)
     ap.add_argument("--seed", type=int, default=0x23EF614D)
@@ -183,7 +184,7 @@ def main():
     if args.config == 3:
         return bench_config3(args, pkg, torch)
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
-    ctx = setup_context(pkg, torch, rank, C, args.seed, not args.full_warmup)
+    ctx = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
     out = {
         "draws": torch.empty((C, T, D), dtype=torch.float64, device="cuda"),
         "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
