@@ -1,0 +1,75 @@
+"""GPU: the alternative engines of the library produce the same bits.  The production paths (LDS-resident
+diagonal kernel, dense round engine with MFMA GEMMs, GEMM-gradient round engine for logistic regression) are
+checked against the independent wave-per-chain kernels selected by the documented tuning knobs."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def _run_with_env(pkg, env, make, steps):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = make()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return steps(ctx)
+
+
+def _same(a, b):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_diag_kernel_lds_variants_agree(pkg):
+    def steps(ctx):
+        ctx.init(); ctx.find_initial_stepsize()
+        r = ctx.run(30, da={})
+        ctx.update_metric_diag(r["draws"])
+        return ctx.run(20)
+    make = lambda: pkg.DeviceContext(1000, 32, seed=5)
+    _same(_run_with_env(pkg, {"DHMC_L1_LDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_L1_LDS": "0"}, make, steps))
+
+
+def test_dense_round_engine_equals_wave_kernel(pkg):
+    rng = np.random.default_rng(3)
+    K = 96
+    A = rng.normal(size=(K, K)); Minv = np.linalg.inv(A.T @ A / K + 0.1 * np.eye(K))
+
+    def steps(ctx):
+        ctx.set_metric_dense(Minv); ctx.init(); ctx.find_initial_stepsize()
+        a = ctx.run(25, da={})
+        b = ctx.run(15)
+        return {**{"w_" + k: v for k, v in a.items()}, **b}
+    make = lambda: pkg.DeviceContext(K, 300, metric=ol.METRIC_DENSE, seed=9)        # 300 chains: two half-batches of 150
+    _same(_run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "0"}, make, steps))
+
+
+def test_logistic_round_engine_equals_functor_kernel(pkg):
+    rng = np.random.default_rng(4)
+    N, D = 777, 70
+    X = rng.normal(size=(N, D)) / 8; y = (rng.random(N) < 0.5).astype(float)
+    params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
+
+    def steps(ctx):
+        ctx.init(); ctx.find_initial_stepsize()
+        a = ctx.run(20, da={})
+        ctx.update_metric_diag(a["draws"])
+        return {**{"w_" + k: v for k, v in a.items()}, **ctx.run(12)}
+    make = lambda: pkg.DeviceContext(D, 40, target=ol.TARGET_LOGISTIC, target_params=params, seed=2)
+    _same(_run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "0"}, make, steps))
