@@ -787,6 +787,7 @@ int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {
     if (!c || !nbytes) return DHMC_ERR_INVALID_ARGUMENT;
     const uint64_t C = c->cfg.chains, Dp = c->Dpad;
     *nbytes = sizeof(BlobHeader) + 4 * C * Dp * sizeof(double) + 2 * C * sizeof(double) + C * sizeof(DAState) + 2 * C * sizeof(uint32_t);
+    if (c->cfg.metric == DHMC_METRIC_DENSE) *nbytes += 2 * Dp * Dp * sizeof(double);   // shared dense M⁻¹ and Wᵀ
     return DHMC_OK;
 }
 
@@ -807,6 +808,10 @@ static int blob_io(dhmc_ctx* c, char* blob, bool exporting) {
     HIP_TRY(c, io(c->st.da, C * sizeof(DAState)));
     HIP_TRY(c, io(c->st.transition, C * sizeof(uint32_t)));
     HIP_TRY(c, io(c->st.status, C * sizeof(uint32_t)));
+    if (c->cfg.metric == DHMC_METRIC_DENSE) {
+        HIP_TRY(c, io(c->d_Minv, Dp * Dp * sizeof(double)));
+        HIP_TRY(c, io(c->d_WT, Dp * Dp * sizeof(double)));
+    }
     return DHMC_OK;
 }
 

@@ -127,3 +127,16 @@ def test_default_warmup_with_symmetric_metric(pkg):
     assert np.allclose(np.cov(q.T), np.linalg.inv(P), atol=0.15, rtol=0.15)
     assert np.allclose(r["kappa"].Minv, np.linalg.inv(P), atol=0.3, rtol=0.3)
     assert r["tree_statistics"].acceptance_rate.mean() >= 0.7
+
+
+def test_dense_state_export_import(pkg):
+    """The resume blob of a dense context carries the shared M⁻¹ / W as well."""
+    K = 10
+    Minv = np.linalg.inv(rand_sigma(K))
+    a = pkg.DeviceContext(K, 3, metric=ol.METRIC_DENSE, seed=4); b = pkg.DeviceContext(K, 3, metric=ol.METRIC_DENSE, seed=4)
+    a.set_metric_dense(Minv); a.init(); a.find_initial_stepsize(); a.run(10, da={})
+    b.import_state(a.export_state())
+    assert np.array_equal(a.metric_dense()[1], b.metric_dense()[1])
+    ra, rb = a.run(6), b.run(6)
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
