@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DHMC_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libd
 
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE = range(6)
 ST_NONFINITE_POSITION, ST_INVALID_INITIAL, ST_STEPSIZE_SEARCH_FAILED, ST_NONFINITE_START_DENSITY = 1, 2, 4, 8
-TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT = range(6)
+TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT, TARGET_DENSE_NORMAL = range(7)
 METRIC_DIAG, METRIC_DENSE = 0, 1
 
 ERROR_NAMES = {ERR_INVALID_ARGUMENT: "invalid argument", ERR_HIP: "HIP runtime error",

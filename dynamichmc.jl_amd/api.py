@@ -25,7 +25,7 @@ __all__ = [
     "default_warmup_stages", "fixed_stepsize_warmup_stages", "GaussianKineticEnergy",
     "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
-    "StandardNormal", "DiagNormal", "TridiagNormal", "Funnel", "LogisticRegression", "AlwaysDivergent",
+    "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent",
     "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
     "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
 ]
@@ -240,6 +240,21 @@ class TridiagNormal(_Target):
 
     def params(self):
         return np.concatenate([self.diag, self.off])
+
+
+class MvNormal(_Target):
+    """ℓ(q) = -½ (q-μ)'Σ⁻¹(q-μ) with a full covariance Σ — the reference tests' multivariate_normal(μ, L)
+    (test/utilities.jl:64).  Intended for small correlated targets (the precision is streamed per chain)."""
+    family = abi.TARGET_DENSE_NORMAL
+
+    def __init__(self, mu, Sigma):
+        self.mu = np.asarray(mu, np.float64); self.Sigma = np.asarray(Sigma, np.float64)
+        self.D = self.mu.size
+        _argcheck(self.Sigma.shape == (self.D, self.D), "Σ is D×D")
+        self.P = np.linalg.inv(self.Sigma); self.P = (self.P + self.P.T) / 2
+
+    def params(self):
+        return np.concatenate([self.mu, self.P.ravel()])
 
 
 class Funnel(_Target):

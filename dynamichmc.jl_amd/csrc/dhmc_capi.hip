@@ -186,6 +186,7 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
     case DHMC_TARGET_TRIDIAG_NORMAL: return dispatch_npl<TridiagNormalT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_FUNNEL: return dispatch_npl<FunnelT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_LOGISTIC: return dispatch_npl<LogisticT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_DENSE_NORMAL: return dispatch_npl<DenseNormalT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_npl<AlwaysDivergentT>(c->NPL, op, P, cs, M);
     default: return DHMC_ERR_UNSUPPORTED;
     }
@@ -294,6 +295,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     case DHMC_TARGET_DIAG_NORMAL: case DHMC_TARGET_TRIDIAG_NORMAL:
         if (!cfg->target_params || cfg->target_params_bytes != sizeof(double) * 2 * (size_t)D) return DHMC_ERR_INVALID_ARGUMENT;
         break;
+    case DHMC_TARGET_DENSE_NORMAL:
+        if (!cfg->target_params || cfg->target_params_bytes != sizeof(double) * ((size_t)D + (size_t)D * D)) return DHMC_ERR_INVALID_ARGUMENT;
+        break;
     case DHMC_TARGET_LOGISTIC: {
         if (!cfg->target_params || cfg->target_params_bytes < 8) return DHMC_ERR_INVALID_ARGUMENT;
         int64_t n;
@@ -312,8 +316,13 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->NPL = npl_for_dim(D);
     if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
     c->Dpad = c->NPL * WAVE;
-    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG;
-    if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS")) c->logistic_rounds = c->logistic_rounds && std::atoi(e) != 0;
+    // Round engines pay ≈8 launches per leapfrog round; they win once a round carries enough chains to fill the
+    // chip (GEMM rows), otherwise the one-wave-per-chain kernels are faster.  DHMC_*_ROUNDS=0/1 overrides.
+    const bool many_chains = cfg->chains >= 128;
+    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && many_chains;
+    if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
+        c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0;
+    c->dense_rounds = many_chains;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
@@ -377,6 +386,20 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemset(c->rb.cp, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cps, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.tbuf, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    }
+    c->tp.Dpad = (int32_t)Dp;
+    if (cfg->target == DHMC_TARGET_DENSE_NORMAL) {
+        const double* src = (const double*)cfg->target_params;
+        std::vector<double> mu(Dp, 0.0), Pm(Dp * Dp, 0.0);
+        std::memcpy(mu.data(), src, sizeof(double) * D);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) Pm[(size_t)i * Dp + j] = (i <= j) ? src[D + (size_t)i * D + j] : src[D + (size_t)j * D + i];
+        double *dmu = nullptr, *dP = nullptr;
+        if ((rc = dev_alloc(c, &dmu, Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &dP, Dp * Dp))) return fail(rc);
+        if (hipMemcpy(dmu, mu.data(), Dp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        if (hipMemcpy(dP, Pm.data(), Dp * Dp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        c->tp.a = dmu; c->tp.b = dP;
     }
     if (cfg->target == DHMC_TARGET_LOGISTIC) {
         // X [npad][Dpad] row-major and Xᵀ [Dpad][npad], zero padded (GEMM operands of the round engine; the

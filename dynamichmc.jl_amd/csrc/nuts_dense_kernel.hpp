@@ -31,24 +31,6 @@ __host__ __device__ inline size_t lds_bytes_dense() {
     return sizeof(double) * (3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
 }
 
-// out = S v for symmetric S (rows streamed, coalesced): out_i = Σ_k fma(S[k][i], v_k, ·), k ascending.
-template <int NPL>
-__device__ __forceinline__ void sym_matvec(const double* __restrict__ S, int Dpad, int D, int lane,
-                                           const double (&v)[NPL], double (&out)[NPL]) {
-#pragma unroll
-    for (int s = 0; s < NPL; ++s) out[s] = 0.0;
-#pragma unroll
-    for (int s2 = 0; s2 < NPL; ++s2) {
-        const int kcount = (D - WAVE * s2) < WAVE ? (D - WAVE * s2) : WAVE;
-        for (int l2 = 0; l2 < kcount; ++l2) {
-            const double vk = readlane_f64(v[s2], l2);
-            const double* __restrict__ rowk = S + (size_t)(WAVE * s2 + l2) * Dpad;
-#pragma unroll
-            for (int s = 0; s < NPL; ++s) out[s] = __builtin_fma(rowk[lane + WAVE * s], vk, out[s]);
-        }
-    }
-}
-
 // rand_p (hamiltonian.jl:124): p = W z, and its p♯
 template <int NPL>
 __device__ __forceinline__ void sample_momentum_dense(const ChainKey& key, uint32_t purpose, uint32_t transition,

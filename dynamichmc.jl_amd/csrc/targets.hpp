@@ -23,8 +23,8 @@
 namespace dhmc {
 
 struct TargetParams {
-    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      LOGISTIC: X  [n][Dpad]     (padded, device)
-    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off       LOGISTIC: Xᵀ [D][npad]
+    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      LOGISTIC: X  [n][Dpad]     DENSE_NORMAL: mu        (padded, device)
+    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off       LOGISTIC: Xᵀ [D][npad]    DENSE_NORMAL: P [Dpad][Dpad]
     const double* c;  //                                          LOGISTIC: y  [npad]
     int64_t n;        //                                          LOGISTIC: observations
     int64_t npad;     //                                          LOGISTIC: n rounded up to 64
@@ -101,6 +101,35 @@ struct TridiagNormalT {
             if (e < D - 1) t = t + off[e] * qp;
             acc = __builtin_fma(q[k], t, acc);
             g[k] = -t;
+        }
+        return acc;
+    }
+    __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
+};
+
+// ℓ = -1/2 (q-μ)'P(q-μ) with a full symmetric precision P (the reference tests' multivariate_normal(μ, L),
+// test/utilities.jl:64, P = (LL')⁻¹): (Pd)_i is one fma chain over k ascending, streamed from L2 per chain —
+// meant for the small correlated targets of the statistical tests, not for large D.
+struct DenseNormalT {
+    static constexpr bool kDeferred = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    const double* mu;
+    const double* P;
+    int Dpad;
+    __device__ explicit DenseNormalT(const TargetParams& p) : mu(p.a), P(p.b), Dpad(p.Dpad) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        double d[NPL], Pd[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) d[k] = q[k] - mu[lane + WAVE * k];
+        sym_matvec<NPL>(P, Dpad, D, lane, d, Pd);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            acc = __builtin_fma(d[k], Pd[k], acc);
+            g[k] = -Pd[k];
         }
         return acc;
     }

@@ -76,6 +76,7 @@ extern "C" {
 #define DHMC_TARGET_TRIDIAG_NORMAL 2 /* l = -1/2 q'Pq, P symmetric tridiagonal.  params: double diag[D], off[D] (off[D-1] ignored) */
 #define DHMC_TARGET_FUNNEL 3      /* Neal's funnel: v=q_0~N(0,3^2), q_i|v~N(0,e^v). params: none */
 #define DHMC_TARGET_LOGISTIC 4    /* Bernoulli-logit regression, N(0,I) prior.  params: int64 n; double X[n][D]; double y[n] */
+#define DHMC_TARGET_DENSE_NORMAL 6 /* l = -1/2 (q-mu)'P(q-mu), P full symmetric (read from its upper triangle). params: double mu[D], P[D][D] */
 #define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
 
 /* ---- kinetic energy (GaussianKineticEnergy, hamiltonian.jl:56-87) -------------------- */

@@ -38,6 +38,9 @@ static std::unique_ptr<Target> make_target(const dhmc_config& cfg) {
         if (cfg.target_params_bytes != sizeof(double) * 2 * (size_t)D) return nullptr;
         return std::make_unique<TridiagNormal>(D, pd, pd + D);
     case DHMC_TARGET_FUNNEL: return D >= 2 ? std::make_unique<Funnel>(D) : nullptr;
+    case DHMC_TARGET_DENSE_NORMAL:
+        if (cfg.target_params_bytes != sizeof(double) * ((size_t)D + (size_t)D * D)) return nullptr;
+        return std::make_unique<DenseNormal>(D, pd, pd + D);
     case DHMC_TARGET_LOGISTIC: {
         if (!cfg.target_params || cfg.target_params_bytes < 8) return nullptr;
         int64_t n;

@@ -66,6 +66,27 @@ struct TridiagNormal : Target {
     }
 };
 
+// DHMC_TARGET_DENSE_NORMAL: ℓ = -1/2 (q-μ)'P(q-μ), P symmetric (upper triangle); (Pd)_i is one fma chain over k
+struct DenseNormal : Target {
+    std::vector<double> mu, P;
+    DenseNormal(int d, const double* m, const double* p) : mu(m, m + d), P((size_t)d * d) {
+        D = d;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) P[(size_t)i * d + j] = (i <= j) ? p[(size_t)i * d + j] : p[(size_t)j * d + i];
+    }
+    void eval(const MathOps&, const double* q, double& lq, double* g) const override {
+        std::vector<double> dv(D), Pd(D);
+        for (int i = 0; i < D; ++i) dv[i] = q[i] - mu[i];
+        for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            for (int k = 0; k < D; ++k) acc = __builtin_fma(P[(size_t)k * D + i], dv[k], acc);
+            Pd[i] = acc;
+            g[i] = -acc;
+        }
+        lq = -0.5 * wave_dot(dv.data(), Pd.data(), D);
+    }
+};
+
 // DHMC_TARGET_FUNNEL (Neal): v = q_0 ~ N(0, 3²), q_i | v ~ N(0, e^v), i >= 1
 //   ℓ = -v²/18 - 1/2 e^{-v} Σ q_i² - (D-1)/2 v
 struct Funnel : Target {

@@ -1,0 +1,54 @@
+"""Extracts the NUMERIC test inputs (μ, d, C / Σ literals) of the reference's statistical tests
+(/root/reference/test/sample-correctness_tests.jl:27-87) into tests/golden/reference_mvn_cases.json.
+Only data is kept — each case becomes {name, mu, L} with x = μ + L z, z ~ N(0, I) (the reference's
+multivariate_normal(μ, L), test/utilities.jl:64-67); no source text is copied.  Run in the build container
+(the reference is not present on the GPU box)."""
+import json
+import os
+import re
+
+import numpy as np
+
+SRC = "/root/reference/test/sample-correctness_tests.jl"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_matrix(txt):
+    rows = [r.strip() for r in txt.replace("\n", " ").split(";")]
+    return np.array([[float(x) for x in r.split()] for r in rows if r])
+
+
+def main():
+    src = open(SRC).read()
+    cases = []
+    # --- ill-conditioned: μ = [...], d = [...], C = [...] possibly followed by ' (transpose) -------------
+    sec = src[src.index('@testset "ill-conditioned multivariate normal"'):src.index('@testset "NUTS tests with specific normal distributions"')]
+    mus = re.findall(r"μ = \[([^\]]+)\]", sec)
+    ds = re.findall(r"\bd = \[([^\]]+)\]", sec)
+    Cs = re.findall(r"C = \[([^\]]+)\]('?)", sec)
+    mu_for = [mus[0], mus[0], mus[1]]          # the second case reuses the first μ
+    for i in range(3):
+        mu = np.array([float(x) for x in mu_for[i].split(",")])
+        d = np.array([float(x) for x in ds[i].split(",")])
+        C = parse_matrix(Cs[i][0])
+        if Cs[i][1] == "'":
+            C = C.T
+        cases.append(dict(name=f"ill-conditioned {i + 1}", mu=mu.tolist(), L=(np.diag(d) @ C).tolist(), metric="Symmetric"))
+    # --- specific normals -------------------------------------------------------------------------------
+    cases.append(dict(name="univariate huge variance", mu=[0.0], L=[[5e8]], metric="Diagonal"))
+    cases.append(dict(name="univariate huge variance, offset", mu=[1.0], L=[[5e8]], metric="Diagonal"))
+    cases.append(dict(name="univariate tiny variance, offset", mu=[1.0], L=[[5e-8]], metric="Diagonal"))
+    cases.append(dict(name="mildly scaled diagonal", mu=[1.0, 2.0, 3.0], L=np.diag([1.0, 2.0, 3.0]).tolist(), metric="Diagonal"))
+    sec = src[src.index('@testset "NUTS tests with specific normal distributions"'):src.index('@testset "NUTS tests with mixtures"')]
+    for m in re.finditer(r"multivariate_normal\(\s*\[([^\]]+)\],\s*cholesky\(\[([^\]]+)\]\)\.L\)", sec):
+        mu = np.array([float(x) for x in m.group(1).split(",")])
+        S = parse_matrix(m.group(2))
+        cases.append(dict(name=f"kept {len(mu)} dim", mu=mu.tolist(), L=np.linalg.cholesky(S).tolist(), metric="Diagonal"))
+    with open(os.path.join(HERE, "reference_mvn_cases.json"), "w") as fh:
+        json.dump(cases, fh, indent=0)
+    for c in cases:
+        print(c["name"], len(c["mu"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 # constants of include/dhmc.h
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE = range(6)
 ST_NONFINITE_POSITION, ST_INVALID_INITIAL, ST_STEPSIZE_SEARCH_FAILED, ST_NONFINITE_START_DENSITY = 1, 2, 4, 8
-TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT = range(6)
+TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT, TARGET_DENSE_NORMAL = range(7)
 METRIC_DIAG, METRIC_DENSE = 0, 1
 
 
@@ -103,6 +103,8 @@ def target_params_blob(target, D, **kw):
         o = np.asarray(kw["off"], np.float64)
         off[:len(o)] = o
         return np.concatenate([np.asarray(kw["diag"], np.float64), off])
+    if target == TARGET_DENSE_NORMAL:
+        return np.concatenate([np.asarray(kw["mu"], np.float64), np.ascontiguousarray(kw["P"], np.float64).ravel()])
     if target == TARGET_LOGISTIC:
         X = np.ascontiguousarray(kw["X"], np.float64); y = np.ascontiguousarray(kw["y"], np.float64)
         return np.concatenate([np.array([X.shape[0]], np.int64).view(np.float64), X.ravel(), y])

@@ -57,7 +57,12 @@ def test_config3_dense_metric_1000dim_slice(pkg):
     idx = np.arange(D)
     Sigma = np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
     params = np.concatenate([diag, off])
-    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=3)
+    import os
+    os.environ["DHMC_DENSE_ROUNDS"] = "1"          # the production engine (MFMA GEMM rounds) even for this 4-chain slice
+    try:
+        dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=3)
+    finally:
+        del os.environ["DHMC_DENSE_ROUNDS"]
     ora = ol.Oracle(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=3, threads=4)
     q0 = np.random.default_rng(5).normal(size=(C, D)) * sig
     for e in (dev, ora):
@@ -66,6 +71,7 @@ def test_config3_dense_metric_1000dim_slice(pkg):
     for k in a:
         assert np.array_equal(a[k], b[k]), k
     assert (a["steps"] >= 3).all()
+    assert dev.last_run_rounds() > 0
 
 
 def test_config4_funnel_4096_chains(pkg):
@@ -110,7 +116,12 @@ def test_config5_logistic_p256_slice(pkg):
 
     X, y = data(2000)
     params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
-    dev = pkg.DeviceContext(D, 6, target=ol.TARGET_LOGISTIC, target_params=params, seed=8)
+    import os
+    os.environ["DHMC_LOGISTIC_ROUNDS"] = "1"       # the production engine (GEMM gradients) even for 6 chains
+    try:
+        dev = pkg.DeviceContext(D, 6, target=ol.TARGET_LOGISTIC, target_params=params, seed=8)
+    finally:
+        del os.environ["DHMC_LOGISTIC_ROUNDS"]
     ora = ol.Oracle(D, 6, target=ol.TARGET_LOGISTIC, params=params, seed=8, threads=6)
     for e in (dev, ora):
         e.init(); e.find_initial_stepsize()
