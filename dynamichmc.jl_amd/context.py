@@ -195,6 +195,48 @@ class DeviceContext:
         self._chk(abi.lib().dhmc_update_metric_dense(self.h, _ptr(draws), C.c_int64(draws.shape[1]), C.c_double(lam), int(_is_device(draws))),
                   "dhmc_update_metric_dense")
 
+    # ---- Diagnostics probes (src/diagnostics.jl) ---------------------------------------------
+    def _probe_chk(self, rc, what, status, allow_failure):
+        if rc == abi.ERR_CHAIN_FAILURE and not allow_failure:
+            bad = np.nonzero(status)[0]
+            bits = int(np.bitwise_or.reduce(status[bad]))
+            msg = next(m for b, m in STATUS_MESSAGES if bits & b)
+            raise DynamicHMCError(msg, chains=bad[:16].tolist(), n_failed=int(bad.size), status=status[bad[:16]].tolist())
+        return self._chk(rc, what, allow_failure)
+
+    def leapfrog_trajectory(self, eps, first, last, p=None, momentum_index=0, with_points=True, allow_failure=False):
+        """leapfrog_trajectory (diagnostics.jl:214-227) for every chain from its current position."""
+        npos = int(last) - int(first) + 1
+        if npos < 1:
+            raise ValueError("ArgumentError in dhmc_leapfrog_trajectory")
+        out = dict(delta=np.zeros((self.C, npos)), logdensity=np.zeros((self.C, npos)),
+                   range=np.zeros((self.C, 2), np.int32), status=np.zeros(self.C, np.uint32),
+                   q=np.zeros((self.C, npos, self.D)) if with_points else None,
+                   p=np.zeros((self.C, npos, self.D)) if with_points else None)
+        if p is not None:
+            p = np.ascontiguousarray(np.broadcast_to(p, (self.C, self.D)), np.float64)
+        rc = abi.lib().dhmc_leapfrog_trajectory(self.h, C.c_double(eps), C.c_int32(first), C.c_int32(last),
+                                                C.c_uint32(momentum_index), _ptr(p), _ptr(out["delta"]),
+                                                _ptr(out["logdensity"]), _ptr(out["q"]), _ptr(out["p"]),
+                                                _ptr(out["range"]), _ptr(out["status"]))
+        self._probe_chk(rc, "dhmc_leapfrog_trajectory", out["status"], allow_failure)
+        return out
+
+    def explore_log_acceptance_ratios(self, eps, n_momenta=20, ps=None, momentum_index=0, allow_failure=False):
+        """explore_log_acceptance_ratios (diagnostics.jl:144-152): [C][n_momenta][len(eps)]."""
+        eps = np.ascontiguousarray(np.atleast_1d(eps), np.float64)
+        if ps is not None:
+            ps = np.ascontiguousarray(ps, np.float64)
+            if ps.ndim == 2:
+                ps = np.ascontiguousarray(np.broadcast_to(ps, (self.C,) + ps.shape))
+            n_momenta = ps.shape[1]
+        out = np.zeros((self.C, n_momenta, eps.size))
+        status = np.zeros(self.C, np.uint32)
+        rc = abi.lib().dhmc_explore_log_acceptance_ratios(self.h, _ptr(eps), C.c_int32(eps.size), C.c_int32(n_momenta),
+                                                          C.c_uint32(momentum_index), _ptr(ps), _ptr(out), _ptr(status))
+        self._probe_chk(rc, "dhmc_explore_log_acceptance_ratios", status, allow_failure)
+        return out
+
     # ---- resume ----------------------------------------------------------------------------
     def export_state(self):
         n = C.c_uint64()

@@ -20,6 +20,7 @@
 #include "metric_dense_adapt.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
+#include "probe_kernels.hpp"
 
 using namespace dhmc;
 
@@ -149,12 +150,25 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
 #undef DHMC_NPL_SWITCH
 }
 
-enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3 };
+enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3, ProbeTrajectory, ProbeRatios };
 
 template <class T, int NPL>
 void dispatch_op(Op op, const void* P, hipStream_t s, const DenseMetric* M) {
     if (op == Op::RoundStart || op == Op::RoundK0 || op == Op::RoundK2 || op == Op::RoundK3) {
         launch_round_op<T, NPL>((int)op - (int)Op::RoundStart, *(const RoundArgs*)P, s);
+        return;
+    }
+    if (op == Op::ProbeTrajectory || op == Op::ProbeRatios) {
+        const ProbeParams& Q = *(const ProbeParams*)P;
+        const dim3 g(Q.C), b(WAVE);
+        if (M) {
+            if (op == Op::ProbeTrajectory) hipLaunchKernelGGL((probe_kernel<T, NPL, true, 0>), g, b, 0, s, Q, *M);
+            else hipLaunchKernelGGL((probe_kernel<T, NPL, true, 1>), g, b, 0, s, Q, *M);
+        } else {
+            const size_t lds = sizeof(double) * Q.Dpad;
+            if (op == Op::ProbeTrajectory) hipLaunchKernelGGL((probe_kernel<T, NPL, false, 0>), g, b, lds, s, Q, DenseMetric{});
+            else hipLaunchKernelGGL((probe_kernel<T, NPL, false, 1>), g, b, lds, s, Q, DenseMetric{});
+        }
         return;
     }
     if (M && op == Op::Run) { launch_run_dense<T, NPL>(*(const RunParams*)P, *M, s); return; }
@@ -805,6 +819,98 @@ struct BlobHeader {
     int32_t dim, chains, Dpad, reserved;
 };
 static const uint64_t BLOB_MAGIC = 0x31434d4844ull;  // "DHMC1"
+
+// ---- Diagnostics probes (probe_kernels.hpp) ---------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+int probe_finish(dhmc_ctx* c, const DevBuf& dst, uint32_t* status) {
+    const int C = c->cfg.chains;
+    std::vector<uint32_t> st(C);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), dst.p, sizeof(uint32_t) * C, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = DHMC_OK;
+    for (int i = 0; i < C; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i]) rc = DHMC_ERR_CHAIN_FAILURE;
+    }
+    return rc;
+}
+}  // namespace
+
+int dhmc_leapfrog_trajectory(dhmc_ctx* c, double eps, int32_t first, int32_t last, uint32_t momentum_index,
+                             const double* p, double* delta, double* logdensity, double* q_out, double* p_out,
+                             int32_t* range, uint32_t* status) {
+    if (!c || !delta || !logdensity) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!(first <= 0 && 0 <= last)) return DHMC_ERR_INVALID_ARGUMENT;   // diagnostics.jl:218
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int C = c->cfg.chains, D = c->cfg.dim;
+    const size_t npos = (size_t)last - first + 1;
+    DevBuf dp, dd, dl, dq, dpo, dr, dst;
+    HIP_TRY(c, hipMalloc(&dd.p, sizeof(double) * C * npos));
+    HIP_TRY(c, hipMalloc(&dl.p, sizeof(double) * C * npos));
+    HIP_TRY(c, hipMalloc(&dr.p, sizeof(int32_t) * 2 * C));
+    HIP_TRY(c, hipMalloc(&dst.p, sizeof(uint32_t) * C));
+    // positions that are not visited stay NaN (all-ones bit pattern)
+    HIP_TRY(c, hipMemsetAsync(dd.p, 0xFF, sizeof(double) * C * npos, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dl.p, 0xFF, sizeof(double) * C * npos, c->stream));
+    if (q_out) {
+        HIP_TRY(c, hipMalloc(&dq.p, sizeof(double) * C * npos * D));
+        HIP_TRY(c, hipMemsetAsync(dq.p, 0xFF, sizeof(double) * C * npos * D, c->stream));
+    }
+    if (p_out) {
+        HIP_TRY(c, hipMalloc(&dpo.p, sizeof(double) * C * npos * D));
+        HIP_TRY(c, hipMemsetAsync(dpo.p, 0xFF, sizeof(double) * C * npos * D, c->stream));
+    }
+    if (p) {
+        HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * D));
+        HIP_TRY(c, hipMemcpyAsync(dp.p, p, sizeof(double) * C * D, hipMemcpyHostToDevice, c->stream));
+    }
+    ProbeParams P{};
+    P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset; P.seed = c->cfg.seed;
+    P.st = c->st; P.tp = c->tp; P.momentum_index = momentum_index; P.p_in = (const double*)dp.p; P.n_mom = 1;
+    P.eps = eps; P.first = first; P.last = last;
+    P.out_delta = (double*)dd.p; P.out_lq = (double*)dl.p; P.out_q = (double*)dq.p; P.out_p = (double*)dpo.p;
+    P.out_range = (int32_t*)dr.p; P.out_status = (uint32_t*)dst.p;
+    int rc = dispatch(c, Op::ProbeTrajectory, &P);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(delta, dd.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(logdensity, dl.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
+    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, dq.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
+    if (p_out) HIP_TRY(c, hipMemcpyAsync(p_out, dpo.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
+    if (range) HIP_TRY(c, hipMemcpyAsync(range, dr.p, sizeof(int32_t) * 2 * C, hipMemcpyDeviceToHost, c->stream));
+    return probe_finish(c, dst, status);
+}
+
+int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n_eps, int32_t n_momenta,
+                                       uint32_t momentum_index, const double* ps, double* out, uint32_t* status) {
+    if (!c || !eps || !out || n_eps <= 0 || n_momenta <= 0) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int C = c->cfg.chains, D = c->cfg.dim;
+    const size_t nout = (size_t)C * n_momenta * n_eps;
+    DevBuf de, dp, dout, dst;
+    HIP_TRY(c, hipMalloc(&de.p, sizeof(double) * n_eps));
+    HIP_TRY(c, hipMalloc(&dout.p, sizeof(double) * nout));
+    HIP_TRY(c, hipMalloc(&dst.p, sizeof(uint32_t) * C));
+    HIP_TRY(c, hipMemcpyAsync(de.p, eps, sizeof(double) * n_eps, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dout.p, 0xFF, sizeof(double) * nout, c->stream));
+    if (ps) {
+        HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * n_momenta * D));
+        HIP_TRY(c, hipMemcpyAsync(dp.p, ps, sizeof(double) * C * n_momenta * D, hipMemcpyHostToDevice, c->stream));
+    }
+    ProbeParams P{};
+    P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset; P.seed = c->cfg.seed;
+    P.st = c->st; P.tp = c->tp; P.momentum_index = momentum_index; P.p_in = (const double*)dp.p; P.n_mom = n_momenta;
+    P.eps_list = (const double*)de.p; P.n_eps = n_eps; P.out_delta = (double*)dout.p; P.out_status = (uint32_t*)dst.p;
+    int rc = dispatch(c, Op::ProbeRatios, &P);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
+    return probe_finish(c, dst, status);
+}
 
 int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {
     if (!c || !nbytes) return DHMC_ERR_INVALID_ARGUMENT;

@@ -7,7 +7,7 @@
 namespace dhmc {
 
 enum : uint32_t { PURPOSE_MOMENTUM = 0, PURPOSE_DIRECTIONS = 1, PURPOSE_TREE = 2,
-                  PURPOSE_SEARCH_MOMENTUM = 3, PURPOSE_INIT_POSITION = 4 };
+                  PURPOSE_SEARCH_MOMENTUM = 3, PURPOSE_INIT_POSITION = 4, PURPOSE_PROBE_MOMENTUM = 5 };
 
 struct ChainKey {
     uint32_t k0, k1, seed_hi;

@@ -79,3 +79,62 @@ def ess_bulk_device(draws, coords=None):
     pair = torch.cummin(pair.clamp(min=0) * keep, dim=1).values * keep
     tau = torch.clamp(-1 + 2 * pair.sum(dim=1), min=1.0 / np.log10(C * N))
     return C * N / tau, torch.sqrt(var_plus / W)
+
+
+# ---- diagnostics that call the hot path (device) -------------------------------------------------------------
+
+def _probe_context(l, q, kappa, rng, device):
+    from . import _abi as abi
+    from .api import GaussianKineticEnergy, _argcheck, _as_rng
+    from .context import DeviceContext
+    q = np.asarray(q, np.float64)
+    q2 = q[None, :] if q.ndim == 1 else q                       # [C][D]: one start point per chain
+    kappa = GaussianKineticEnergy(l.dimension()) if kappa is None else kappa   # diagnostics.jl:146,216
+    _argcheck(kappa.size() == l.dimension(), "dimension(ℓ) == size(κ, 1)")    # hamiltonian.jl:147
+    rng = _as_rng(0x23EF614D if rng is None else rng)
+    ctx = DeviceContext(l.dimension(), q2.shape[0], target=l.family, target_params=l.params(), seed=rng.seed,
+                        chain_offset=rng.chain_offset, device=device,
+                        metric=abi.METRIC_DENSE if kappa.dense else abi.METRIC_DIAG)
+    ctx.init(q2, allow_failure=True)                            # evaluate_ℓ(ℓ, q), non-strict (diagnostics.jl:148,219)
+    if (ctx.status() & abi.ST_NONFINITE_POSITION).any():        # hamiltonian.jl:203 throws also when non-strict
+        ctx._raise(abi.ERR_CHAIN_FAILURE, "evaluate_ℓ")
+    if kappa.dense:
+        ctx.set_metric_dense(kappa.Minv)
+    else:
+        ctx.set_metric_diag(kappa.Minv)
+    return ctx, q.ndim == 1
+
+
+def explore_log_acceptance_ratios(l, q, log2eps, *, rng=None, kappa=None, N=20, ps=None, device=0):
+    """diagnostics.jl:144-152: the uncapped log acceptance ratios of one leapfrog step from `q` for step sizes
+    2.0 .^ log2ϵs and `N` random momenta (or the given `ps` [N][D]); returns [len(log2eps), N] as the reference
+    (with a leading chain axis when `q` is [C][D])."""
+    ctx, single = _probe_context(l, q, kappa, rng, device)
+    try:
+        eps = np.power(2.0, np.asarray(log2eps, np.float64))
+        out = ctx.explore_log_acceptance_ratios(eps, n_momenta=N, ps=ps)       # [C][N][n_eps]
+    finally:
+        ctx.close()
+    out = np.swapaxes(out, 1, 2)
+    return out[0] if single else out
+
+
+def leapfrog_trajectory(l, q, eps, positions, *, rng=None, kappa=None, p=None, device=0):
+    """diagnostics.jl:214-227: the leapfrog trajectory through `positions` (a range containing 0) relative to
+    `q`, tracked in each direction up to the first non-finite log density.  Returns a list of dicts
+    (z = dict(q, lq, p), position, Δ) as the reference's vector of NamedTuples (a list per chain for [C][D] q)."""
+    positions = list(positions)
+    A, B = positions[0], positions[-1]
+    if not (positions == list(range(A, B + 1)) and A <= 0 <= B):
+        raise ValueError("ArgumentError: Positions has to contain `0`.")     # diagnostics.jl:218
+    ctx, single = _probe_context(l, q, kappa, rng, device)
+    try:
+        r = ctx.leapfrog_trajectory(eps, A, B, p=p)
+    finally:
+        ctx.close()
+    res = []
+    for c in range(r["delta"].shape[0]):
+        lo, hi = r["range"][c]
+        res.append([dict(z=dict(q=r["q"][c, i - A], lq=float(r["logdensity"][c, i - A]), p=r["p"][c, i - A]),
+                         position=i, Δ=float(r["delta"][c, i - A])) for i in range(lo, hi + 1)])
+    return res[0] if single else res

@@ -42,6 +42,8 @@
  *   purpose 3: momentum for the initial step size search (mcmc.jl:139), as purpose 0.
  *   purpose 4: initial position U[-2,2)^D (mcmc.jl:108): call index j yields coordinates
  *              e0,e1 as for purpose 0, q = u01_closed_open(r)*4 - 2.
+ *   purpose 5: momenta of the leapfrog probes (Diagnostics, diagnostics.jl:147,216), as purpose 0 with
+ *              the momentum's index in the `transition` word.
  * A Julia `TapeRNG <: AbstractRNG` that replays this stream makes the real reference
  * reproduce these draws.
  */
@@ -188,6 +190,28 @@ int dhmc_update_metric_diag(dhmc_ctx* ctx, const double* draws, int64_t n, doubl
  * chains == 1 this is the reference's estimator.  Returns DHMC_ERR_INVALID_ARGUMENT if the estimate is not
  * positive definite (e.g. J <= D with λ = 0). */
 int dhmc_update_metric_dense(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda, int on_device);
+
+/* ---- Diagnostics that call the hot path directly (src/diagnostics.jl), for every chain from its current
+ *      position; the chains are not modified.  All buffers are HOST pointers.  status [C] (may be NULL)
+ *      receives the DHMC_ST_* bits of the reference's throw sites; any non-zero bit makes the call return
+ *      DHMC_ERR_CHAIN_FAILURE (outputs are still written). --------------------------------------------- */
+/* leapfrog_trajectory(ℓ, q, ϵ, first:last; κ, p) (diagnostics.jl:214-227): positions first..last relative
+ * to the chain's position (first <= 0 <= last, else DHMC_ERR_INVALID_ARGUMENT as the @argcheck of :218), step
+ * eps forward and -eps backward, each direction tracked until the first non-finite ℓq (that point included,
+ * :176-186).  p: [C][D] momenta, or NULL for p = rand_p (stream purpose 5, index momentum_index).
+ * delta, logdensity: [C][npos] (Δ = logdensity(H,z) - π₀, :196; ℓq), npos = last-first+1; q_out, p_out:
+ * [C][npos][D] or NULL; range: [C][2] = the positions actually visited (lo, hi).  Entries of positions
+ * that were not visited are NaN. */
+int dhmc_leapfrog_trajectory(dhmc_ctx* ctx, double eps, int32_t first, int32_t last, uint32_t momentum_index,
+                             const double* p, double* delta, double* logdensity, double* q_out, double* p_out,
+                             int32_t* range, uint32_t* status);
+/* explore_log_acceptance_ratios(ℓ, q, log2ϵs; κ, N, ps) (diagnostics.jl:144-152): out [C][n_momenta][n_eps]
+ * (= the reference's [n_eps, N] matrix, column-major, per chain) of the uncapped log acceptance ratios
+ * local_log_acceptance_ratio(H, PhasePoint(Q, p))(eps[i]) (stepsize.jl:75-85); eps = 2.0 .^ log2ϵs is formed
+ * by the caller.  ps: [C][n_momenta][D] or NULL for rand_p draws (purpose 5, indices momentum_index + m).
+ * A non-finite starting Hamiltonian sets DHMC_ST_NONFINITE_START_DENSITY (stepsize.jl:77-79). */
+int dhmc_explore_log_acceptance_ratios(dhmc_ctx* ctx, const double* eps, int32_t n_eps, int32_t n_momenta,
+                                       uint32_t momentum_index, const double* ps, double* out, uint32_t* status);
 
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);

@@ -12,6 +12,7 @@
 #endif
 #include "../include/dhmc.h"
 #include "dummy.hpp"
+#include "diagnostics.hpp"
 #include "mcmc.hpp"
 #include "metric.hpp"
 
@@ -183,6 +184,60 @@ int oracle_find_initial_stepsize(oracle_ctx* c, const dhmc_stepsize_search* p) {
 #pragma omp parallel for num_threads(c->threads) schedule(dynamic)
     for (int i = 0; i < C; ++i) warmup_stepsize_search(c->chains[i], *c->target, c->M, P);
     return any_failure(c);
+}
+
+// Diagnostics (include/dhmc.h: dhmc_leapfrog_trajectory / dhmc_explore_log_acceptance_ratios), same layouts
+int oracle_leapfrog_trajectory(oracle_ctx* c, double eps, int32_t first, int32_t last, uint32_t momentum_index,
+                               const double* p, double* delta, double* logdensity_out, double* q_out, double* p_out,
+                               int32_t* range, uint32_t* status) {
+    if (!(first <= 0 && 0 <= last)) return DHMC_ERR_INVALID_ARGUMENT;  // diagnostics.jl:218
+    int D = c->cfg.dim, C = c->cfg.chains, npos = last - first + 1;
+    int rc = DHMC_OK;
+    for (int i = 0; i < C; ++i) {
+        uint32_t st = 0;
+        auto tr = leapfrog_trajectory(c->chains[i], *c->target, c->M, eps, first, last, p ? p + (size_t)i * D : nullptr,
+                                      momentum_index, &st);
+        for (int k = 0; k < npos; ++k) {
+            delta[(size_t)i * npos + k] = NAN;
+            logdensity_out[(size_t)i * npos + k] = NAN;
+            for (int d = 0; d < D; ++d) {
+                if (q_out) q_out[((size_t)i * npos + k) * D + d] = NAN;
+                if (p_out) p_out[((size_t)i * npos + k) * D + d] = NAN;
+            }
+        }
+        int lo = 0, hi = 0;
+        for (auto& pi : tr) {
+            int k = pi.position - first;
+            delta[(size_t)i * npos + k] = pi.delta;
+            logdensity_out[(size_t)i * npos + k] = pi.z->Q.lq;
+            for (int d = 0; d < D; ++d) {
+                if (q_out) q_out[((size_t)i * npos + k) * D + d] = (*pi.z->Q.q)[d];
+                if (p_out) p_out[((size_t)i * npos + k) * D + d] = (*pi.z->p)[d];
+            }
+            lo = pi.position < lo ? pi.position : lo;
+            hi = pi.position > hi ? pi.position : hi;
+        }
+        if (range) { range[2 * i] = lo; range[2 * i + 1] = hi; }
+        if (status) status[i] = st;
+        if (st) rc = DHMC_ERR_CHAIN_FAILURE;
+    }
+    return rc;
+}
+int oracle_explore_log_acceptance_ratios(oracle_ctx* c, const double* eps, int32_t n_eps, int32_t n_momenta,
+                                         uint32_t momentum_index, const double* ps, double* out, uint32_t* status) {
+    if (n_eps < 0 || n_momenta < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    int D = c->cfg.dim, C = c->cfg.chains;
+    int rc = DHMC_OK;
+    for (int i = 0; i < C; ++i) {
+        uint32_t st = 0;
+        double* o = out + (size_t)i * n_momenta * n_eps;
+        for (int k = 0; k < n_momenta * n_eps; ++k) o[k] = NAN;
+        explore_log_acceptance_ratios(c->chains[i], *c->target, c->M, eps, n_eps, n_momenta,
+                                      ps ? ps + (size_t)i * n_momenta * D : nullptr, momentum_index, o, &st);
+        if (status) status[i] = st;
+        if (st) rc = DHMC_ERR_CHAIN_FAILURE;
+    }
+    return rc;
 }
 
 int oracle_run(oracle_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {

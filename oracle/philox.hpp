@@ -34,6 +34,7 @@ enum Purpose : uint32_t {
     PURPOSE_TREE = 2,
     PURPOSE_SEARCH_MOMENTUM = 3,
     PURPOSE_INIT_POSITION = 4,
+    PURPOSE_PROBE_MOMENTUM = 5,
 };
 
 // One chain's view of the stream: key = (seed lo, global chain index),

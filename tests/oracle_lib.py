@@ -247,6 +247,33 @@ class Oracle:
         draws = np.ascontiguousarray(draws, np.float64)
         self._chk(lib().oracle_update_metric_diag(self.h, _p(draws), C.c_int64(draws.shape[1]), C.c_double(lam)))
 
+    def leapfrog_trajectory(self, eps, first, last, p=None, momentum_index=0, allow_failure=False):
+        npos = last - first + 1
+        out = dict(delta=np.zeros((self.C, npos)), logdensity=np.zeros((self.C, npos)),
+                   range=np.zeros((self.C, 2), np.int32), status=np.zeros(self.C, np.uint32),
+                   q=np.zeros((self.C, npos, self.D)), p=np.zeros((self.C, npos, self.D)))
+        if p is not None:
+            p = np.ascontiguousarray(np.broadcast_to(p, (self.C, self.D)), np.float64)
+        rc = lib().oracle_leapfrog_trajectory(self.h, C.c_double(eps), C.c_int32(first), C.c_int32(last),
+                                              C.c_uint32(momentum_index), _p(p), _p(out["delta"]), _p(out["logdensity"]),
+                                              _p(out["q"]), _p(out["p"]), _p(out["range"]), _p(out["status"]))
+        self._chk(rc, (OK, ERR_CHAIN_FAILURE) if allow_failure else (OK,))
+        return out
+
+    def explore_log_acceptance_ratios(self, eps, n_momenta=20, ps=None, momentum_index=0, allow_failure=False):
+        eps = np.ascontiguousarray(np.atleast_1d(eps), np.float64)
+        if ps is not None:
+            ps = np.ascontiguousarray(ps, np.float64)
+            if ps.ndim == 2:
+                ps = np.ascontiguousarray(np.broadcast_to(ps, (self.C,) + ps.shape))
+            n_momenta = ps.shape[1]
+        out = np.zeros((self.C, n_momenta, eps.size))
+        status = np.zeros(self.C, np.uint32)
+        rc = lib().oracle_explore_log_acceptance_ratios(self.h, _p(eps), C.c_int32(eps.size), C.c_int32(n_momenta),
+                                                        C.c_uint32(momentum_index), _p(ps), _p(out), _p(status))
+        self._chk(rc, (OK, ERR_CHAIN_FAILURE) if allow_failure else (OK,))
+        return out
+
     def da_state(self):
         mu = np.zeros(self.C); m = np.zeros(self.C, np.int64); hb = np.zeros(self.C)
         le = np.zeros(self.C); leb = np.zeros(self.C)

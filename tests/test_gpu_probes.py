@@ -1,0 +1,131 @@
+"""GPU: the Diagnostics functions that call the hot path — leapfrog_trajectory and
+explore_log_acceptance_ratios (src/diagnostics.jl:144-152, 214-227) — through the C ABI, bit for bit against
+the oracle, plus the reference's own tests for them (test/test_diagnostics.jl:42-76) through the host API."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def _pair(pkg, D, C, target=ol.TARGET_STD_NORMAL, params=None, **kw):
+    return (pkg.DeviceContext(D, C, target=target, target_params=params, **kw),
+            ol.Oracle(D, C, target=target, params=params, threads=4, **kw))
+
+
+def _same(a, b, what):
+    for k in ("delta", "logdensity", "q", "p", "range", "status"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"{what}: {k}"
+
+
+CASES = [
+    ("std3", 3, ol.TARGET_STD_NORMAL, None),
+    ("std100", 100, ol.TARGET_STD_NORMAL, None),
+    ("std1000", 1000, ol.TARGET_STD_NORMAL, None),
+    ("diag70", 70, ol.TARGET_DIAG_NORMAL, lambda D: ol.target_params_blob(
+        ol.TARGET_DIAG_NORMAL, D, mu=np.linspace(-1, 1, D), prec=np.linspace(0.5, 4, D))),
+    ("funnel30", 30, ol.TARGET_FUNNEL, None),
+    ("tridiag200", 200, ol.TARGET_TRIDIAG_NORMAL, lambda D: ol.target_params_blob(
+        ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))),
+]
+
+
+@pytest.mark.parametrize("name,D,target,mk", CASES, ids=[c[0] for c in CASES])
+def test_trajectory_and_ratios_match_oracle(pkg, name, D, target, mk):
+    C = 5
+    params = mk(D) if mk else None
+    dev, ora = _pair(pkg, D, C, target=target, params=params, seed=7)
+    dev.init(); ora.init()
+    minv = np.random.default_rng(3).uniform(0.5, 2.0, (C, D))
+    dev.set_metric_diag(minv); ora.set_metric_diag(minv)
+    for eps, first, last, idx in ((0.1, -6, 9, 0), (0.37, 0, 5, 3), (0.05, -4, 0, 1)):
+        _same(dev.leapfrog_trajectory(eps, first, last, momentum_index=idx),
+              ora.leapfrog_trajectory(eps, first, last, momentum_index=idx), f"{name} eps={eps}")
+    p = np.random.default_rng(5).normal(size=(C, D))
+    _same(dev.leapfrog_trajectory(0.2, -2, 2, p=p), ora.leapfrog_trajectory(0.2, -2, 2, p=p), f"{name} given p")
+    eps = 2.0 ** np.arange(-5, 3)
+    a = dev.explore_log_acceptance_ratios(eps, n_momenta=7, momentum_index=2, allow_failure=True)
+    b = ora.explore_log_acceptance_ratios(eps, n_momenta=7, momentum_index=2, allow_failure=True)
+    assert np.array_equal(a, b, equal_nan=True), name
+    ps = np.random.default_rng(6).normal(size=(C, 3, D))
+    assert np.array_equal(dev.explore_log_acceptance_ratios(eps, ps=ps, allow_failure=True),
+                          ora.explore_log_acceptance_ratios(eps, ps=ps, allow_failure=True), equal_nan=True)
+    # the chains themselves are untouched
+    for x, y in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, y)
+    assert not dev.status().any()
+
+
+def test_dense_metric_probes_match_oracle(pkg):
+    D, C = 40, 4
+    params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
+    dev, ora = _pair(pkg, D, C, target=ol.TARGET_TRIDIAG_NORMAL, params=params, metric=ol.METRIC_DENSE, seed=21)
+    A = np.random.default_rng(1).normal(size=(D, D))
+    S = A @ A.T / D + np.eye(D)
+    dev.init(); ora.init()
+    dev.set_metric_dense(S); ora.set_metric_dense(S)
+    _same(dev.leapfrog_trajectory(0.15, -5, 7, momentum_index=4), ora.leapfrog_trajectory(0.15, -5, 7, momentum_index=4), "dense")
+    p = np.random.default_rng(2).normal(size=(C, D))
+    _same(dev.leapfrog_trajectory(0.15, -1, 3, p=p), ora.leapfrog_trajectory(0.15, -1, 3, p=p), "dense given p")
+    eps = 2.0 ** np.arange(-4, 2)
+    assert np.array_equal(dev.explore_log_acceptance_ratios(eps, n_momenta=5), ora.explore_log_acceptance_ratios(eps, n_momenta=5))
+
+
+def test_trajectory_stops_at_first_nonfinite_density(pkg):   # diagnostics.jl:176-186
+    D = 30
+    dev, ora = _pair(pkg, D, 6, target=ol.TARGET_FUNNEL, seed=5)
+    q0 = np.zeros((6, D)); q0[:, 0] = np.linspace(-6, 6, 6)
+    dev.init(q0); ora.init(q0)
+    a = dev.leapfrog_trajectory(40.0, -4, 4, allow_failure=True)     # an absurd step: overflow within a few steps
+    b = ora.leapfrog_trajectory(40.0, -4, 4, allow_failure=True)
+    for k in ("delta", "logdensity", "range"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert (a["range"][:, 1] < 4).any() or (a["range"][:, 0] > -4).any()
+    assert np.isnan(a["delta"]).any()
+    dv, oa = _pair(pkg, 4, 2, target=ol.TARGET_ALWAYS_DIVERGENT)
+    dv.init(np.zeros((2, 4)), allow_failure=True); oa.init(np.zeros((2, 4)), allow_failure=True)
+    x = dv.leapfrog_trajectory(0.1, -3, 4, allow_failure=True); y = oa.leapfrog_trajectory(0.1, -3, 4, allow_failure=True)
+    assert np.array_equal(x["range"], y["range"]) and np.array_equal(x["delta"], y["delta"], equal_nan=True)
+
+
+def test_argument_checks(pkg):   # diagnostics.jl:218
+    dev = pkg.DeviceContext(3, 2)
+    dev.init()
+    with pytest.raises(ValueError):
+        dev.leapfrog_trajectory(0.1, 1, 3)
+    with pytest.raises(ValueError):
+        dev.leapfrog_trajectory(0.1, -3, -1)
+
+
+def test_reference_log_acceptance_ratios(pkg):   # test_diagnostics.jl:42-49
+    l = pkg.DiagNormal(np.ones(5), np.ones(5))
+    log2eps = range(-5, 6)
+    logA = pkg.diagnostics.explore_log_acceptance_ratios(l, np.zeros(5), log2eps, N=13)
+    assert np.isfinite(logA).all()
+    assert logA.shape == (len(log2eps), 13)
+
+
+def test_reference_leapfrog_trajectory(pkg):   # test_diagnostics.jl:51-76
+    K, eps, ix0 = 2, 0.1, 5
+    l = pkg.DiagNormal(np.ones(K), np.ones(K))
+    kappa = pkg.GaussianKineticEnergy(K)
+    p = np.ones(K) * 0.98
+    # manual trajectory zs1[1..15] (0..14 steps from q = 0), by the closed-form Gaussian leapfrog
+    zs, q, pp = [], np.zeros(K), p.copy()
+    for _ in range(15):
+        zs.append((q.copy(), pp.copy(), -0.5 * ((q - 1) ** 2).sum() - 0.5 * (pp ** 2).sum()))
+        pm = pp + eps / 2 * (-(q - 1.0)); q = q + eps * pm; pp = pm + eps / 2 * (-(q - 1.0))
+    pis = np.array([z[2] for z in zs])
+    traj = pkg.diagnostics.leapfrog_trajectory(l, zs[ix0 - 1][0], eps, range(1 - ix0, 15 - ix0 + 1), kappa=kappa, p=zs[ix0 - 1][1])
+    assert [t["position"] for t in traj] == list(range(1 - ix0, 15 - ix0 + 1))
+    assert np.allclose([t["Δ"] for t in traj], pis - pis[ix0 - 1], atol=1e-5)
+    assert all(np.allclose(t["z"]["q"], z[0]) and np.allclose(t["z"]["p"], z[1]) for t, z in zip(traj, zs))
+    with pytest.raises(ValueError):
+        pkg.diagnostics.leapfrog_trajectory(l, np.zeros(K), eps, range(1, 4))
