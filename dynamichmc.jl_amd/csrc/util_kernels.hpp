@@ -1,0 +1,31 @@
+// Family-independent helper kernels of the C ABI (included by dhmc_capi.hip only).
+#pragma once
+#include "nuts_kernels.hpp"
+
+namespace dhmc {
+
+// Set M⁻¹ from a user array (GaussianKineticEnergy(Diagonal), hamiltonian.jl:80)
+__global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __restrict__ src, int per_chain,
+                                       double* __restrict__ minv, double* __restrict__ W) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * Dpad) return;
+    int c = (int)(idx / Dpad), e = (int)(idx % Dpad);
+    if (e < D) {
+        double m = src[per_chain ? (size_t)c * D + e : (size_t)e];
+        minv[idx] = m;
+        W[idx] = __builtin_sqrt(1.0 / m);
+    } else {
+        minv[idx] = 1.0;
+        W[idx] = 0.0;
+    }
+}
+
+// padded [C][Dpad] <-> unpadded [C][D]
+__global__ void unpad_kernel(int D, int Dpad, int C, const double* __restrict__ src, double* __restrict__ dst) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * D) return;
+    int c = (int)(idx / D), e = (int)(idx % D);
+    dst[idx] = src[(size_t)c * Dpad + e];
+}
+
+}  // namespace dhmc
