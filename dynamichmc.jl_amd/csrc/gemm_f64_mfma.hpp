@@ -114,6 +114,131 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Skinny product with a very long K (the logistic gradient G = R·X: 1024 × 10⁵ × 256): only M·N/256 ≈ one 16×16
+// MFMA tile per SIMD exists and each is one 10⁵-long k-ordered chain, so the kernel has to keep a single wave
+// per SIMD fed.  One workgroup per CU = 32×32 outputs (4 waves × one MFMA tile), K in steps of 64:
+//   * A (R[row][k], contiguous along k: transposed on the way) and B (X[k][col]) tiles go through double-buffered
+//     LDS with XOR swizzles (conflict-free fragment reads, at most 2-way conflicts on the writes);
+//   * three K-steps of 16-byte global loads are in flight ahead of the one being multiplied (register ring, loop
+//     unrolled by 4, no branch inside the unrolled body so the s_waitcnt placement keeps them in flight);
+//   * each 16×16×4 step is issued as four independent v_mfma_f64_4x4x4_f64 chains (below);
+//   * workgroup id -> tile is XCD-aware: the N/32 column tiles of one row block run on the same XCD back to back,
+//     so a row block of A is fetched from HBM once and re-read from that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SK_TK = 64;
+
+// v_mfma_f64_4x4x4_f64 (layout and order measured on gfx950, tools/experiments/mfma_f64_4x4x4_layout.hip): with
+// lane L = 16 g + 4 b + c, the instruction computes four independent 4×4×4 products, block b = 0..3:
+//     D[lane 16 i + 4 b + j] = fma chain over k = 0,1,2,3 (ascending, from C) of A[lane 16 k + 4 b + i] · B[lane 16 k + 4 b + j].
+// A 16×16×4 step of a wave's tile (4×4 blocks of 4×4) is issued as FOUR such instructions on four independent
+// accumulators: A operands u = 0,1 hold row block b^u in position b, B operands v = 0,1 hold column block
+// b^(2v); the 16 (row block, column block) pairs (b^u, b^2v) are all distinct, so acc[u][v] owns block pair
+// (b^u, b^2v) for the whole K loop — the same ascending k chain per output element as v_mfma_f64_16x16x4_f64,
+// but a single wave issues the four independent chains ~2.8× faster than the one dependent 16x16x4 chain
+// (tools/experiments/mfma_f64_chain.hip, mfma_f64_blocks_rate.hip: 73 vs 26 TFLOP/s at one wave per SIMD).
+// The operand "permutations" are just LDS read addresses (no DPP: lane rotations cost more than the MFMAs).
+template <int P>
+__global__ __launch_bounds__(256, 1) void gemm_skinny_f64_kernel(const double* __restrict__ A, int lda,
+                                                                 const double* __restrict__ B, int ldb,
+                                                                 double* __restrict__ OUT, int ldo, int K, int M, int N) {
+    static_assert(P % 2 == 0, "the LDS double buffer is indexed by the ring slot");
+    const int ncol = N / 32, nrb = (M + 31) / 32;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rb = xcd + 8 * (j / ncol), cb = j % ncol;
+    if (rb >= nrb) return;
+    const int row0 = rb * 32, col0 = cb * 32;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int r16 = lane & 15, kk = lane >> 4;
+
+    __shared__ double As[2][SK_TK * 32];   // As[buf][k][row ^ 2 (k >> 3)]
+    __shared__ double Bs[2][SK_TK * 32];   // Bs[buf][k][col ^ 2 (k & 3)]
+
+    // A: thread -> row a_row, the 8 consecutive k starting at 8 a_c (64 contiguous bytes)
+    const int a_row = t >> 3, a_c = t & 7;
+    int a_grow = row0 + a_row;
+    a_grow = a_grow < M ? a_grow : M - 1;
+    const double* a_src = A + (size_t)a_grow * lda + 8 * a_c;
+    const int a_dst = (8 * a_c) * 32 + (a_row ^ (2 * a_c));
+    // B: thread -> k row b_k, the 8 consecutive columns starting at 8 b_c
+    const int b_k = t >> 2, b_c = t & 3;
+    const double* b_src = B + (size_t)b_k * ldb + col0 + 8 * b_c;
+    const int b_dst = b_k * 32 + 8 * b_c, b_x = 2 * (b_k & 3);
+    // fragment reads
+    const int a_rd = 16 * wr + r16;                     // row; swizzle 2 (i >> 1) applied per step
+    const int b_rd = kk * 32 + ((16 * wc + r16) ^ (2 * kk));
+    const int nt = K / SK_TK;
+
+    double av[P][8], bv[P][8];
+    auto issue = [&](int tile, double (&a)[8], double (&b)[8]) {
+        const int tt = tile < nt ? tile : nt - 1;
+        const double* ap = a_src + (size_t)tt * SK_TK;
+        const double* bp = b_src + (size_t)tt * SK_TK * ldb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = ap[i]; b[i] = bp[i]; }
+    };
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < P - 1; ++s) issue(s, av[s], bv[s]);
+
+    // one K-step: refill the ring slot consumed in the previous step, stage tile `tile` through LDS, multiply
+    auto step = [&](int tile, int s) {
+#ifndef DHMC_SK_NO_LOADS
+        issue(tile + P - 1, av[(s + P - 1) % P], bv[(s + P - 1) % P]);
+#endif
+        double* as = As[s & 1];
+        double* bs = Bs[s & 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            as[a_dst + i * 32] = av[s][i];
+            bs[b_dst + (i ^ b_x)] = bv[s][i];
+        }
+        __syncthreads();
+        double af[2][16], bf[2][16];                   // all operands of the tile first: one LDS latency per tile
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ar = (4 * i + kk) * 32, sw = 2 * (i >> 1);
+            af[0][i] = as[ar + (a_rd ^ sw)];
+            af[1][i] = as[ar + (a_rd ^ sw ^ 4)];
+            bf[0][i] = bs[(4 * i) * 32 + b_rd];
+            bf[1][i] = bs[(4 * i) * 32 + (b_rd ^ 8)];
+        }
+#ifndef DHMC_SK_NO_MFMA
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[0][i], bf[0][i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[0][i], bf[1][i], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[1][i], bf[0][i], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[1][i], bf[1][i], acc[3], 0, 0, 0);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i & 3] += af[0][i] * bf[0][i] + af[1][i] * bf[1][i];
+#endif
+    };
+    // Full groups of P steps run without any branch inside the unrolled body, so the compiler's s_waitcnt
+    // placement keeps P-1 K-steps of loads in flight (a conditional body made it drain the queue every P steps).
+    const int nfull = nt - nt % P;
+    for (int t0 = 0; t0 < nfull; t0 += P) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) step(t0 + s, s);
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s)
+        if (nfull + s < nt) step(nfull + s, s);        // uniform
+    // acc[2u+v], lane 16 i + 4 b + j: row 4 (b^u) + i, column 4 (b^2v) + j of the wave's 16×16 tile
+    const int bb = (lane >> 2) & 3, bj = lane & 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int grow = row0 + 16 * wr + 4 * (bb ^ u) + kk;
+        if (grow < M) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) OUT[(size_t)grow * ldo + col0 + 16 * wc + 4 * (bb ^ (2 * v)) + bj] = acc[2 * u + v];
+        }
+    }
+}
+
 // host launchers.  Square metric products: OUT rows <- A rows · B with K = N = ld = Dpad.
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
@@ -129,6 +254,9 @@ inline void launch_gemm(const double* A, int lda, const double* B, int ldb, doub
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
         hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+    } else if (K % SK_TK == 0 && K >= 64 * SK_TK) {
+        const int ncol = N / 32, nrb = (M + 31) / 32;
+        hipLaunchKernelGGL((gemm_skinny_f64_kernel<4>), dim3(8 * ncol * ((nrb + 7) / 8)), dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, N);
     } else {
         dim3 grid(N / 32, (M + 31) / 32);
         hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 1, 64>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);

@@ -81,8 +81,18 @@ __global__ __launch_bounds__(64) void logistic_sum_kernel(RunParams P, RoundBuff
     if (R.ts[chain].phase != PH_LEAF) return;
     const int64_t Npad = P.tp.npad;
     const double* tt = L.T + (size_t)chain * Npad;
+    // the adds are one ordered chain per lane; the loads are not: 16 of them (8 KB per wave) in flight at a time
     double lpart = 0.0;
-    for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) lpart = lpart + tt[n0 + lane];
+    constexpr int U = 16;
+    int64_t n0 = 0;
+    for (; n0 + U * WAVE <= Npad; n0 += U * WAVE) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = tt[n0 + u * WAVE + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) lpart = lpart + v[u];
+    }
+    for (; n0 < Npad; n0 += WAVE) lpart = lpart + tt[n0 + lane];
     const double s1 = wave_allreduce1(lpart);
     if (lane == 0) L.S1[chain] = s1;
 }

@@ -60,9 +60,11 @@ def test_dense_round_engine_equals_wave_kernel(pkg):
     _same(_run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "0"}, make, steps))
 
 
-def test_logistic_round_engine_equals_functor_kernel(pkg):
+@pytest.mark.parametrize("N,D,C", [(777, 70, 40), (6000, 70, 40), (4100, 200, 70)],
+                         ids=["short-K", "long-K skinny GEMM", "long-K skinny GEMM, 3 row blocks"])
+def test_logistic_round_engine_equals_functor_kernel(pkg, N, D, C):
+    """N >= 4096 observations sends G = R·X through gemm_skinny_f64_kernel (deep-pipelined, XCD-aware)."""
     rng = np.random.default_rng(4)
-    N, D = 777, 70
     X = rng.normal(size=(N, D)) / 8; y = (rng.random(N) < 0.5).astype(float)
     params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
 
@@ -71,5 +73,5 @@ def test_logistic_round_engine_equals_functor_kernel(pkg):
         a = ctx.run(20, da={})
         ctx.update_metric_diag(a["draws"])
         return {**{"w_" + k: v for k, v in a.items()}, **ctx.run(12)}
-    make = lambda: pkg.DeviceContext(D, 40, target=ol.TARGET_LOGISTIC, target_params=params, seed=2)
+    make = lambda: pkg.DeviceContext(D, C, target=ol.TARGET_LOGISTIC, target_params=params, seed=2)
     _same(_run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "0"}, make, steps))
