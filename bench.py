@@ -100,7 +100,6 @@ def bench_config3(args, pkg, torch):
     """BASELINE.json configs[2]: 1000-dim correlated MVN (tridiagonal precision), dense M⁻¹ = Σ shared by all
     chains, 4096 chains, sampling at a fixed per-chain ϵ found by dual averaging.  Not the driver's line (that is
     configs[1]); run with --config 3 for the MFMA roofline of the dense path."""
-    import oracle_lib as ol
     Dd, C, T, K = 1000, args.chains, args.transitions, args.steps
     rho = 0.5
     sig = np.logspace(-1, 1, Dd)
@@ -109,7 +108,7 @@ def bench_config3(args, pkg, torch):
     off = np.zeros(Dd); off[:Dd - 1] = -rho / (1 - rho ** 2) / (sig[:-1] * sig[1:])
     idx = np.arange(Dd)
     Sigma = np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
-    ctx = pkg.DeviceContext(Dd, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL,
+    ctx = pkg.DeviceContext(Dd, C, metric=pkg.abi.METRIC_DENSE, target=pkg.abi.TARGET_TRIDIAG_NORMAL,
                             target_params=np.concatenate([diag, off]), seed=args.seed,
                             stream=torch.cuda.current_stream().cuda_stream)
     ctx.set_metric_dense(Sigma)
@@ -150,9 +149,65 @@ def bench_config3(args, pkg, torch):
                      "rounds": rounds}}))
 
 
+def bench_config45(args, pkg, torch):
+    """One GPU's share of BASELINE.json configs[3] (Neal's funnel D=30, 32768 chains over 8 GPUs -> 4096 here) and
+    configs[4] (logistic regression N=1e5, p=256, 8192 chains over 8 GPUs -> 1024 here).  Not the driver's line."""
+    T, K = args.transitions, args.steps
+    if args.config == 4:
+        D, C = 30, 4096 if args.chains == CHAINS_PER_GPU else args.chains
+        ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_FUNNEL, seed=args.seed, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.init(); ctx.find_initial_stepsize()
+        for n, metric in ((75, False), (25, True), (50, True), (100, True), (200, True), (50, False)):
+            d = torch.empty((C, n, D), dtype=torch.float64, device="cuda")
+            ctx.run_into(n, {"draws": d}, da={})
+            if metric:
+                ctx.update_metric_diag(d)
+        name = "Neal's funnel D=30, diagonal metric, 4096 chains = one GPU's share of 32768 (BASELINE.json configs[3])"
+        flops_per_leapfrog = None
+    else:
+        N, D, C = 100000, 256, 1024 if args.chains == CHAINS_PER_GPU else args.chains
+        rng = np.random.default_rng(0)
+        X = rng.normal(size=(N, D)) / 16
+        y = (rng.random(N) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+        ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_LOGISTIC, target_params=pkg.LogisticRegression(X, y).params(),
+                                seed=args.seed, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.init(); ctx.set_stepsize(0.02)
+        d = torch.empty((C, 20, D), dtype=torch.float64, device="cuda")
+        ctx.run_into(20, {"draws": d}, da={}); ctx.update_metric_diag(d); ctx.run_into(15, {}, da={})
+        name = "logistic regression N=1e5 p=256, diagonal metric, 1024 chains = one GPU's share of 8192 (BASELINE.json configs[4])"
+        flops_per_leapfrog = 4.0 * 100032 * 256      # two GEMM passes over X per gradient (SURVEY.md §8d)
+    out = {"steps": torch.empty((C, T), dtype=torch.int64, device="cuda"), "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
+           "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
+    for _ in range(args.warmup):
+        ctx.run_into(T, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); lf = 0; kms = []
+    for _ in range(K):
+        ctx.run_into(T, out)
+        lf += ctx.last_run_leapfrogs(); kms.append(ctx.last_run_kernel_ms())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if flops_per_leapfrog:
+        ach = lf * flops_per_leapfrog / (sum(kms) * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+                "kernel": "gemm_skinny_f64_kernel + gemm_rows_f64_kernel (fp64 MFMA), share of whole round time",
+                "note": "4·N·p flops per leapfrog of the chains that took it / total kernel time of the rounds"}
+    else:
+        ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                "kernel": "nuts_run_kernel<FunnelT,1>", "note": "48·D algorithmic bytes per leapfrog; a 30-dim chain is latency-, not bandwidth-bound"}
+    print(json.dumps({
+        "metric": "leapfrog-steps/sec (all chains)", "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "config": {"workload": name, "transitions_per_step": T, "chains_per_gpu": C},
+        "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
+                 "mean_acceptance": float(out["acceptance_rate"].mean())},
+        "roofline": roof}))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (default, diagonal metric) or 3 (dense metric)")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (default, diagonal metric), 3 (dense metric), 4 / 5 (one GPU's share of the funnel / logistic configs)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -183,6 +238,8 @@ def main():
 
     if args.config == 3:
         return bench_config3(args, pkg, torch)
+    if args.config in (4, 5):
+        return bench_config45(args, pkg, torch)
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
     ctx = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
     out = {

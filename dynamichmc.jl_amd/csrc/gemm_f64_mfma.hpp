@@ -17,9 +17,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef DHMC_GEMM_BLK
+#define DHMC_GEMM_BLK false
+#endif
+
 namespace dhmc {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+// one DPP-rotated copy of a double inside each row of 16 lanes (two 32-bit DPP movs; every lane has a source)
+template <int CTRL>
+__device__ __forceinline__ double gemm_dpp_f64(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;   // metric_dense_adapt.hpp's covariance kernel uses these
 
@@ -27,7 +40,7 @@ constexpr int GEMM_TK = 16, GEMM_LDS_STRIDE = 80;   // metric_dense_adapt.hpp's 
 // row_list[0..*row_count-1].  A is [*][lda], B is [K][ldb], OUT is [*][ldo]; K a multiple of TK, N a multiple of
 // the column tile.  WT = waves per side, FR = 16×16 MFMA tiles per wave side: <2,2> -> 64×64 tile (4 waves,
 // each 32×32); <2,1> -> 32×32 tile (4 waves, each one MFMA tile) for skinny products.
-template <int WT, int FR, int TK>
+template <int WT, int FR, int TK, bool BLK = false>
 __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const double* __restrict__ A, int lda,
                                                                    const double* __restrict__ B, int ldb,
                                                                    double* __restrict__ OUT, int ldo, int K, int nrows,
@@ -58,6 +71,8 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     const int b_k = t / B_TPR, b_c = (t % B_TPR) * PER;
     const double* b_src = B + (size_t)b_k * ldb + col0 + b_c;
 
+    // BLK: every 16×16×4 step is issued as four v_mfma_f64_4x4x4_f64 on four accumulators (operand pairing described at
+    // gemm_skinny_f64_kernel below) — same bits, higher issue rate than v_mfma_f64_16x16x4_f64 on gfx950.
     mfma_d4 acc[FR][FR];
 #pragma unroll
     for (int i = 0; i < FR; ++i)
@@ -86,32 +101,75 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 4) {
             const int kr = (kk + (lane >> 4)) * LS;
-            double a[FR], b[FR];
+            if constexpr (!BLK) {
+                double a[FR], b[FR];
 #pragma unroll
-            for (int i = 0; i < FR; ++i) {
-                a[i] = As[kr + wr * WS + 16 * i + (lane & 15)];
-                b[i] = Bs[kr + wc * WS + 16 * i + (lane & 15)];
+                for (int i = 0; i < FR; ++i) {
+                    a[i] = As[kr + wr * WS + 16 * i + (lane & 15)];
+                    b[i] = Bs[kr + wc * WS + 16 * i + (lane & 15)];
+                }
+#pragma unroll
+                for (int i = 0; i < FR; ++i)
+#pragma unroll
+                    for (int j = 0; j < FR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                // operands: u = 0 as read; A u = 1 holds row block b+2 (lanes rotated by 8 inside each row of 16),
+                // B v = 1 holds column block b+1 (rotated by 4): the pairs (b+2u, b+v) are the 16 blocks of the tile.
+                // One DPP rotation serves FR tiles, so it costs far less than a second LDS read.
+                double a[FR][2], b[FR][2];
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    a[i][0] = As[kr + wr * WS + 16 * i + (lane & 15)];
+                    b[i][0] = Bs[kr + wc * WS + 16 * i + (lane & 15)];
+                }
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    a[i][1] = gemm_dpp_f64<0x128>(a[i][0]);   // row_ror:8
+                    b[i][1] = gemm_dpp_f64<0x12C>(b[i][0]);   // row_ror:12: lane c reads lane (c + 4) & 15
+                }
+#pragma unroll
+                for (int i = 0; i < FR; ++i)
+#pragma unroll
+                    for (int j = 0; j < FR; ++j)
+#pragma unroll
+                        for (int uv = 0; uv < 4; ++uv)
+                            acc[i][j][uv] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][uv >> 1], b[j][uv & 1], acc[i][j][uv], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < FR; ++i)
-#pragma unroll
-                for (int j = 0; j < FR; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    if constexpr (!BLK) {
+        // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < FR; ++i)
+        for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lrow = row0 + wr * WS + i * 16 + (lane >> 4) + 4 * r;
-            if (lrow < count) {
-                const int grow = row_list ? row_list[lrow] : lrow;
-                double* o = OUT + (size_t)grow * ldo + col0 + wc * WS + (lane & 15);
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = row0 + wr * WS + i * 16 + (lane >> 4) + 4 * r;
+                if (lrow < count) {
+                    const int grow = row_list ? row_list[lrow] : lrow;
+                    double* o = OUT + (size_t)grow * ldo + col0 + wc * WS + (lane & 15);
 #pragma unroll
-                for (int j = 0; j < FR; ++j) o[16 * j] = acc[i][j][r];
+                    for (int j = 0; j < FR; ++j) o[16 * j] = acc[i][j][r];
+                }
             }
-        }
+    } else {
+        // acc[i][j][2u+v], lane 16 g + 4 bb + bj: row 4 ((bb+2u)&3) + g, column 4 ((bb+v)&3) + bj of the 16×16 tile (i, j)
+        const int g = lane >> 4, bb = (lane >> 2) & 3, bj = lane & 3;
+#pragma unroll
+        for (int i = 0; i < FR; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int lrow = row0 + wr * WS + i * 16 + 4 * ((bb + 2 * u) & 3) + g;
+                if (lrow < count) {
+                    const int grow = row_list ? row_list[lrow] : lrow;
+                    double* o = OUT + (size_t)grow * ldo + col0 + wc * WS + bj;
+#pragma unroll
+                    for (int j = 0; j < FR; ++j)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) o[16 * j + 4 * ((bb + v) & 3)] = acc[i][j][2 * u + v];
+                }
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -243,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_f64_kernel(const double* _
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
     dim3 grid(ld / 64, (nrows + 63) / 64);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
 }
 // General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16).  64×64 tiles (4 waves × 32×32)
 // when that grid fills the chip; otherwise 32×32 tiles worked by 4 waves of one 16×16 MFMA tile each, so a
@@ -253,7 +311,7 @@ inline void launch_gemm(const double* A, int lda, const double* B, int ldb, doub
     const long tiles64 = (long)((M + 63) / 64) * (N / 64);
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     } else if (K % SK_TK == 0 && K >= 64 * SK_TK) {
         const int ncol = N / 32, nrb = (M + 31) / 32;
         hipLaunchKernelGGL((gemm_skinny_f64_kernel<4>), dim3(8 * ncol * ((nrb + 7) / 8)), dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, N);
