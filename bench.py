@@ -228,6 +228,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank %= max(1, torch.cuda.device_count())     # a launcher that hides all but one GPU per rank leaves one device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
