@@ -221,11 +221,22 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     auto row_acc = [&](int idx) { const double* r = wsv(idx); return [r, lane](int k) { return r[lane + WAVE * k]; }; };
 
-    double q[NPL], p[NPL], g[NPL], ps[NPL], cf[NPL], cfs[NPL], cr[NPL];
-    ldv<NPL>(P.st.q + row, lane, q);
-    ldv<NPL>(P.st.g + row, lane, g);
+    // Only the leaf's (p, p♯) and the running summary (first, first♯, ρ) are held in registers: q and ∇ℓ of the
+    // point are never computed on here, only copied (proposal slots, parked edges, the draw) — streamed row to row
+    // so that the kernel fits two waves per SIMD without scratch.
+    double p[NPL], ps[NPL], cf[NPL], cfs[NPL], cr[NPL];
     ldv<NPL>(R.cp + row, lane, p);
     ldv<NPL>(R.cps + row, lane, ps);
+    auto copy_row = [&](const double* __restrict__ src, double* __restrict__ dst) {
+#pragma unroll
+        for (int k0 = 0; k0 < NPL; k0 += 4) {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4 && k0 + u < NPL; ++u) t[u] = src[lane + WAVE * (k0 + u)];
+#pragma unroll
+            for (int u = 0; u < 4 && k0 + u < NPL; ++u) dst[lane + WAVE * (k0 + u)] = t[u];
+        }
+    };
 
     auto randexp = [&]() -> double {   // Random.randexp at NUTS.jl:44: the nrand-th draw of this transition
         uint64_t r1, r2;
@@ -236,8 +247,8 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(S.free_mask);
         S.free_mask &= ~(1ull << s);
-        stv<NPL>(wsv(wd_slot(max_depth, s, 0)), lane, q);
-        if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(wd_slot(max_depth, s, 1)), lane, g);
+        copy_row(P.st.q + row, wsv(wd_slot(max_depth, s, 0)));
+        if constexpr (!T::kRecomputeGrad) copy_row(P.st.g + row, wsv(wd_slot(max_depth, s, 1)));
         S.sl_lq[s] = lq_leaf;
         S.sl_pi[s] = pi_leaf;
         return s;
@@ -377,20 +388,26 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
         double a = det_exp(S.vtop_lsa) / (double)S.vtop_steps;
         const double acc_rate = uni_f64(a < 1.0 ? a : 1.0);
         S.init_slot = S.zeta_top;
-        ldv<NPL>(wsv(wd_slot(max_depth, S.init_slot, 0)), lane, q);
-        if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-        else ldv<NPL>(wsv(wd_slot(max_depth, S.init_slot, 1)), lane, g);
         S.lq_cur = S.sl_lq[S.init_slot];
         const double pi_stat = S.sl_pi[S.init_slot];
-        stv<NPL>(P.st.q + row, lane, q);
-        stv<NPL>(P.st.g + row, lane, g);
         const size_t o = (size_t)chain * P.N + S.n;
-        if (P.out.draws) {
-            double* drow = P.out.draws + o * D;
+        {
+            double q[NPL];
+            ldv<NPL>(wsv(wd_slot(max_depth, S.init_slot, 0)), lane, q);
+            stv<NPL>(P.st.q + row, lane, q);
+            if (P.out.draws) {
+                double* drow = P.out.draws + o * D;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k)
-                if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
+                for (int k = 0; k < NPL; ++k)
+                    if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
+            }
+            if constexpr (T::kRecomputeGrad) {
+                double g[NPL];
+                (void)tgt.eval(q, g, lane, D);
+                stv<NPL>(P.st.g + row, lane, g);
+            }
         }
+        if constexpr (!T::kRecomputeGrad) copy_row(wsv(wd_slot(max_depth, S.init_slot, 1)), P.st.g + row);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = S.lq_cur;
             if (P.out.eps) P.out.eps[o] = eps_used;
@@ -436,18 +453,23 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
             S.dirs >>= 1;
             const int ndir = nfwd ? 1 : 0;
             if (S.reg_edge != ndir) {
-                stv<NPL>(wsv(wd_edge(S.reg_edge, 0)), lane, q);
-                if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(wd_edge(S.reg_edge, 1)), lane, g);
+                copy_row(P.st.q + row, wsv(wd_edge(S.reg_edge, 0)));
+                if constexpr (!T::kRecomputeGrad) copy_row(P.st.g + row, wsv(wd_edge(S.reg_edge, 1)));
                 if (S.reg_edge == 1) S.stored1 = 1; else S.stored0 = 1;
                 const bool have = nfwd ? (S.stored1 != 0) : (S.stored0 != 0);
                 const int qsrc = have ? wd_edge(ndir, 0) : wd_slot(max_depth, S.init_slot, 0);
                 const int gsrc = have ? wd_edge(ndir, 1) : wd_slot(max_depth, S.init_slot, 1);
-                ldv<NPL>(wsv(qsrc), lane, q);
-                if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-                else ldv<NPL>(wsv(gsrc), lane, g);
+                if constexpr (T::kRecomputeGrad) {
+                    double q[NPL], g[NPL];
+                    ldv<NPL>(wsv(qsrc), lane, q);
+                    (void)tgt.eval(q, g, lane, D);
+                    stv<NPL>(P.st.q + row, lane, q);
+                    stv<NPL>(P.st.g + row, lane, g);
+                } else {
+                    copy_row(wsv(qsrc), P.st.q + row);
+                    copy_row(wsv(gsrc), P.st.g + row);
+                }
                 ldv<NPL>(wsv(wd_top(nfwd ? 2 : 0)), lane, p);
-                stv<NPL>(P.st.q + row, lane, q);
-                stv<NPL>(P.st.g + row, lane, g);
             }
             S.reg_edge = ndir;
             S.dir = ndir;
@@ -461,8 +483,9 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
             S.j = j + 1;
         }
         const double h = eps_s / 2;
+        const double* __restrict__ grow = P.st.g + row;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];   // pₘ of the next leapfrog (hamiltonian.jl:277)
+        for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * grow[lane + WAVE * k];   // pₘ of the next leapfrog (hamiltonian.jl:277)
         stv<NPL>(R.cp + row, lane, p);
     }
     __syncthreads();
