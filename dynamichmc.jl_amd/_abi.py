@@ -68,6 +68,26 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If this library pulled in the
+    system copy first, a later `import torch` would bring a SECOND HIP runtime into the process, and that one sees
+    no GPUs.  Loading torch's copy first (when torch is installed; torch itself is not imported) makes both sides
+    resolve to one runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libdhmc_amd.so from the package tree.  Never falls back to anything else."""
     global _lib
@@ -76,6 +96,7 @@ def lib():
             raise LibraryMissing(
                 f"{LIB_PATH} not found: build it with `make -C dynamichmc.jl_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(L, s)

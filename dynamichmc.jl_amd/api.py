@@ -332,6 +332,8 @@ class SamplingLogDensity:
     algorithm: NUTS
     reporter: Any
     ctx: DeviceContext
+    on_device: bool = False      # results stay in HBM as torch CUDA tensors instead of numpy arrays
+    keep_warmup: bool = True     # False: warmup-stage draws are consumed on the device and never copied out
 
 
 def _as_rng(rng):
@@ -340,6 +342,42 @@ def _as_rng(rng):
     if isinstance(rng, (int, np.integer)):
         return PhiloxRNG(int(rng))
     raise TypeError("rng must be a PhiloxRNG or an integer seed")
+
+
+def _device_buffers(ctx, N):
+    """Output buffers for dhmc_run in HBM (torch is plumbing here: an allocator for device memory)."""
+    try:
+        import torch
+    except ImportError:
+        return None
+    if not torch.cuda.is_available():
+        return None
+    dev = torch.device("cuda", ctx.cfg.device)
+    tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32, np.uint32: torch.int32}
+    return {name: torch.empty((ctx.C, N, ctx.D) if name == "draws" else (ctx.C, N), dtype=tdt[dt], device=dev)
+            for name, dt in abi.OUTPUT_FIELDS}
+
+
+def _host(arrs):
+    out = {}
+    for k, v in arrs.items():
+        a = v.cpu().numpy() if hasattr(v, "is_cuda") else v
+        out[k] = a.view(np.uint32) if k == "directions" else a
+    return out
+
+
+def _run(slogd, N, da=None, keep=True):
+    """One dhmc_run of all chains.  The outputs are written to HBM and only come to the host when the caller keeps
+    them as numpy arrays (`keep` and not `on_device`); returns (arrays, draws usable for the metric update)."""
+    ctx = slogd.ctx
+    bufs = _device_buffers(ctx, N)
+    if bufs is None:
+        arrs = ctx.run(N, da=da)
+        return arrs, arrs["draws"]
+    ctx.run_into(N, bufs, da=da)
+    if not keep:
+        return None, bufs["draws"]
+    return (bufs if slogd.on_device else _host(bufs)), bufs["draws"]
 
 
 def _collect(arrs):
@@ -399,14 +437,17 @@ def warmup(slogd, stage, warmup_state):
         _argcheck(warmup_state.eps is not None, "ϵ > 0")       # stepsize.jl:135
         ad = stage.stepsize_adaptation
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
-        draws, ts, lds, epss = _collect(ctx.run(stage.N, da=da))
+        arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup)
         if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210),
-            ctx.update_metric_dense(draws, stage.lam)          # pooled over the context's chains (shared dense M⁻¹)
+            ctx.update_metric_dense(dev_draws, stage.lam)      # pooled over the context's chains (shared dense M⁻¹)
         elif stage.M == Diagonal:
-            ctx.update_metric_diag(draws, stage.lam)           # mcmc.jl:281-284
+            ctx.update_metric_diag(dev_draws, stage.lam)       # mcmc.jl:281-284, from the draws where they are (HBM)
             slogd.reporter.report("adaptation finished")
         st = _state(ctx)
         slogd.reporter.report("warmup stage finished", N=stage.N, eps=float(np.median(st.eps)))
+        if arrs is None:
+            return None, st
+        draws, ts, lds, epss = _collect(arrs)
         return dict(posterior_matrix=draws, tree_statistics=ts, eps=epss, logdensities=lds), st
     raise TypeError(f"unknown warmup stage {stage!r}")
 
@@ -422,14 +463,16 @@ def _warmup(slogd, stages, initial_warmup_state):             # mcmc.jl:450-457
 def mcmc(slogd, N, warmup_state):
     """mcmc.jl:366-381."""
     _argcheck(warmup_state.eps is not None, "ϵ > 0")
-    draws, ts, lds, _ = _collect(slogd.ctx.run(N))
+    arrs, _ = _run(slogd, N)
+    draws, ts, lds, _ = _collect(arrs)
     slogd.reporter.report("inference finished", N=N)
     return dict(posterior_matrix=draws, tree_statistics=ts, logdensities=lds)
 
 
 def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0):
-    """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU."""
+                     reporter=None, device=0, on_device=False, _keep_warmup=True):
+    """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU.  `on_device=True` returns the
+    posterior matrices and statistics as torch CUDA tensors (no PCIe copy of the draws)."""
     warmup_stages = default_warmup_stages() if warmup_stages is None else warmup_stages
     reporter = default_reporter() if reporter is None else reporter
     rng = _as_rng(rng)
@@ -441,7 +484,7 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
                         chain_offset=rng.chain_offset, device=device, metric=metric)
-    slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx)
+    slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx, on_device=on_device, keep_warmup=_keep_warmup)
     initial = initialize_warmup_state(slogd, **dict(initialization))
     wu, final = _warmup(slogd, warmup_stages, initial)
     inference = mcmc(slogd, N, final)
@@ -450,10 +493,11 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
 
 
 def mcmc_with_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0):
-    """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C]."""
+                     reporter=None, device=0, on_device=False):
+    """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C].
+    The warmup stages' draws never leave the GPU (the reference discards them too, mcmc.jl:579-583)."""
     r = mcmc_keep_warmup(rng, l, N, chains=chains, initialization=initialization, warmup_stages=warmup_stages,
-                         algorithm=algorithm, reporter=reporter, device=device)
+                         algorithm=algorithm, reporter=reporter, device=device, on_device=on_device, _keep_warmup=False)
     out = dict(r["inference"])
     out["kappa"] = r["final_warmup_state"].kappa
     out["eps"] = r["final_warmup_state"].eps

@@ -133,3 +133,22 @@ def test_full_size_properties(pkg):
     s = small.run(N, fields=["draws", "steps"])
     assert np.array_equal(s["draws"], q[100:164].cpu().numpy())
     assert np.array_equal(s["steps"], steps[100:164].cpu().numpy())
+
+
+def test_results_on_device_equal_host_results(pkg):
+    """on_device=True hands back torch CUDA tensors (no PCIe copy of the draws); same bits as the numpy path, and
+    the warmup stages — whose draws only feed the metric update — never leave the GPU either way."""
+    import torch
+    l = pkg.DiagNormal(np.linspace(-1, 1, 40), np.linspace(0.5, 3, 40))
+    a = pkg.mcmc_with_warmup(9, l, 150, chains=6, reporter=pkg.NoProgressReport())
+    b = pkg.mcmc_with_warmup(9, l, 150, chains=6, reporter=pkg.NoProgressReport(), on_device=True)
+    assert isinstance(a["posterior_matrix"], np.ndarray) and b["posterior_matrix"].is_cuda
+    assert np.array_equal(a["posterior_matrix"], b["posterior_matrix"].cpu().numpy())
+    assert np.array_equal(a["logdensities"], b["logdensities"].cpu().numpy())
+    for f in ("pi", "depth", "termination_left", "termination_right", "acceptance_rate", "steps"):
+        assert np.array_equal(getattr(a["tree_statistics"], f), getattr(b["tree_statistics"], f).cpu().numpy()), f
+    assert np.array_equal(a["tree_statistics"].directions, b["tree_statistics"].directions.cpu().numpy().view(np.uint32))
+    assert np.array_equal(a["eps"], b["eps"])
+    k = pkg.mcmc_keep_warmup(9, l, 150, chains=6, reporter=pkg.NoProgressReport())
+    assert np.array_equal(k["inference"]["posterior_matrix"], a["posterior_matrix"])
+    assert k["warmup"][2]["results"]["posterior_matrix"].shape == (6, 25, 40)      # first metric window kept on request
