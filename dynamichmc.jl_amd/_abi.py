@@ -59,7 +59,7 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_update_metric_dense", "dhmc_state_bytes",
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
            "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes",
-           "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios"]
+           "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat"]
 
 _lib = None
 

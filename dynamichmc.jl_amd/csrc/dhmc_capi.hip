@@ -15,6 +15,7 @@
 
 #include "../../include/dhmc.h"
 #include "dense_metric.hpp"
+#include "ess_kernels.hpp"
 #include "logistic_rounds.hpp"
 #include "metric_dense_adapt.hpp"
 #include "launch.hpp"
@@ -821,6 +822,32 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
     return probe_finish(c, dst, status);
+}
+
+int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat) {
+    if (!draws || !coords || !ess || !rhat || chains < 1 || n < 4 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
+    if (n > 8192) return DHMC_ERR_UNSUPPORTED;
+    for (int i = 0; i < ncoords; ++i)
+        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dc, da, dm, de, dr;
+    const size_t na = (size_t)ncoords * chains * n;
+    if (hipMalloc(&dc.p, sizeof(int32_t) * ncoords) != hipSuccess || hipMalloc(&da.p, sizeof(double) * na) != hipSuccess ||
+        hipMalloc(&dm.p, sizeof(double) * ncoords * chains) != hipSuccess || hipMalloc(&de.p, sizeof(double) * ncoords) != hipSuccess ||
+        hipMalloc(&dr.p, sizeof(double) * ncoords) != hipSuccess)
+        return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(dc.p, coords, sizeof(int32_t) * ncoords, hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
+    hipLaunchKernelGGL(ess_acov_kernel, dim3(ncoords, (unsigned)chains), dim3(ESS_THREADS), sizeof(double) * n, s, draws, n, dim,
+                       (const int32_t*)dc.p, chains, (double*)da.p, (double*)dm.p);
+    hipLaunchKernelGGL(ess_finish_kernel, dim3(ncoords), dim3(ESS_THREADS), sizeof(double) * n, s, (const double*)da.p,
+                       (const double*)dm.p, n, chains, (double*)de.p, (double*)dr.p);
+    if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(ess, de.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(rhat, dr.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
+    return DHMC_OK;
 }
 
 int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {

@@ -57,9 +57,29 @@ def ess_rhat(x):
 
 
 def ess_bulk_device(draws, coords=None):
-    """Bulk ESS per coordinate on the GPU for draws [C][N][D] held in a CUDA torch tensor (same estimator as
-    ess_rhat above: multi-chain autocorrelation by FFT, Geyer's initial monotone sequence), so ESS/s can be
-    reported without shipping the draws to the host.  Returns (ess [k], rhat [k])."""
+    """ESS and R-hat per coordinate for draws [C][N][D] held in HBM (a CUDA torch tensor), computed where they lie by
+    the library's HIP kernels (`dhmc_ess_rhat`, csrc/ess_kernels.hpp: the estimator of ess_rhat above), so ESS/s can
+    be reported without shipping the draws to the host.  Returns numpy arrays (ess [k], rhat [k])."""
+    import ctypes as C_
+    from . import _abi as abi
+    Cn, N, D = draws.shape
+    if not (draws.is_cuda and draws.is_contiguous() and str(draws.dtype) == "torch.float64"):
+        raise ValueError("draws must be a contiguous float64 CUDA tensor [C][N][D]")
+    idx = np.arange(D, dtype=np.int32) if coords is None else np.ascontiguousarray(
+        coords.cpu().numpy() if hasattr(coords, "cpu") else coords, np.int32)
+    ess = np.zeros(idx.size); rhat = np.zeros(idx.size)
+    import torch
+    rc = abi.lib().dhmc_ess_rhat(C_.c_int32(draws.device.index or 0), C_.c_void_p(torch.cuda.current_stream(draws.device).cuda_stream),
+                                 C_.c_void_p(draws.data_ptr()), C_.c_int64(Cn), C_.c_int64(N), C_.c_int64(D),
+                                 C_.c_void_p(idx.ctypes.data), C_.c_int32(idx.size), C_.c_void_p(ess.ctypes.data),
+                                 C_.c_void_p(rhat.ctypes.data))
+    if rc != abi.OK:
+        raise RuntimeError(f"dhmc_ess_rhat: {abi.ERROR_NAMES.get(rc, rc)}")
+    return ess, rhat
+
+
+def ess_bulk_torch(draws, coords=None):
+    """The same estimator with torch FFTs — an independent cross-check of the HIP kernels (tests only)."""
     import torch
     C, N, D = draws.shape
     idx = torch.arange(D, device=draws.device) if coords is None else torch.as_tensor(coords, device=draws.device)

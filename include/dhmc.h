@@ -213,6 +213,15 @@ int dhmc_leapfrog_trajectory(dhmc_ctx* ctx, double eps, int32_t first, int32_t l
 int dhmc_explore_log_acceptance_ratios(dhmc_ctx* ctx, const double* eps, int32_t n_eps, int32_t n_momenta,
                                        uint32_t momentum_index, const double* ps, double* out, uint32_t* status);
 
+/* ---- posterior diagnostics on the device: effective sample size and R-hat of `ncoords`
+ *      coordinates of draws [chains][n][dim] held in HBM (e.g. dhmc_outputs.draws with on_device = 1), so ESS/s can
+ *      be reported without moving the draws.  Estimator: multi-chain autocorrelation with Geyer's initial monotone
+ *      positive sequence (what the reference's tests obtain from MCMCDiagnosticTools.ess_rhat,
+ *      test/sample-correctness_utilities.jl:40-43; that package is not vendored, parity unpinned).  coords, ess,
+ *      rhat are HOST arrays; stream may be NULL; n <= 8192 in this build, n >= 4. ---------------------------- */
+int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
+
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);
 int dhmc_export_state(dhmc_ctx* ctx, void* host_blob, uint64_t nbytes);

@@ -129,3 +129,27 @@ def test_reference_leapfrog_trajectory(pkg):   # test_diagnostics.jl:51-76
     assert all(np.allclose(t["z"]["q"], z[0]) and np.allclose(t["z"]["p"], z[1]) for t, z in zip(traj, zs))
     with pytest.raises(ValueError):
         pkg.diagnostics.leapfrog_trajectory(l, np.zeros(K), eps, range(1, 4))
+
+
+def test_ess_rhat_kernels_match_host_estimator(pkg):
+    """dhmc_ess_rhat (HIP, draws where they lie in HBM) against diagnostics.ess_rhat (numpy FFT) and the torch flavour."""
+    import torch
+    rng = np.random.default_rng(11)
+    for C, N, D, phi in ((6, 500, 5, 0.6), (64, 100, 40, 0.0), (1, 1001, 3, 0.9), (3, 37, 2, -0.4)):
+        e = rng.normal(size=(C, N, D))
+        x = np.zeros_like(e)
+        x[:, 0] = e[:, 0]
+        for n in range(1, N):
+            x[:, n] = phi * x[:, n - 1] + e[:, n]          # AR(1): ESS well below / above C·N
+        x += rng.normal(size=(C, 1, D)) * 0.05              # slightly different chain means: R-hat > 1
+        coords = np.arange(D, dtype=np.int32)[:: max(1, D // 7)]
+        t = torch.from_numpy(x).cuda()
+        ess, rhat = pkg.diagnostics.ess_bulk_device(t, coords)
+        e2, r2 = pkg.diagnostics.ess_bulk_torch(t, torch.from_numpy(coords).long().cuda())
+        for k, j in enumerate(coords):
+            eh, rh = pkg.diagnostics.ess_rhat(x[:, :, j])
+            assert np.isclose(ess[k], eh, rtol=1e-9), (C, N, j, ess[k], eh)
+            assert np.isclose(rhat[k], rh, rtol=1e-12)
+        assert np.allclose(ess, e2.cpu().numpy(), rtol=1e-9) and np.allclose(rhat, r2.cpu().numpy(), rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"))   # n < 4

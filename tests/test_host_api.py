@@ -109,7 +109,7 @@ def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8,
     ess, rhat = pkg.diagnostics.ess_rhat(x)
     assert 6000 < ess < 10000 and abs(rhat - 1) < 0.01
     import torch
-    e2, r2 = pkg.diagnostics.ess_bulk_device(torch.from_numpy(x)[:, :, None])     # same estimator, torch flavour
+    e2, r2 = pkg.diagnostics.ess_bulk_torch(torch.from_numpy(x)[:, :, None])      # same estimator, torch flavour
     assert abs(float(e2[0]) - ess) / ess < 1e-6 and abs(float(r2[0]) - rhat) < 1e-9
 
 
