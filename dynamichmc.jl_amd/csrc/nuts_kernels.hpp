@@ -95,8 +95,14 @@ __host__ __device__ inline int ws_nvec(int max_depth) { return 8 + 3 * max_depth
 // per-level and per-slot scalars.
 constexpr int LDS_LEVELS = 32;
 constexpr int LDS_SLOTS = 36;
-__host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds) {
-    return sizeof(double) * ((size_t)Dpad * (l1_in_lds ? 4 : 2) + 3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
+// Short chains keep MORE of the suspended stack in LDS: levels 2 .. 1+lds_extra_levels(NPL) (first, last, ρ: 3 rows
+// each), ≈11-14 KB per wave in all.  A level that lives in the HBM workspace costs an exposed L2/HBM round trip
+// (≈2 µs, more than a whole small-D leapfrog) every time a subtree of that size is merged — 1/8 of all leaves for
+// levels ≥ 3 — and a wave-per-chain kernel on a short chain has nothing else to hide it behind.
+__host__ __device__ constexpr int lds_extra_levels(int NPL) { return NPL == 1 ? 6 : NPL == 2 ? 3 : NPL == 4 ? 1 : 0; }
+__host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds, int extra_levels) {
+    return sizeof(double) * ((size_t)Dpad * ((l1_in_lds ? 4 : 2) + 3 * extra_levels) + 3 * LDS_LEVELS + 2 * LDS_SLOTS) +
+           sizeof(int) * LDS_LEVELS;
 }
 
 __device__ __forceinline__ double joint_logdensity(double lq, double K) {  // hamiltonian.jl:251-256
@@ -271,7 +277,9 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     double* l0_lds = lds + Dpad;                           // [Dpad]   level-0 suspended momentum
     double* l1f_lds = lds + 2 * Dpad;                      // [Dpad]   level-1 first   (L1LDS only)
     double* l1l_lds = lds + 3 * Dpad;                      // [Dpad]   level-1 last    (L1LDS only)
-    double* lv_omega = lds + (L1LDS ? 4 : 2) * Dpad;       // [LDS_LEVELS]
+    constexpr int NXL = L1LDS ? lds_extra_levels(NPL) : 0; // levels 2 .. 1+NXL in LDS too (short chains)
+    double* xl_lds = lds + 4 * Dpad;                       // [NXL][3][Dpad]  first, last, ρ
+    double* lv_omega = lds + ((L1LDS ? 4 : 2) + 3 * NXL) * Dpad;   // [LDS_LEVELS]
     double* lv_vlsa = lv_omega + LDS_LEVELS;
     double* lv_vsteps = lv_vlsa + LDS_LEVELS;
     double* sl_lq = lv_vsteps + LDS_LEVELS;                // [LDS_SLOTS]
@@ -295,10 +303,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
     double tpm[NPL], tpp[NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
-    // the level-2 suspended summary (first, last, ρ) also stays in registers when vectors are short enough
-    // (from NPL = 4 up the three extra vectors would spill; there level 2 goes to the HBM workspace)
-    constexpr bool kL2Reg = NPL <= 2;
-    double l2f[kL2Reg ? NPL : 1], l2l[kL2Reg ? NPL : 1], l2r[kL2Reg ? NPL : 1];
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(P.st.g + row, lane, g);
     double lq_cur = P.st.lq[chain];
@@ -461,10 +465,13 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
                                 turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
                                               : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
-                            } else if (kL2Reg && level == 2) {
-                                auto a_lf = [&](int k) { return l2f[kL2Reg ? k : 0]; };
-                                auto a_ll = [&](int k) { return l2l[kL2Reg ? k : 0]; };
-                                auto a_lr = [&](int k) { return l2r[kL2Reg ? k : 0]; };
+                            } else if (NXL > 0 && level < 2 + NXL) {
+                                const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
+                                const double* Ll = Lf + Dpad;
+                                const double* Lr = Ll + Dpad;
+                                auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
                                 turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
                                               : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
                             } else {
@@ -554,9 +561,11 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         } else if (L1LDS && level == 1) {
                             stv<NPL>(l1f_lds, lane, cf);
                             stv<NPL>(l1l_lds, lane, p);
-                        } else if (kL2Reg && level == 2) {
-#pragma unroll
-                            for (int k = 0; k < (kL2Reg ? NPL : 0); ++k) { l2f[k] = cf[k]; l2l[k] = p[k]; l2r[k] = cr[k]; }
+                        } else if (NXL > 0 && level < 2 + NXL) {
+                            double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
+                            stv<NPL>(Lf, lane, cf);
+                            stv<NPL>(Lf + Dpad, lane, p);
+                            stv<NPL>(Lf + 2 * Dpad, lane, cr);
                         } else {
                             stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
                             stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
