@@ -137,7 +137,10 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
     const double h = eps / 2;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
-        double pm = p[k] + h * g[k];                 // :277
+        double gk;
+        if constexpr (T::kPointwiseGrad) gk = tgt.grad1(q[k], lane + WAVE * k);   // ∇ℓq recomputed, not carried
+        else gk = g[k];
+        double pm = p[k] + h * gk;                   // :277
         double t = m_lds[lane + WAVE * k] * pm;      // ∇kinetic_energy(κ, pₘ) = M⁻¹ pₘ
         q[k] = q[k] + eps * t;                       // :278
         p[k] = pm;
@@ -410,7 +413,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 const int qsrc = have ? ws_edge(dir, 0) : ws_slot(max_depth, init_slot, 0);
                 const int gsrc = have ? ws_edge(dir, 2) : ws_slot(max_depth, init_slot, 1);
                 ldv<NPL>(wsv(qsrc), lane, q);
-                if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+                if constexpr (T::kPointwiseGrad) {}
+                else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
                 else ldv<NPL>(wsv(gsrc), lane, g);
                 if (fwd) {
 #pragma unroll
@@ -600,7 +604,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         }();
         init_slot = zeta_top;
         ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
-        if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+        if constexpr (T::kPointwiseGrad) {}
+        else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
         else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
         lq_cur = uni_f64(sl_lq[init_slot]);
         const double pi_stat = uni_f64(sl_pi[init_slot]);
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 
     // ---- write the chain back (WarmupState + adaptation state) --------------------------
     stv<NPL>(P.st.q + row, lane, q);
+    if constexpr (T::kPointwiseGrad) (void)tgt.eval(q, g, lane, D);
     stv<NPL>(P.st.g + row, lane, g);
     if (lane == 0) {
         P.st.lq[chain] = lq_cur;

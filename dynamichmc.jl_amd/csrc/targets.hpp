@@ -11,6 +11,9 @@
 //                                calls finish()), or ℓ itself (kDeferred = false).
 //   kRecomputeGrad               ∇ℓ is cheap enough that a stored proposal keeps only q and the
 //                                gradient is re-evaluated when the proposal becomes the chain's position.
+//   kPointwiseGrad               element e of ∇ℓ is a function of q_e alone at no memory cost (grad1): the kernels then
+//                                never keep ∇ℓ of the current point alive between leapfrogs — one D-vector less in
+//                                registers — and recompute it in the first half step.  Same bits as eval's g.
 //   kFiniteLqImpliesFiniteQ      a finite ℓq is only possible at a finite position, so the position scan
 //                                of evaluate_ℓ (src/hamiltonian.jl:203) is needed only when ℓq is not finite.
 //   kFiniteLqImpliesFiniteGrad   a finite ℓq implies a finite gradient, so the ∇ℓ scan of evaluate_ℓ
@@ -35,6 +38,7 @@ struct TargetParams {
 struct StdNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kPointwiseGrad = true;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit StdNormalT(const TargetParams&) {}
@@ -48,12 +52,14 @@ struct StdNormalT {
         }
         return acc;
     }
+    __device__ __forceinline__ double grad1(double qk, int) const { return -qk; }   // element e of ∇ℓ from q_e alone
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
 };
 
 struct DiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* mu;
@@ -78,6 +84,7 @@ struct DiagNormalT {
 struct TridiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* diag;
@@ -113,6 +120,7 @@ struct TridiagNormalT {
 struct DenseNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* mu;
@@ -141,6 +149,7 @@ struct DenseNormalT {
 struct FunnelT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |e^{-v} q_i| <= max(e^{-v}, e^{-v} q_i^2)
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit FunnelT(const TargetParams&) {}
@@ -175,6 +184,7 @@ struct FunnelT {
 struct LogisticT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |y - σ| <= 1, β finite when β·β is
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = false;              // the gradient is the expensive part: keep it with proposals
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* X;
@@ -231,6 +241,7 @@ struct LogisticT {
 struct AlwaysDivergentT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    static constexpr bool kPointwiseGrad = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit AlwaysDivergentT(const TargetParams&) {}
