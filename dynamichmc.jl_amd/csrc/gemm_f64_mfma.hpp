@@ -297,6 +297,167 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_f64_kernel(const double* _
     }
 }
 
+// Producer/consumer form of the same kernel: 512 threads = per SIMD one CONSUMER wave (LDS fragment reads + the
+// four MFMA chains of its 16×16 tile, nothing else in its instruction stream) and one PRODUCER wave (the global
+// loads, the register ring and the LDS tile writes).  One s_barrier per 64-k step hands tile t+1 over while tile t
+// is being multiplied, so the load/transposition phase of the single-role kernel no longer sits in front of every
+// MFMA phase.  Same tiles, same LDS layout, same bits.
+typedef double gemm_d2 __attribute__((ext_vector_type(2)));
+constexpr int PC_TK = 32;      // k per step of the producer/consumer kernel
+
+template <int P>
+__global__ __launch_bounds__(512, 1) void gemm_skinny_pc_f64_kernel(const double* __restrict__ A, int lda,
+                                                                    const double* __restrict__ B, int ldb,
+                                                                    double* __restrict__ OUT, int ldo, int K, int M, int N) {
+    const int ncol = N / 32, nrb = (M + 31) / 32;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rb = xcd + 8 * (j / ncol), cb = j % ncol;
+    if (rb >= nrb) return;
+    const int row0 = rb * 32, col0 = cb * 32;
+    const int nt = K / PC_TK;
+    // LDS tiles hold PAIRS (k, k+4): entry kp = 4 h + kk (h = pair of MFMA steps 2h, 2h+1; kk = k & 3) carries the
+    // operands of both steps of one lane, so a fragment read is one ds_read_b128.  Three buffers: tile t is being
+    // multiplied from registers, t+1 is being read into the other register set, t+2 is being written.
+    __shared__ gemm_d2 As[3][16 * 32];   // As[buf][kp][row ^ 2 h]
+    __shared__ gemm_d2 Bs[3][16 * 32];   // Bs[buf][kp][col ^ 2 kk]
+
+    if (threadIdx.x >= 256) {
+        // ---------------- producer ----------------
+        const int t = threadIdx.x - 256;
+        // A: row a_row; group of 8 k's a_h (= step pair), elements m = 2 a_m, 2 a_m + 1 and their partners m + 4
+        const int a_row = t >> 3, a_h = (t >> 1) & 3, a_m = t & 1;
+        int a_grow = row0 + a_row;
+        a_grow = a_grow < M ? a_grow : M - 1;
+        const double* a_src = A + (size_t)a_grow * lda + 8 * a_h + 2 * a_m;
+        const int a_dst = (4 * a_h + 2 * a_m) * 32 + (a_row ^ (2 * a_h));
+        // B: pair entry b_kp (rows k and k+4, k = 8 (b_kp >> 2) + (b_kp & 3)), the 2 consecutive columns from 2 b_c
+        const int b_kp = t >> 4, b_c = t & 15;
+        const int b_k = 8 * (b_kp >> 2) + (b_kp & 3);
+        const double* b_src = B + (size_t)b_k * ldb + col0 + 2 * b_c;
+        const int b_dst = b_kp * 32, b_x = 2 * (b_kp & 3);
+        double av[P][4], bv[P][4];
+        auto issue = [&](int tile, double (&a)[4], double (&b)[4]) {
+            const int tt = tile < nt ? tile : nt - 1;
+            const double* ap = a_src + (size_t)tt * PC_TK;
+            const double* bp = b_src + (size_t)tt * PC_TK * ldb;
+            a[0] = ap[0]; a[1] = ap[1]; a[2] = ap[4]; a[3] = ap[5];
+            b[0] = bp[0]; b[1] = bp[1]; b[2] = bp[(size_t)4 * ldb]; b[3] = bp[(size_t)4 * ldb + 1];
+        };
+        auto stage = [&](int buf, const double (&a)[4], const double (&b)[4]) {
+            gemm_d2* as = As[buf];
+            gemm_d2* bs = Bs[buf];
+            as[a_dst] = gemm_d2{a[0], a[2]};
+            as[a_dst + 32] = gemm_d2{a[1], a[3]};
+            bs[b_dst + ((2 * b_c) ^ b_x)] = gemm_d2{b[0], b[2]};
+            bs[b_dst + ((2 * b_c + 1) ^ b_x)] = gemm_d2{b[1], b[3]};
+        };
+        // tiles 0 .. P-1 requested; barrier k is passed once tile k is staged (k < nt), plus the closing barrier nt
+#pragma unroll
+        for (int s = 0; s < P; ++s) issue(s, av[s], bv[s]);
+        int buf = 0;
+        const int nfull = nt - nt % P;
+        for (int t0 = 0; t0 < nfull; t0 += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                stage(buf, av[s], bv[s]);
+                buf = buf == 2 ? 0 : buf + 1;
+#ifndef DHMC_SK_NO_LOADS
+                issue(t0 + s + P, av[s], bv[s]);
+#endif
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (nfull + s < nt) {                            // uniform
+                stage(buf, av[s], bv[s]);
+                buf = buf == 2 ? 0 : buf + 1;
+                __syncthreads();
+            }
+        __syncthreads();                                     // closing barrier nt
+        return;
+    }
+    // ---------------- consumer ----------------
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int a_rd = kk * 32 + 16 * wr + r16;               // + 128 per step pair h, row swizzle 2 h applied there
+    const int b_rd = kk * 32 + ((16 * wc + r16) ^ (2 * kk));
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    gemm_d2 fa[2][2][4], fb[2][2][4];                        // [register set][variant][step pair]
+    auto fetch = [&](int buf, gemm_d2 (&af)[2][4], gemm_d2 (&bf)[2][4], int h0, int h1) {
+        const gemm_d2* as = As[buf];
+        const gemm_d2* bs = Bs[buf];
+#pragma unroll
+        for (int h = h0; h < h1; ++h) {
+            af[0][h] = as[(a_rd + 128 * h) ^ (2 * h)];
+            af[1][h] = as[(a_rd + 128 * h) ^ (2 * h) ^ 4];
+            bf[0][h] = bs[128 * h + b_rd];
+            bf[1][h] = bs[128 * h + (b_rd ^ 8)];
+        }
+    };
+    auto mult = [&](const gemm_d2 (&af)[2][4], const gemm_d2 (&bf)[2][4], int h0, int h1) {
+#ifdef DHMC_SK_NO_MFMA
+        for (int h = h0; h < h1; ++h) acc[h & 3] += af[0][h][0] * bf[0][h][1] + af[1][h][1] * bf[1][h][0];
+        return;
+#endif
+#pragma unroll
+        for (int h = h0; h < h1; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[0][h][e], bf[0][h][e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[0][h][e], bf[1][h][e], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[1][h][e], bf[0][h][e], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[1][h][e], bf[1][h][e], acc[3], 0, 0, 0);
+            }
+    };
+    // one tile: multiply the fragments read during the previous tile while reading the next tile's, in two halves of
+    // 8 reads (never more than 15 LDS reads outstanding: the lgkmcnt counter has 4 bits, and waiting for "the old
+    // reads" must not mean waiting for new ones)
+    auto tile_step = [&](int nbuf, bool more, gemm_d2 (&caf)[2][4], gemm_d2 (&cbf)[2][4], gemm_d2 (&naf)[2][4], gemm_d2 (&nbf)[2][4]) {
+        if (more) fetch(nbuf, naf, nbf, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(caf, cbf, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) fetch(nbuf, naf, nbf, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(caf, cbf, 2, 4);
+    };
+    // The consumer's barriers are bare s_barrier's: it never writes LDS, and its own outstanding fragment reads need
+    // not drain there (a __syncthreads would wait for them and serialise the read-ahead with the MFMAs).  The
+    // compiler-level fences keep the reads of a tile behind the barrier that publishes it, and the phases in order.
+    auto handover = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    handover();                                              // barrier 0: tile 0 staged
+    fetch(0, fa[0], fb[0], 0, 4);
+    int buf = 1;
+    int tile = 0;
+    for (; tile + 1 < nt; tile += 2) {
+        handover();                                          // barrier tile+1: the next tile is staged
+        tile_step(buf, true, fa[0], fb[0], fa[1], fb[1]);
+        buf = buf == 2 ? 0 : buf + 1;
+        handover();
+        tile_step(buf, tile + 2 < nt, fa[1], fb[1], fa[0], fb[0]);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (tile < nt) {                                         // odd tile count: the last tile is in set 0
+        handover();
+        tile_step(buf, false, fa[0], fb[0], fa[1], fb[1]);
+    }
+    const int bb = (lane >> 2) & 3, bj = lane & 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int grow = row0 + 16 * wr + 4 * (bb ^ u) + kk;
+        if (grow < M) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) OUT[(size_t)grow * ldo + col0 + 16 * wc + 4 * (bb ^ (2 * v)) + bj] = acc[2 * u + v];
+        }
+    }
+}
+
 // host launchers.  Square metric products: OUT rows <- A rows · B with K = N = ld = Dpad.
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
@@ -312,9 +473,13 @@ inline void launch_gemm(const double* A, int lda, const double* B, int ldb, doub
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
         hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
-    } else if (K % SK_TK == 0 && K >= 64 * SK_TK) {
+    } else if (K % SK_TK == 0 && K >= 64 * SK_TK) {   // (SK_TK is a multiple of PC_TK)
         const int ncol = N / 32, nrb = (M + 31) / 32;
+#ifdef DHMC_SK_SINGLE_ROLE
         hipLaunchKernelGGL((gemm_skinny_f64_kernel<4>), dim3(8 * ncol * ((nrb + 7) / 8)), dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, N);
+#else
+        hipLaunchKernelGGL((gemm_skinny_pc_f64_kernel<8>), dim3(8 * ncol * ((nrb + 7) / 8)), dim3(512), 0, s, A, lda, B, ldb, OUT, ldo, K, M, N);
+#endif
     } else {
         dim3 grid(N / 32, (M + 31) / 32);
         hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 1, 64>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
