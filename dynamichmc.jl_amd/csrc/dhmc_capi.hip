@@ -36,6 +36,7 @@ struct dhmc_ctx {
     double last_ms = 0.0;
     unsigned long long last_leapfrogs = 0;
     int l1_in_lds = 1;
+    int k3_block = 1;
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
@@ -251,6 +252,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->dense_rounds = many_chains;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
+    if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
     const size_t C = cfg->chains, Dp = c->Dpad;
@@ -556,6 +558,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.max_depth = c->cfg.max_depth; P.nvec = c->nvec; P.min_delta = c->cfg.min_delta; P.seed = c->cfg.seed;
     P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
     P.l1_in_lds = c->l1_in_lds;
+    P.k3_block = c->k3_block;
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;

@@ -1,6 +1,7 @@
 // Definitions behind launch.hpp: included only by family.hip, which instantiates dispatch_family<T> for ONE
 // target family per translation unit.
 #pragma once
+#include "dense_rounds_k3b.hpp"
 #include "launch.hpp"
 
 namespace dhmc {
@@ -43,7 +44,16 @@ void launch_round_op(int which, const RoundArgs& a, hipStream_t s) {
     case 0: hipLaunchKernelGGL((rounds_start_kernel<NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     case 1: hipLaunchKernelGGL((rounds_k0_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     case 2: hipLaunchKernelGGL((rounds_k2_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
-    default: hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
+    default:
+        // chains of 512+ coordinates: a workgroup (4 waves) per chain; DHMC_K3_BLOCK=0 (read at dhmc_create) keeps the one-wave kernel
+        if constexpr (NPL >= 8) {
+            if (a.P.k3_block) {
+                hipLaunchKernelGGL((rounds_k3b_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE * K3B_WPC), 0, s, a.P, a.R);
+                break;
+            }
+        }
+        hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R);
+        break;
     }
 }
 

@@ -75,3 +75,21 @@ def test_logistic_round_engine_equals_functor_kernel(pkg, N, D, C):
         return {**{"w_" + k: v for k, v in a.items()}, **ctx.run(12)}
     make = lambda: pkg.DeviceContext(D, C, target=ol.TARGET_LOGISTIC, target_params=params, seed=2)
     _same(_run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "0"}, make, steps))
+
+
+@pytest.mark.parametrize("D", [500, 1000])
+def test_block_per_chain_k3_equals_wave_per_chain_k3(pkg, D):
+    """Round engines, chains of 512+ coordinates: K3 as a 4-wave workgroup per chain (dots chained from wave to wave
+    in the ABI's order) against the one-wave-per-chain K3 (DHMC_K3_BLOCK=0)."""
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(D, 40))
+    S = A @ A.T / 40 + np.eye(D)
+    params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
+
+    def steps(ctx):
+        ctx.set_metric_dense(S); ctx.init(); ctx.find_initial_stepsize()
+        a = ctx.run(12, da={})
+        return {**{"w_" + k: v for k, v in a.items()}, **ctx.run(8)}
+    make = lambda: pkg.DeviceContext(D, 24, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, metric=ol.METRIC_DENSE, seed=5)
+    env = {"DHMC_DENSE_ROUNDS": "1"}
+    _same(_run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "1"}, make, steps), _run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "0"}, make, steps))
