@@ -11,14 +11,15 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DHMC_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libdhmc_amd.so")   # override: A/B builds only
 
-OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE = range(6)
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE, ERR_CALLBACK = range(7)
 ST_NONFINITE_POSITION, ST_INVALID_INITIAL, ST_STEPSIZE_SEARCH_FAILED, ST_NONFINITE_START_DENSITY = 1, 2, 4, 8
-TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT, TARGET_DENSE_NORMAL = range(7)
+TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT, TARGET_DENSE_NORMAL, TARGET_EXTERNAL = range(8)
 METRIC_DIAG, METRIC_DENSE = 0, 1
 
 ERROR_NAMES = {ERR_INVALID_ARGUMENT: "invalid argument", ERR_HIP: "HIP runtime error",
                ERR_UNSUPPORTED: "unsupported configuration", ERR_CHAIN_FAILURE: "chain failure",
-               ERR_NO_DEVICE: "no HIP device (there is no CPU fallback)"}
+               ERR_NO_DEVICE: "no HIP device (there is no CPU fallback)",
+               ERR_CALLBACK: "the external log-density callback is missing or failed"}
 
 
 class Config(C.Structure):
@@ -47,6 +48,9 @@ class Outputs(C.Structure):
                 ("term_right", C.c_void_p), ("depth", C.c_void_p), ("directions", C.c_void_p)]
 
 
+# int fn(void* user, const double* q, int64 chains, int64 ld, int64 dim, double* lq, double* grad, void* stream)
+LOGDENSITY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
+
 OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np.float64),
                  ("pi", np.float64), ("acceptance_rate", np.float64), ("steps", np.int64),
                  ("term_left", np.int64), ("term_right", np.int64), ("depth", np.int32),
@@ -59,7 +63,8 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_update_metric_dense", "dhmc_state_bytes",
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
            "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes",
-           "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat"]
+           "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
+           "dhmc_set_logdensity_callback"]
 
 _lib = None
 

@@ -25,7 +25,7 @@ __all__ = [
     "default_warmup_stages", "fixed_stepsize_warmup_stages", "GaussianKineticEnergy",
     "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
-    "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent",
+    "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent", "TorchLogDensity",
     "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
     "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
 ]
@@ -279,6 +279,33 @@ class LogisticRegression(_Target):
         return np.concatenate([np.array([self.X.shape[0]], np.int64).view(np.float64), self.X.ravel(), self.y])
 
 
+class TorchLogDensity(_Target):
+    """The user's own model (the reference accepts any LogDensityProblems object, hamiltonian.jl:146-147,204): a batched
+    PyTorch function evaluated on the GPU for all chains at once, once per leapfrog round.  Either
+    `logdensity_and_gradient(q) -> (lq [C], grad [C][D])`, or just `logdensity(q) -> lq [C]` (any differentiable torch
+    code; the gradient then comes from autograd).  q is a float64 CUDA tensor [C][D].  Diagonal metric."""
+    family = abi.TARGET_EXTERNAL
+
+    def __init__(self, dimension, logdensity=None, logdensity_and_gradient=None):
+        _argcheck((logdensity is None) != (logdensity_and_gradient is None), "give logdensity or logdensity_and_gradient")
+        self.D = int(dimension)
+        self._f, self._fg = logdensity, logdensity_and_gradient
+
+    def callback(self):
+        if self._fg is not None:
+            return self._fg
+        import torch
+        f = self._f
+
+        def fg(q):
+            with torch.enable_grad():
+                x = q.detach().clone().requires_grad_(True)
+                lq = f(x)
+                (g,) = torch.autograd.grad(lq.sum(), x)
+            return lq.detach(), g
+        return fg
+
+
 class AlwaysDivergent(_Target):
     """The reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)."""
     family = abi.TARGET_ALWAYS_DIVERGENT
@@ -484,6 +511,8 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
                         chain_offset=rng.chain_offset, device=device, metric=metric)
+    if l.family == abi.TARGET_EXTERNAL:
+        ctx.set_logdensity_callback(l.callback())
     slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx, on_device=on_device, keep_warmup=_keep_warmup)
     initial = initialize_warmup_state(slogd, **dict(initialization))
     wu, final = _warmup(slogd, warmup_stages, initial)

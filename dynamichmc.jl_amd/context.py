@@ -78,6 +78,9 @@ class DeviceContext:
             bits = int(np.bitwise_or.reduce(st[bad]))
             msg = next(m for b, m in STATUS_MESSAGES if bits & b)
             raise DynamicHMCError(msg, chains=bad[:16].tolist(), n_failed=int(bad.size), status=st[bad[:16]].tolist())
+        if rc == abi.ERR_CALLBACK and getattr(self, "_cb_error", None) is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err                                # the exception the user's log density raised
         detail = abi.lib().dhmc_last_error(self.h).decode() if self.h else ""
         raise RuntimeError(f"{what}: {abi.ERROR_NAMES.get(rc, rc)} {detail}")
 
@@ -194,6 +197,37 @@ class DeviceContext:
             draws = np.ascontiguousarray(draws, np.float64)
         self._chk(abi.lib().dhmc_update_metric_dense(self.h, _ptr(draws), C.c_int64(draws.shape[1]), C.c_double(lam), int(_is_device(draws))),
                   "dhmc_update_metric_dense")
+
+    # ---- DHMC_TARGET_EXTERNAL: the user's own batched log density --------------------------------
+    def set_logdensity_callback(self, fn):
+        """`fn(q) -> (lq, grad)` with q a CUDA torch tensor [C][D] (a view of the library's buffer: do not keep it),
+        lq [C], grad [C][D]: the LogDensityProblems.logdensity_and_gradient of all chains at once (hamiltonian.jl:204).
+        Called once per leapfrog round on the context's stream."""
+        import contextlib
+        import torch
+
+        class _Dev:     # a raw device pointer as a zero-copy torch tensor
+            def __init__(s, ptr, shape, strides):
+                s.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(int(ptr), False), version=2, strides=strides)
+        dev = torch.device("cuda", self.cfg.device)
+        self._cb_error = None
+
+        def trampoline(user, q_ptr, chains, ld, dim, lq_ptr, grad_ptr, stream):
+            try:
+                ctxm = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)) if stream else contextlib.nullcontext()
+                with ctxm:
+                    q = torch.as_tensor(_Dev(q_ptr, (chains, ld), (ld * 8, 8)), device=dev)[:, :dim]
+                    lq_out = torch.as_tensor(_Dev(lq_ptr, (chains,), (8,)), device=dev)
+                    g_out = torch.as_tensor(_Dev(grad_ptr, (chains, ld), (ld * 8, 8)), device=dev)
+                    lq, g = fn(q)
+                    lq_out.copy_(lq.to(torch.float64))
+                    g_out[:, :dim].copy_(g.to(torch.float64))
+                return 0
+            except Exception as e:          # no exception may cross the C ABI
+                self._cb_error = e
+                return 1
+        self._cb = abi.LOGDENSITY_FN(trampoline)      # keep the ctypes thunk alive as long as the context
+        self._chk(abi.lib().dhmc_set_logdensity_callback(self.h, self._cb, None), "dhmc_set_logdensity_callback")
 
     # ---- Diagnostics probes (src/diagnostics.jl) ---------------------------------------------
     def _probe_chk(self, rc, what, status, allow_failure):

@@ -15,6 +15,7 @@
 
 #include "../../include/dhmc.h"
 #include "dense_metric.hpp"
+#include "external_rounds.hpp"
 #include "ess_kernels.hpp"
 #include "logistic_rounds.hpp"
 #include "metric_dense_adapt.hpp"
@@ -47,6 +48,10 @@ struct dhmc_ctx {
     int dense_rounds = 1;
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     LogisticRound lr{};
+    int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
+    dhmc_logdensity_fn ext_fn = nullptr;
+    void* ext_user = nullptr;
+    ExtSearchState* d_ss = nullptr;
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
     std::string err;
@@ -115,6 +120,7 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
     case DHMC_TARGET_LOGISTIC: return dispatch_family<LogisticT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_DENSE_NORMAL: return dispatch_family<DenseNormalT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_ALWAYS_DIVERGENT: return dispatch_family<AlwaysDivergentT>(c->NPL, op, P, cs, M);
+    case DHMC_TARGET_EXTERNAL: return dispatch_family<ExternalT>(c->NPL, op, P, cs, M);
     default: return DHMC_ERR_UNSUPPORTED;
     }
 }
@@ -232,6 +238,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (n <= 0 || cfg->target_params_bytes != 8 + sizeof(double) * (uint64_t)n * (D + 1)) return DHMC_ERR_INVALID_ARGUMENT;
         break;
     }
+    case DHMC_TARGET_EXTERNAL:
+        if (cfg->metric != DHMC_METRIC_DIAG) return DHMC_ERR_UNSUPPORTED;
+        break;
     default: return DHMC_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -250,7 +259,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
         c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0;
     c->dense_rounds = many_chains;
-    c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
+    c->external = cfg->target == DHMC_TARGET_EXTERNAL;
+    c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
@@ -295,7 +305,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
     }
-    if (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds) {   // buffers of the round engines
+    if (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) {   // buffers of the round engines
         if ((rc = dev_alloc(c, &c->rb.cp, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.cps, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
@@ -358,6 +368,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
         }
     }
+    if (c->external) {
+        if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_ss, C))) return fail(rc);
+    }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
     // unit metric, ε unspecified
     {
@@ -386,6 +400,32 @@ int dhmc_destroy(dhmc_ctx* c) {
     return DHMC_OK;
 }
 
+// ---- DHMC_TARGET_EXTERNAL (external_rounds.hpp) -------------------------------------------------
+namespace {
+// ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
+int external_eval(dhmc_ctx* c, const double* q) {
+    if (!c->ext_fn) { c->err = "DHMC_TARGET_EXTERNAL: no callback set (dhmc_set_logdensity_callback)"; return DHMC_ERR_CALLBACK; }
+    const int rc = c->ext_fn(c->ext_user, q, c->cfg.chains, c->Dpad, c->cfg.dim, c->lr.S1, c->rb.tbuf, (void*)c->stream);
+    if (rc != 0) { c->err = "DHMC_TARGET_EXTERNAL: the callback returned " + std::to_string(rc); return DHMC_ERR_CALLBACK; }
+    return DHMC_OK;
+}
+#define DHMC_EXT_NPL(KERNEL, GRID, ...)                                                                        \
+    switch (c->NPL) {                                                                                          \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    default: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    }
+}  // namespace
+
+int dhmc_set_logdensity_callback(dhmc_ctx* c, dhmc_logdensity_fn fn, void* user) {
+    if (!c || !c->external) return DHMC_ERR_INVALID_ARGUMENT;
+    c->ext_fn = fn;
+    c->ext_user = user;
+    return DHMC_OK;
+}
+
 int dhmc_set_stream(dhmc_ctx* c, void* s) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
     c->stream = (hipStream_t)s;
@@ -405,6 +445,11 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     if (rc) { stage_free(c, &s); return rc; }
     HIP_TRY(c, hipGetLastError());
     stage_free(c, &s);
+    if (c->external) {     // the positions are set; ℓ and ∇ℓ come from the callback, then evaluate_ℓ(strict) (mcmc.jl:131)
+        if ((rc = external_eval(c, c->st.q))) return rc;
+        DHMC_EXT_NPL(external_init_finish_kernel, dim3(c->cfg.chains), c->cfg.dim, c->Dpad, c->st, c->lr.S1, c->rb.tbuf)
+        HIP_TRY(c, hipGetLastError());
+    }
     return status_code(c);
 }
 
@@ -524,6 +569,26 @@ int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (double e : h)
         if (!std::isnan(e)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:137 "stepsize ϵ manually specified"
+    if (c->external) {
+        // the same bracketing search, all chains per callback: trial positions -> callback -> one decision per chain
+        ExtSearchParams E{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold, d.maxiter_crossing,
+                          c->st, c->d_ss, c->rb.cps, c->rb.cp, c->lr.S1, c->rb.tbuf, c->rb.list_count};
+        int remaining = 0;
+        HIP_TRY(c, hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream));
+        DHMC_EXT_NPL(ext_search_begin_kernel, dim3(C), E)
+        HIP_TRY(c, hipMemcpyAsync(&remaining, c->rb.list_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        while (remaining > 0) {
+            int rc = external_eval(c, c->rb.cp);
+            if (rc) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream));
+            DHMC_EXT_NPL(ext_search_step_kernel, dim3(C), E)
+            HIP_TRY(c, hipMemcpyAsync(&remaining, c->rb.list_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        HIP_TRY(c, hipGetLastError());
+        return status_code(c);
+    }
     SearchParams P{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold,
                    d.maxiter_crossing, c->st, c->tp};
     int rc = dispatch(c, Op::Search, &P);
@@ -593,7 +658,30 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
-    if (e == hipSuccess && c->logistic_rounds) {
+    if (e == hipSuccess && c->external) {
+        // round engine with the host's callback as the gradient (external_rounds.hpp)
+        RoundArgs ra{P, c->rb};
+        e = hipMemsetAsync(c->rb.list_count, 0, 2 * sizeof(int), c->stream);
+        if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
+        unsigned long long rounds = 0;
+        int done = 0;
+        while (e == hipSuccess && done < C) {
+            for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
+                launch_logistic_op(0, c->NPL, ra, c->lr, c->stream);                                   // p = W∘z, p♯
+                dispatch(c, Op::RoundK0, &ra);
+                e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
+                launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
+                rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
+                if (rc) { cleanup(); return rc; }
+                DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′, p♯
+                dispatch(c, Op::RoundK3, &ra);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        c->last_rounds = rounds;
+    } else if (e == hipSuccess && c->logistic_rounds) {
         // GEMM-gradient round engine (logistic_rounds.hpp)
         RoundArgs ra{P, c->rb};
         const int ld = c->Dpad;
@@ -759,6 +847,7 @@ int dhmc_leapfrog_trajectory(dhmc_ctx* c, double eps, int32_t first, int32_t las
                              const double* p, double* delta, double* logdensity, double* q_out, double* p_out,
                              int32_t* range, uint32_t* status) {
     if (!c || !delta || !logdensity) return DHMC_ERR_INVALID_ARGUMENT;
+    if (c->external) return DHMC_ERR_UNSUPPORTED;   // the probes evaluate the density inside a kernel
     if (!(first <= 0 && 0 <= last)) return DHMC_ERR_INVALID_ARGUMENT;   // diagnostics.jl:218
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int C = c->cfg.chains, D = c->cfg.dim;
@@ -803,6 +892,7 @@ int dhmc_leapfrog_trajectory(dhmc_ctx* c, double eps, int32_t first, int32_t las
 int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n_eps, int32_t n_momenta,
                                        uint32_t momentum_index, const double* ps, double* out, uint32_t* status) {
     if (!c || !eps || !out || n_eps <= 0 || n_momenta <= 0) return DHMC_ERR_INVALID_ARGUMENT;
+    if (c->external) return DHMC_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int C = c->cfg.chains, D = c->cfg.dim;
     const size_t nout = (size_t)C * n_momenta * n_eps;

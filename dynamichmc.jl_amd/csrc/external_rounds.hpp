@@ -1,0 +1,182 @@
+// The user's own log density on the device: DHMC_TARGET_EXTERNAL (include/dhmc.h).
+//
+// The reference takes ANY LogDensityProblems model (logdensity_and_gradient, src/hamiltonian.jl:204).  The built-in
+// functor families of targets.hpp are evaluated inside the kernels; an external model is instead evaluated for ALL
+// chains at once by a callback the host registers (dhmc_set_logdensity_callback: q [C][ld] in HBM -> ℓ [C], ∇ℓ
+// [C][ld] in HBM, on the context's stream — e.g. a batched PyTorch function, dynamichmc.jl_amd/api.py
+// TorchLogDensity).  That fits the round engine (dense_rounds.hpp / logistic_rounds.hpp) exactly: every round is
+// one leapfrog for every chain,
+//      K0<diag>  K1 (q′ = q + ϵ M⁻¹pₘ)   callback(Q′) -> (ℓ, ∇ℓ)   K2ext (evaluate_ℓ's rules, p′, p♯)   K3
+// with a per-chain diagonal metric.  The kernels here are the two that touch the callback's outputs, and the
+// batched initial step size search (stepsize.jl:46-85), whose trial leapfrogs need the callback as well.
+#pragma once
+#include "logistic_rounds.hpp"
+
+namespace dhmc {
+
+// evaluate_ℓ (hamiltonian.jl:202-217) on what the callback returned for one chain: the row's position must be finite
+// (else the reference throws, :203), then (ℓ finite ∧ ∇ℓ finite) ∨ ℓ == -Inf keeps ℓ, anything else demotes to -Inf.
+template <int NPL>
+__device__ __forceinline__ double external_evaluate(const double* __restrict__ qrow, const double* __restrict__ grow, int lane, int D,
+                                                    double lq_in, double (&g)[NPL], bool& pos_finite, bool& valid) {
+    bool qfin = true, gfin = true;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double gv = e < D ? grow[e] : 0.0;      // padding columns of the callback's output are ignored
+        g[k] = gv;
+        qfin = qfin && dm_isfinite(qrow[e]);
+        gfin = gfin && dm_isfinite(gv);
+    }
+    pos_finite = wave_all(qfin);
+    const bool grad_finite = wave_all(gfin);
+    const double lq = uni_f64(lq_in);
+    valid = pos_finite && ((dm_isfinite(lq) && grad_finite) || lq == -dm_inf());
+    return valid ? lq : -dm_inf();
+}
+
+// initialize_warmup_state's strict evaluation (mcmc.jl:131 -> hamiltonian.jl:212-216)
+template <int NPL>
+__global__ __launch_bounds__(64) void external_init_finish_kernel(int D, int Dpad, ChainArrays st, const double* __restrict__ lq_in,
+                                                                 const double* __restrict__ grad_in) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * Dpad;
+    double g[NPL];
+    bool pos_finite, valid;
+    const double lq = external_evaluate<NPL>(st.q + row, grad_in + row, lane, D, lq_in[chain], g, pos_finite, valid);
+    stv<NPL>(st.g + row, lane, g);
+    if (lane == 0) {
+        st.lq[chain] = lq;
+        uint32_t s = 0;
+        if (!pos_finite) s |= DHMC_ST_NONFINITE_POSITION;
+        else if (!valid) s |= DHMC_ST_INVALID_INITIAL;
+        st.status[chain] = s;
+    }
+}
+
+// K2 of the round engine for an external density: ∇ℓ(q′), ℓ(q′) from the callback; second half step; p♯
+template <int NPL>
+__global__ __launch_bounds__(64) void rounds_k2_external_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
+    TreeState& S = R.ts[chain];
+    if (S.phase != PH_LEAF) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    const double h = S.eps_s / 2;
+    double g[NPL], p[NPL];
+    bool pos_finite, valid;
+    const double lq = external_evaluate<NPL>(P.st.q + row, R.tbuf + row, lane, P.D, L.S1[chain], g, pos_finite, valid);
+    ldv<NPL>(R.cp + row, lane, p);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];                      // hamiltonian.jl:280
+    stv<NPL>(P.st.g + row, lane, g);
+    stv<NPL>(R.cp + row, lane, p);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) R.cps[row + lane + WAVE * k] = P.st.minv[row + lane + WAVE * k] * p[k];
+    if (lane == 0) {
+        S.lq_leaf = lq;
+        if (!pos_finite) S.status |= DHMC_ST_NONFINITE_POSITION;
+    }
+}
+
+// ---- warmup(::InitialStepsizeSearch) (mcmc.jl:134-148 -> stepsize.jl:46-85), all chains per callback ----------
+struct ExtSearchState {
+    double l0, eps;
+    int32_t dbl, iter, active, pad_;
+};
+struct ExtSearchParams {
+    int D, Dpad, C, chain_offset;
+    uint64_t seed;
+    double initial_eps, log_threshold;
+    int maxiter;
+    ChainArrays st;
+    ExtSearchState* ss;   // [C]
+    double* p0;           // [C][Dpad]  the search momentum
+    double* trial;        // [C][Dpad]  trial positions handed to the callback
+    const double* lq_in;  // [C]        callback outputs for the trial positions
+    const double* grad_in;
+    int* remaining;       // number of chains still searching after this step
+};
+
+template <int NPL>
+__device__ __forceinline__ void ext_search_propose(const ExtSearchParams& P, size_t row, int lane, double eps) {
+    const double h = eps / 2;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double pm = P.p0[row + e] + h * P.st.g[row + e];              // hamiltonian.jl:277
+        const double t = P.st.minv[row + e] * pm;
+        P.trial[row + e] = P.st.q[row + e] + eps * t;                        // :278
+    }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_begin_kernel(ExtSearchParams P) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+    double p0[NPL];
+    sample_momentum<NPL>(key, PURPOSE_SEARCH_MOMENTUM, P.st.transition[chain], P.st.W + row, lane, p0);
+    stv<NPL>(P.p0 + row, lane, p0);
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p0[k], P.st.minv[row + lane + WAVE * k] * p0[k], kacc);
+    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc) / 2.0));
+    ExtSearchState s{l0, P.initial_eps, 0, -1, 1, 0};
+    if (!dm_isfinite(l0)) {   // stepsize.jl:77-79
+        s.active = 0;
+        if (lane == 0) P.st.status[chain] |= DHMC_ST_NONFINITE_START_DENSITY;
+    } else {
+        ext_search_propose<NPL>(P, row, lane, s.eps);
+        if (lane == 0) atomicAdd(P.remaining, 1);
+    }
+    if (lane == 0) P.ss[chain] = s;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_step_kernel(ExtSearchParams P) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    ExtSearchState s = P.ss[chain];
+    if (!s.active) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    double g[NPL];
+    bool pos_finite, valid;
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], g, pos_finite, valid);
+    const double h = s.eps / 2;
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double pm = P.p0[row + e] + h * P.st.g[row + e];
+        const double p1 = pm + h * g[k];                                     // hamiltonian.jl:280
+        kacc = __builtin_fma(p1, P.st.minv[row + e] * p1, kacc);
+    }
+    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc) / 2.0)) - s.l0;   // stepsize.jl:81-83
+    uint32_t st = 0;
+    if (!pos_finite) st |= DHMC_ST_NONFINITE_POSITION;
+    if (s.iter < 0) {                       // A(initial ϵ): which way to go (stepsize.jl:49-50)
+        s.dbl = A > P.log_threshold;
+        s.iter = 0;
+        s.eps = s.dbl ? 2 * s.eps : s.eps / 2;
+    } else if (s.dbl ? (A < P.log_threshold) : (A > P.log_threshold)) {
+        s.active = 0;                       // crossed: this ϵ′ is the answer (:54)
+    } else {
+        s.iter += 1;
+        if (s.iter >= P.maxiter) {          // :57-59
+            s.active = 0;
+            st |= DHMC_ST_STEPSIZE_SEARCH_FAILED;
+        } else {
+            s.eps = s.dbl ? 2 * s.eps : s.eps / 2;
+        }
+    }
+    if (s.active) {
+        ext_search_propose<NPL>(P, row, lane, s.eps);
+        if (lane == 0) atomicAdd(P.remaining, 1);
+    }
+    if (lane == 0) {
+        P.ss[chain] = s;
+        if (!s.active) P.st.eps[chain] = s.eps;
+        if (st) P.st.status[chain] |= st;
+    }
+}
+
+}  // namespace dhmc

@@ -258,4 +258,23 @@ struct AlwaysDivergentT {
     __device__ __forceinline__ double finish(double s) const { return s; }
 };
 
+// DHMC_TARGET_EXTERNAL: the density lives in the host's callback (external_rounds.hpp), never in a kernel.  The
+// functor exists so that the family dispatches like the others; the library only launches round-engine kernels
+// for it (their use of the functor is limited to kRecomputeGrad == false: gradients are stored, never recomputed).
+struct ExternalT {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = false;
+    static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kRecomputeGrad = false;
+    static constexpr bool kFiniteLqImpliesFiniteQ = false;
+    __device__ explicit ExternalT(const TargetParams&) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&)[NPL], double (&g)[NPL], int, int) const {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] = dm_nan();
+        return dm_nan();
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+
 }  // namespace dhmc

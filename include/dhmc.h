@@ -64,6 +64,7 @@ extern "C" {
 #define DHMC_ERR_UNSUPPORTED 3      /* valid request outside what this build implements */
 #define DHMC_ERR_CHAIN_FAILURE 4    /* >=1 chain hit a reference `throw` site; see dhmc_get_status */
 #define DHMC_ERR_NO_DEVICE 5        /* no HIP device / kernels unavailable: there is NO CPU fallback */
+#define DHMC_ERR_CALLBACK 6         /* the DHMC_TARGET_EXTERNAL callback is missing or returned non-zero */
 
 /* ---- per-chain status bits (reference throw sites) ----------------------------------- */
 #define DHMC_ST_NONFINITE_POSITION 1u      /* hamiltonian.jl:203 "Position vector has non-finite elements." */
@@ -79,6 +80,8 @@ extern "C" {
 #define DHMC_TARGET_FUNNEL 3      /* Neal's funnel: v=q_0~N(0,3^2), q_i|v~N(0,e^v). params: none */
 #define DHMC_TARGET_LOGISTIC 4    /* Bernoulli-logit regression, N(0,I) prior.  params: int64 n; double X[n][D]; double y[n] */
 #define DHMC_TARGET_DENSE_NORMAL 6 /* l = -1/2 (q-mu)'P(q-mu), P full symmetric (read from its upper triangle). params: double mu[D], P[D][D] */
+#define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
+                                    * (dhmc_set_logdensity_callback); diagonal metric only. params: none */
 #define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
 
 /* ---- kinetic energy (GaussianKineticEnergy, hamiltonian.jl:56-87) -------------------- */
@@ -169,6 +172,17 @@ int dhmc_get_metric_dense(dhmc_ctx* ctx, double* minv, double* W);
 int dhmc_set_stepsize(dhmc_ctx* ctx, const double* eps, int per_chain, int on_device);
 int dhmc_get_stepsize(dhmc_ctx* ctx, double* eps, int on_device); /* [C] */
 int dhmc_get_status(dhmc_ctx* ctx, uint32_t* status); /* host [C] */
+
+/* ---- DHMC_TARGET_EXTERNAL: the downward plugin API.  The reference calls LogDensityProblems.logdensity_and_gradient(ℓ, q)
+ *      (hamiltonian.jl:204) once per leapfrog per chain; here the callback is called once per leapfrog ROUND with the
+ *      positions of all chains: q [chains][ld] (device; columns >= dim are padding), and must put ℓ(q_c) into
+ *      lq [chains] and ∇ℓ(q_c) into grad [chains][ld] (device; padding columns are ignored), enqueued on `stream`
+ *      (a hipStream_t) or finished when it returns.  Non-finite outputs are legal: evaluate_ℓ's rules
+ *      (hamiltonian.jl:202-217) are applied to them.  Return 0; anything else aborts the call with DHMC_ERR_CALLBACK.
+ *      Must be set before dhmc_init.  The Python host wraps a batched PyTorch function this way (api.TorchLogDensity). */
+typedef int (*dhmc_logdensity_fn)(void* user, const double* q, int64_t chains, int64_t ld, int64_t dim, double* lq,
+                                  double* grad, void* stream);
+int dhmc_set_logdensity_callback(dhmc_ctx* ctx, dhmc_logdensity_fn fn, void* user);
 
 /* ---- warmup(::InitialStepsizeSearch) (mcmc.jl:134-148 -> stepsize.jl:46-85) ---------- */
 int dhmc_find_initial_stepsize(dhmc_ctx* ctx, const dhmc_stepsize_search* params);
