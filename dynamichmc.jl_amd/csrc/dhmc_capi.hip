@@ -920,7 +920,7 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n
 int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat) {
     if (!draws || !coords || !ess || !rhat || chains < 1 || n < 4 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
-    if (n > 8192) return DHMC_ERR_UNSUPPORTED;
+    if (n > 7680) return DHMC_ERR_UNSUPPORTED;   // one series (n doubles) + the reduction scratch must fit 64 KB of LDS
     for (int i = 0; i < ncoords; ++i)
         if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;

@@ -232,7 +232,7 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* ctx, const double* eps, int32_t
  *      be reported without moving the draws.  Estimator: multi-chain autocorrelation with Geyer's initial monotone
  *      positive sequence (what the reference's tests obtain from MCMCDiagnosticTools.ess_rhat,
  *      test/sample-correctness_utilities.jl:40-43; that package is not vendored, parity unpinned).  coords, ess,
- *      rhat are HOST arrays; stream may be NULL; n <= 8192 in this build, n >= 4. ---------------------------- */
+ *      rhat are HOST arrays; stream may be NULL; 4 <= n <= 7680 in this build. ---------------------------- */
 int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
 

@@ -153,3 +153,13 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
         assert np.allclose(ess, e2.cpu().numpy(), rtol=1e-9) and np.allclose(rhat, r2.cpu().numpy(), rtol=1e-12)
     with pytest.raises(RuntimeError):
         pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"))   # n < 4
+
+
+def test_ess_rhat_longest_series(pkg):
+    """n = 7680 draws per chain is the longest series one workgroup holds in LDS; beyond it the call is refused."""
+    import torch
+    x = torch.randn((2, 7680, 3), dtype=torch.float64, device="cuda")
+    ess, rhat = pkg.diagnostics.ess_bulk_device(x, np.array([0, 2], np.int32))
+    assert (ess > 0.5 * 2 * 7680).all() and (np.abs(rhat - 1) < 0.01).all()
+    with pytest.raises(RuntimeError):
+        pkg.diagnostics.ess_bulk_device(torch.zeros((1, 7681, 1), dtype=torch.float64, device="cuda"))
