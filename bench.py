@@ -317,7 +317,8 @@ def main():
                        "phase": "sampling (fixed adapted eps and M^-1 per chain)", "max_depth": 10,
                        "parallelism": f"chains sharded x{world}, no data-path collective"},
             "ess_per_sec": ess_rate,
-            "ess_note": f"min bulk ESS over 16 coordinates, {ess_T} further draws x all chains, untimed continuation",
+            "ess_note": f"min rank-normalised split-chain bulk ESS (Vehtari et al. 2021; dhmc_ess_bulk) over 16 coordinates, "
+                        f"{ess_T} further draws x all chains, untimed continuation",
             "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
                      "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -5,6 +5,7 @@
 // stream, and maps per-chain failure words onto return codes.  There is NO CPU path in this
 // library: without a HIP device every entry point that computes returns DHMC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -939,6 +940,47 @@ int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t cha
     if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
     if (hipMemcpyAsync(ess, de.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
     if (hipMemcpyAsync(rhat, dr.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
+    return DHMC_OK;
+}
+
+int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat) {
+    if (!draws || !coords || !ess || !rhat || chains < 1 || n < 8 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
+    const int64_t half = n / 2, N2 = 2 * half, S = chains * N2, C2 = 2 * chains;
+    if (half > 7680 || S > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
+    for (int i = 0; i < ncoords; ++i)
+        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dk, dk2, di, di2, dz, da, dm, de, dr, dtmp, dc0;
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
+                                           (int32_t*)nullptr, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
+    const int32_t zero = 0;
+    if (hipMalloc(&dk.p, sizeof(double) * S) != hipSuccess || hipMalloc(&dk2.p, sizeof(double) * S) != hipSuccess ||
+        hipMalloc(&di.p, sizeof(int32_t) * S) != hipSuccess || hipMalloc(&di2.p, sizeof(int32_t) * S) != hipSuccess ||
+        hipMalloc(&dz.p, sizeof(double) * S) != hipSuccess || hipMalloc(&da.p, sizeof(double) * S) != hipSuccess ||
+        hipMalloc(&dm.p, sizeof(double) * C2) != hipSuccess || hipMalloc(&de.p, sizeof(double)) != hipSuccess ||
+        hipMalloc(&dr.p, sizeof(double)) != hipSuccess || hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess ||
+        hipMalloc(&dc0.p, sizeof(int32_t)) != hipSuccess)
+        return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(dc0.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    for (int j = 0; j < ncoords; ++j) {
+        hipLaunchKernelGGL(ess_gather_kernel, dim3(nb), dim3(256), 0, s, draws, n, dim, coords[j], chains, N2, (double*)dk.p, (int32_t*)di.p);
+        if (hipcub::DeviceRadixSort::SortPairs(dtmp.p, tmp_bytes, (const double*)dk.p, (double*)dk2.p, (const int32_t*)di.p,
+                                               (int32_t*)di2.p, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
+        hipLaunchKernelGGL(ess_rank_kernel, dim3(nb), dim3(256), 0, s, (const double*)dk2.p, (const int32_t*)di2.p, S, (double*)dz.p);
+        // z is [2C][N'][1]: the estimator of dhmc_ess_rhat on one "coordinate"
+        hipLaunchKernelGGL(ess_acov_kernel, dim3(1, (unsigned)C2), dim3(ESS_THREADS), sizeof(double) * half, s, (const double*)dz.p, half,
+                           (int64_t)1, (const int32_t*)dc0.p, C2, (double*)da.p, (double*)dm.p);
+        hipLaunchKernelGGL(ess_finish_kernel, dim3(1), dim3(ESS_THREADS), sizeof(double) * half, s, (const double*)da.p,
+                           (const double*)dm.p, half, C2, (double*)de.p, (double*)dr.p);
+        if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
+        if (hipMemcpyAsync(ess + j, de.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+        if (hipMemcpyAsync(rhat + j, dr.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    }
     if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
     return DHMC_OK;
 }

@@ -100,4 +100,32 @@ __global__ __launch_bounds__(ESS_THREADS) void ess_finish_kernel(const double* _
     rhat[j] = sqrt(var_plus / W);
 }
 
+// ---- rank normalisation (bulk ESS of Vehtari, Gelman, Simpson, Carpenter, Bürkner 2021; what MCMCDiagnosticTools'
+// ess_rhat computes by default for the reference's tests): each chain is split in two halves, all S = 2C·N' draws of a
+// coordinate are replaced by z = Φ⁻¹((rank − 3/8)/(S + 1/4)) with average ranks for ties (NUTS repeats a draw
+// whenever the initial point is selected), and the estimator above runs on z laid out as [2C][N'][1]. -------------
+
+// keys[i] = the i-th kept draw of coordinate `coord` (i = c·2N' + n: the odd leftover draw of a chain is dropped)
+__global__ void ess_gather_kernel(const double* __restrict__ draws, int64_t N, int64_t D, int32_t coord, int64_t C, int64_t N2,
+                                  double* __restrict__ keys, int32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * N2) return;
+    const int64_t c = i / N2, n = i % N2;
+    keys[i] = draws[((size_t)c * N + n) * D + coord];
+    idx[i] = (int32_t)i;
+}
+
+// sorted keys + their original indices -> z scores at the original places (which ARE the split layout [2C][N']:
+// i = c·2N' + n = (2c + n/N')·N' + n%N')
+__global__ void ess_rank_kernel(const double* __restrict__ skeys, const int32_t* __restrict__ sidx, int64_t S, double* __restrict__ z) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S) return;
+    const double key = skeys[r];
+    int64_t lo = r, hi = r;                                   // the run of equal keys containing r (ties are short)
+    while (lo > 0 && skeys[lo - 1] == key) --lo;
+    while (hi + 1 < S && skeys[hi + 1] == key) ++hi;
+    const double rank = 0.5 * (double)(lo + hi) + 1.0;       // average rank, 1-based
+    z[sidx[r]] = normcdfinv((rank - 0.375) / ((double)S + 0.25));
+}
+
 }  // namespace dhmc

@@ -56,10 +56,26 @@ def ess_rhat(x):
     return C * N / tau, float(np.sqrt(var_plus / W))
 
 
-def ess_bulk_device(draws, coords=None):
+def ess_bulk(x):
+    """Bulk ESS and rank-normalised split-R-hat of one scalar, x [C][N] (Vehtari et al. 2021; the default kind of
+    MCMCDiagnosticTools.ess_rhat, which the reference's tests call): split every chain in two, replace the draws by the
+    normal scores of their average ranks, then the estimator of ess_rhat.  Host flavour (scipy) of `dhmc_ess_bulk`."""
+    from scipy.special import ndtri
+    from scipy.stats import rankdata
+    x = np.asarray(x, np.float64)
+    C, N = x.shape
+    h = N // 2
+    xs = x[:, :2 * h].reshape(2 * C, h)
+    r = rankdata(xs.ravel(), method="average").reshape(xs.shape)
+    return ess_rhat(ndtri((r - 0.375) / (xs.size + 0.25)))
+
+
+def ess_bulk_device(draws, coords=None, kind="bulk"):
     """ESS and R-hat per coordinate for draws [C][N][D] held in HBM (a CUDA torch tensor), computed where they lie by
-    the library's HIP kernels (`dhmc_ess_rhat`, csrc/ess_kernels.hpp: the estimator of ess_rhat above), so ESS/s can
-    be reported without shipping the draws to the host.  Returns numpy arrays (ess [k], rhat [k])."""
+    the library's HIP kernels (csrc/ess_kernels.hpp), so ESS/s can be reported without shipping the draws to the host
+    (SURVEY.md §8 f-3).  kind = "bulk": rank-normalised split-chain bulk ESS (`dhmc_ess_bulk`, the estimator of
+    ess_bulk above); "plain": no split, no rank normalisation (`dhmc_ess_rhat`, ess_rhat above).
+    Returns numpy arrays (ess [k], rhat [k])."""
     import ctypes as C_
     from . import _abi as abi
     Cn, N, D = draws.shape
@@ -69,12 +85,13 @@ def ess_bulk_device(draws, coords=None):
         coords.cpu().numpy() if hasattr(coords, "cpu") else coords, np.int32)
     ess = np.zeros(idx.size); rhat = np.zeros(idx.size)
     import torch
-    rc = abi.lib().dhmc_ess_rhat(C_.c_int32(draws.device.index or 0), C_.c_void_p(torch.cuda.current_stream(draws.device).cuda_stream),
+    fn = abi.lib().dhmc_ess_bulk if kind == "bulk" else abi.lib().dhmc_ess_rhat
+    rc = fn(C_.c_int32(draws.device.index or 0), C_.c_void_p(torch.cuda.current_stream(draws.device).cuda_stream),
                                  C_.c_void_p(draws.data_ptr()), C_.c_int64(Cn), C_.c_int64(N), C_.c_int64(D),
                                  C_.c_void_p(idx.ctypes.data), C_.c_int32(idx.size), C_.c_void_p(ess.ctypes.data),
                                  C_.c_void_p(rhat.ctypes.data))
     if rc != abi.OK:
-        raise RuntimeError(f"dhmc_ess_rhat: {abi.ERROR_NAMES.get(rc, rc)}")
+        raise RuntimeError(f"dhmc_ess_{'bulk' if kind == 'bulk' else 'rhat'}: {abi.ERROR_NAMES.get(rc, rc)}")
     return ess, rhat
 
 

@@ -235,6 +235,12 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* ctx, const double* eps, int32_t
  *      rhat are HOST arrays; stream may be NULL; 4 <= n <= 7680 in this build. ---------------------------- */
 int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
+/* Bulk ESS and rank-normalised split-R̂ (Vehtari et al. 2021 — MCMCDiagnosticTools.ess_rhat's default kind): every chain
+ * is split in two halves (an odd last draw is dropped), the 2·chains·(n/2) draws of a coordinate are replaced by the
+ * normal scores of their average ranks, and the estimator of dhmc_ess_rhat runs on those.  Same arguments; n >= 8,
+ * n/2 <= 7680. */
+int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
 
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);

@@ -144,22 +144,30 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
         x += rng.normal(size=(C, 1, D)) * 0.05              # slightly different chain means: R-hat > 1
         coords = np.arange(D, dtype=np.int32)[:: max(1, D // 7)]
         t = torch.from_numpy(x).cuda()
-        ess, rhat = pkg.diagnostics.ess_bulk_device(t, coords)
+        ess, rhat = pkg.diagnostics.ess_bulk_device(t, coords, kind="plain")
         e2, r2 = pkg.diagnostics.ess_bulk_torch(t, torch.from_numpy(coords).long().cuda())
         for k, j in enumerate(coords):
             eh, rh = pkg.diagnostics.ess_rhat(x[:, :, j])
             assert np.isclose(ess[k], eh, rtol=1e-9), (C, N, j, ess[k], eh)
             assert np.isclose(rhat[k], rh, rtol=1e-12)
         assert np.allclose(ess, e2.cpu().numpy(), rtol=1e-9) and np.allclose(rhat, r2.cpu().numpy(), rtol=1e-12)
+        # rank-normalised split-chain bulk ESS (Vehtari et al. 2021) against the scipy flavour; ties included
+        xt = x.copy(); xt[:, 1::7] = xt[:, 0:-1:7][:, :xt[:, 1::7].shape[1]]      # repeated draws, as NUTS produces
+        tt = torch.from_numpy(xt).cuda()
+        eb, rb = pkg.diagnostics.ess_bulk_device(tt, coords)
+        for k, j in enumerate(coords):
+            eh, rh = pkg.diagnostics.ess_bulk(xt[:, :, j])
+            assert np.isclose(eb[k], eh, rtol=1e-7), (C, N, j, eb[k], eh)
+            assert np.isclose(rb[k], rh, rtol=1e-9)
     with pytest.raises(RuntimeError):
-        pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"))   # n < 4
+        pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"), kind="plain")   # n < 4
 
 
 def test_ess_rhat_longest_series(pkg):
     """n = 7680 draws per chain is the longest series one workgroup holds in LDS; beyond it the call is refused."""
     import torch
     x = torch.randn((2, 7680, 3), dtype=torch.float64, device="cuda")
-    ess, rhat = pkg.diagnostics.ess_bulk_device(x, np.array([0, 2], np.int32))
+    ess, rhat = pkg.diagnostics.ess_bulk_device(x, np.array([0, 2], np.int32), kind="plain")
     assert (ess > 0.5 * 2 * 7680).all() and (np.abs(rhat - 1) < 0.01).all()
     with pytest.raises(RuntimeError):
-        pkg.diagnostics.ess_bulk_device(torch.zeros((1, 7681, 1), dtype=torch.float64, device="cuda"))
+        pkg.diagnostics.ess_bulk_device(torch.zeros((1, 7681, 1), dtype=torch.float64, device="cuda"), kind="plain")

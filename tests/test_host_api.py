@@ -111,6 +111,10 @@ def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8,
     import torch
     e2, r2 = pkg.diagnostics.ess_bulk_torch(torch.from_numpy(x)[:, :, None])      # same estimator, torch flavour
     assert abs(float(e2[0]) - ess) / ess < 1e-6 and abs(float(r2[0]) - rhat) < 1e-9
+    eb, rb = pkg.diagnostics.ess_bulk(x)                                            # rank-normalised, split chains
+    assert 6000 < eb < 10000 and abs(rb - 1) < 0.01
+    eb2, _ = pkg.diagnostics.ess_bulk(np.exp(3 * x))                                # invariant under monotone maps
+    assert abs(eb2 - eb) < 1e-9 * eb
 
 
 def test_shard_chains(pkg):
