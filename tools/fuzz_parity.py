@@ -13,7 +13,7 @@ t0 = time.time(); ncase = 0; nfail = 0; nrun = 0; ntrans = 0; nleap = 0
 while time.time() - t0 < budget:
     kind = rng.choice(["std", "diag", "tridiag", "funnel", "logistic", "densenormal", "std_dense", "tridiag_dense", "divergent"])
     dense = kind.endswith("_dense")
-    D = int(rng.choice([1, 2, 3, 5, 17, 30, 63, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512, 700, 1000, 1024])) if not dense else int(rng.choice([2, 5, 17, 40, 64, 90]))
+    D = int(rng.choice([1, 2, 3, 5, 17, 30, 63, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512, 700, 1000, 1024])) if not dense else int(rng.choice([2, 5, 17, 40, 64, 90, 90, 90, 520, 1000]))
     if kind in ("logistic",): D = int(rng.choice([2, 6, 20, 70]))
     if kind in ("densenormal",): D = int(rng.choice([2, 5, 12, 40]))
     if kind == "funnel": D = max(D, 2)
@@ -37,9 +37,17 @@ while time.time() - t0 < budget:
         target = ol.TARGET_DENSE_NORMAL; A = rng.normal(size=(D, D)); P = A @ A.T / D + np.eye(D)
         params = ol.target_params_blob(target, D, mu=rng.normal(size=D), P=P)
     kw = dict(target=target, seed=seed, max_depth=md, chain_offset=off, metric=ol.METRIC_DENSE if dense else ol.METRIC_DIAG)
-    dev = pkg.DeviceContext(D, C, target_params=params, **kw)
+    # engine choice (read at context creation): the round engines, normally chosen from 128 chains up, and their K3 variants
+    env = {}
+    if dense and rng.random() < 0.4: env = {"DHMC_DENSE_ROUNDS": "1", "DHMC_K3_BLOCK": str(int(rng.random() < 0.5))}
+    if kind == "logistic" and rng.random() < 0.5: env = {"DHMC_LOGISTIC_ROUNDS": "1"}
+    os.environ.update(env)
+    try:
+        dev = pkg.DeviceContext(D, C, target_params=params, **kw)
+    finally:
+        for k_ in env: os.environ.pop(k_, None)
     ora = ol.Oracle(D, C, params=params, threads=4, **kw)
-    desc = f"{kind} D={D} C={C} max_depth={md} seed={seed} offset={off}"
+    desc = f"{kind} D={D} C={C} max_depth={md} seed={seed} offset={off} env={env}"
     try:
         q0 = None if rng.random() < 0.5 or kind == "divergent" else rng.normal(size=(C, D))
         if kind == "divergent": q0 = np.zeros((C, D))
@@ -59,7 +67,7 @@ while time.time() - t0 < budget:
         if np.isnan(dev.stepsize()).any() or dev.status().any():
             ncase += 1; continue
         for _ in range(int(rng.integers(1, 4))):
-            n = int(rng.integers(1, 25)); adapt = rng.random() < 0.6
+            n = int(rng.integers(1, 25 if D < 500 or not dense else 4)); adapt = rng.random() < 0.6
             x = dev.run(n, da={} if adapt else None, allow_failure=True); y_ = ora.run(n, da={} if adapt else None, allow_failure=True)
             for k in x:
                 assert np.array_equal(x[k], y_[k], equal_nan=True), f"field {k}"
