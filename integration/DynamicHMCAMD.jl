@@ -1,24 +1,6 @@
-# INTEGRATION — binding `libdhmc_amd.so` from the reference's side
-
-The reference (tpapp/DynamicHMC.jl) is Julia. Neither this container nor the GPU box has a
-Julia runtime, so the shim below is **unexecuted** (mechanical `ccall` wrappers; every call
-it makes is exercised through the identical ctypes binding in
-`dynamichmc.jl_amd/_abi.py` + `context.py`, which the GPU tests drive). The C ABI is
-`include/dhmc.h`; structs are plain C layout.
-
-## 1. What a maintainer replaces
-
-`warmup(sampling_logdensity, tuning::TuningNUTS{M}, warmup_state)` (`src/mcmc.jl:258-286`) and
-`mcmc(sampling_logdensity, N, warmup_state)` (`src/mcmc.jl:366-381`) each contain one
-`for i in 1:N` loop that calls `sample_tree`. With the library, the loop becomes one
-`dhmc_run` call for all chains; `warmup(::InitialStepsizeSearch)` (`mcmc.jl:134-148`) becomes
-`dhmc_find_initial_stepsize`; the metric update at `mcmc.jl:281-284` becomes
-`dhmc_update_metric_diag`. Everything above (`_warmup`'s fold over stages, reporters,
-result NamedTuples) stays Julia.
-
-## 2. Julia shim (unexecuted; also as a file: `integration/DynamicHMCAMD.jl`)
-
-```julia
+# NOT EXECUTED in this repository (no Julia runtime in the build image or on the GPU box): the ccall shim of
+# INTEGRATION.md §2 as a file.  Every call it makes is exercised through the identical ctypes binding
+# (dynamichmc.jl_amd/_abi.py, context.py) by the GPU tests, and through tests/cabi/cabi_client.c from plain C.
 module DynamicHMCAMD
 using DynamicHMC: NUTS, DualAveraging, InitialStepsizeSearch, TuningNUTS, DynamicHMCError,
                   TreeStatisticsNUTS, InvalidTree, Directions
@@ -162,70 +144,3 @@ function export_state(ctx)
     blob
 end
 end
-```
-
-Target families are selected by `target` (0 standard normal, 1 diagonal normal `[μ; prec]`, 2 tridiagonal-precision
-normal `[diag; off]`, 3 Neal's funnel, 4 logistic regression `[Int64 n; X (n×D row-major); y]`, 5 the reference's
-AlwaysDivergentTest, 6 full-precision normal `[μ; P (D×D)]`, 7 the caller's own model through `set_logdensity!`) with the parameter blob described in `include/dhmc.h`; a new family is one device functor in
-`csrc/targets.hpp` (the LogDensityProblems `logdensity_and_gradient` contract of `hamiltonian.jl:204`).
-
-Array layout note: the ABI's `[C][N][D]` row-major block is exactly a Julia `Array{Float64,3}`
-of size `(D, N, C)`; `pm[:, :, c]` is chain c's `posterior_matrix` (`mcmc.jl:230`), and
-`stack_posterior_matrices` (`mcmc.jl:602-604`) is `permutedims(pm, (2, 3, 1))`.
-
-## 3. Replaying the ABI's random stream through the real reference (`TapeRNG`)
-
-Bit-level cross-checks against Julia need the reference to consume the same numbers. The
-reference already takes `p` and `directions` as keyword overrides
-(`sample_tree(rng, algorithm, H, Q, ϵ; p, directions)`, `src/NUTS.jl:232-233`), and its only other
-draw inside a transition is `randexp(rng, Float64)` (`NUTS.jl:44`). So:
-
-```julia
-struct TapeRNG <: Random.AbstractRNG; draws::Vector{Float64}; pos::Base.RefValue{Int}; end
-Random.randexp(r::TapeRNG, ::Type{Float64}) = r.draws[r.pos[] += 1]
-# per transition t of chain c:  p = W .* normals(purpose 0), directions = word0(purpose 1),
-# draws = det_randexp.(purpose 2, index 0,1,2,...)   — include/dhmc.h, include/dhmc_detmath.h
-Q′, stats = sample_tree(TapeRNG(draws, Ref(0)), NUTS(), H, Q, ϵ; p = p, directions = Directions(d))
-```
-with the Philox outputs produced by `oracle/philox.hpp` (or any Philox4x32-10). What remains
-different from this library is then only BLAS `dot` order and libm vs `dhmc_detmath.h`
-(last-place effects; `tests/test_gpu_statistics.py` bounds them with the libm oracle).
-
-## 4. Python / ctypes binding (executed; what the tests use)
-
-`dynamichmc.jl_amd/_abi.py` declares the same structs with `ctypes.Structure`, loads
-`lib/libdhmc_amd.so` (and fails loudly if it is missing), and `context.DeviceContext` wraps
-each entry point one-to-one: `init`, `find_initial_stepsize`, `run` / `run_into` (host numpy
-or device torch buffers), `update_metric_diag`, `set_/get_` state, `export_state` /
-`import_state`. `api.py` is the `mcmc_with_warmup` layer. torch is used only by callers for
-device buffers, the stream handle passed to `dhmc_set_stream`, and `torch.distributed`.
-
-### Two process-level notes for Python hosts
-
-* **One HIP runtime.** PyTorch wheels bundle their own `libamdhip64.so` (same SONAME as `/opt/rocm`'s).  If
-  `libdhmc_amd.so` pulled in the system copy before `import torch`, the process would hold two HIP runtimes and the
-  second one reports "No HIP GPUs are available".  `_abi.lib()` therefore loads torch's copy first when torch is
-  installed (torch itself is not imported), so the import order no longer matters.
-* **Results can stay in HBM.** `mcmc_with_warmup(..., on_device=True)` returns the posterior matrix, log densities
-  and tree statistics as torch CUDA tensors; the warmup stages' draws are consumed by the metric update on the
-  device and are only copied to the host by `mcmc_keep_warmup` (which returns them).
-
-### The caller's own model
-
-`DHMC_TARGET_EXTERNAL` + `dhmc_set_logdensity_callback(ctx, fn, user)`: `fn(user, q, chains, ld, dim, lq, grad, stream)`
-receives device pointers (positions of all chains, row stride `ld`) and fills ℓ and ∇ℓ for all of them — the batched
-counterpart of `LogDensityProblems.logdensity_and_gradient(ℓ, q)` (`hamiltonian.jl:204`).  From Julia that is a
-`@cfunction` around a GPU-array implementation of the user's model (AMDGPU.jl arrays wrapped with `unsafe_wrap`);
-from Python, `TorchLogDensity(D, logdensity = f)` wraps any differentiable torch function and
-`mcmc_with_warmup(rng, TorchLogDensity(...), N; chains = C)` reads like the reference call.
-
-### A plain-C client
-
-`tests/cabi/cabi_client.c` is a C99 program (`-pedantic -Werror` clean) that drives the library through `include/dhmc.h`
-alone — create, init, step-size search, an adaptive stage, the diagonal metric update, an inference block — and is run
-on the GPU by `tests/test_gpu_cabi.py`, which checks its draws, step counts and ϵ against the ctypes path bit for bit.
-
-## 5. Build
-
-`python -c "import __graft_entry__ as g; g.build()"` → `make -j8 -C dynamichmc.jl_amd/csrc` (one object per target family + the C ABI)
-(`hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared`) and `make -C oracle`.
