@@ -118,18 +118,21 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
     const size_t row = (size_t)chain * Dpad;
     double* ws = P.st.ws + (size_t)chain * P.nvec * Dpad;
     auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
-    double p[NPL], ps[NPL], g[NPL];
-    ldv<NPL>(R.tbuf + row, lane, p);
-    ldv<NPL>(R.cps + row, lane, ps);
-    ldv<NPL>(P.st.g + row, lane, g);
+    // streamed slot by slot (no register arrays: chains of up to 64 slots per lane come through here)
+    const double* __restrict__ p0row = R.tbuf + row;
+    const double* __restrict__ psrow = R.cps + row;
     double kacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], ps[k], kacc);
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double pk = p0row[e], psk = psrow[e];
+        kacc = __builtin_fma(pk, psk, kacc);
+        wsv(wd_top(0))[e] = pk; wsv(wd_top(1))[e] = psk;              // leaf τ of z₀ (NUTS.jl:120-123)
+        wsv(wd_top(2))[e] = pk; wsv(wd_top(3))[e] = psk;
+        wsv(wd_top(4))[e] = pk;
+    }
     const double lq_cur = S.lq_cur;
     const double pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
-    stv<NPL>(wsv(wd_top(0)), lane, p); stv<NPL>(wsv(wd_top(1)), lane, ps);   // leaf τ of z₀ (NUTS.jl:120-123)
-    stv<NPL>(wsv(wd_top(2)), lane, p); stv<NPL>(wsv(wd_top(3)), lane, ps);
-    stv<NPL>(wsv(wd_top(4)), lane, p);
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     uint32_t w[4];
     philox4x32_10(0u, PURPOSE_DIRECTIONS, S.tr, key.seed_hi, key.k0, key.k1, w);
@@ -138,9 +141,12 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
     const bool fwd = (dirs0 & 1u) != 0;
     const double eps_s = fwd ? eps : -eps;
     const double h = eps_s / 2;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];                 // pₘ of the first leapfrog (hamiltonian.jl:277)
-    stv<NPL>(R.cp + row, lane, p);
+    const double* __restrict__ grow = P.st.g + row;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        R.cp[row + e] = p0row[e] + h * grow[e];                          // pₘ of the first leapfrog (hamiltonian.jl:277)
+    }
     if (lane == 0) {
         const int nslots = ws_nslots(P.max_depth);
         S.pi0 = pi0;

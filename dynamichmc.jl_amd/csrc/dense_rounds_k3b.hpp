@@ -1,5 +1,6 @@
-// K3 of the round engines (dense_rounds.hpp) as a WORKGROUP per chain: four waves, each owning a quarter of the
-// chain's slots (wave w: slots k = w·NT … w·NT+NT-1, NT = NPL/4), for chains of 512+ coordinates.
+// K3 of the round engines (dense_rounds.hpp) as a WORKGROUP per chain: four (NPL 8, 16), eight (NPL 32) or sixteen
+// (NPL 64) waves, each owning NT consecutive slots of the chain (wave w: slots k = w·NT … w·NT+NT-1), for chains of
+// 512+ coordinates.
 //
 // Why: the one-wave-per-chain K3 needs the whole 512-register budget of a SIMD lane at NPL = 16 (one wave per SIMD),
 // so it can neither hide its HBM latency behind other waves nor share a CU with the other half-batch's GEMM.  This
@@ -19,17 +20,18 @@
 
 namespace dhmc {
 
-constexpr int K3B_WPC = 4;
+// waves per chain: four slots per lane and wave (NPL 16 -> 4 waves, 32 -> 8, 64 -> 16 = a 1024-thread workgroup)
+__host__ __device__ constexpr int k3b_waves(int NPL) { return NPL >= 16 ? NPL / 4 : 4; }
 
-template <int N, class Step>
+template <int N, int WPC, class Step>
 __device__ __forceinline__ void chain_allreduce(int wave, int lane, double (*xch)[WAVE], double* red, Step step, double (&out)[N]) {
     double acc[N];
-    for (int w = 0; w < K3B_WPC; ++w) {
+    for (int w = 0; w < WPC; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int n = 0; n < N; ++n) acc[n] = w == 0 ? 0.0 : xch[n][lane];
             step(acc);
-            if (w + 1 < K3B_WPC) {
+            if (w + 1 < WPC) {
 #pragma unroll
                 for (int n = 0; n < N; ++n) xch[n][lane] = acc[n];
             } else {
@@ -48,7 +50,8 @@ __device__ __forceinline__ void chain_allreduce(int wave, int lane, double (*xch
 }
 
 template <class T, int NPL>
-__global__ __launch_bounds__(WAVE * K3B_WPC) void rounds_k3b_kernel(RunParams P, RoundBuffers R) {
+__global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunParams P, RoundBuffers R) {
+    constexpr int K3B_WPC = k3b_waves(NPL);
     static_assert(NPL % (2 * K3B_WPC) == 0, "each wave owns an even number of slots (the momentum stream yields pairs)");
     constexpr int NT = NPL / K3B_WPC;
     const int chain = P.chain_base + blockIdx.x;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WAVE * K3B_WPC) void rounds_k3b_kernel(RunParams P,
 #pragma unroll
         for (int k = 0; k < NT; ++k) { cf[k] = nf[k]; cfs[k] = nfs[k]; cr[k] = rr[k]; }
         double acc[6];
-        chain_allreduce<6>(wave, lane, xch, red, [&](double (&a)[6]) {
+        chain_allreduce<6, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[6]) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 a[0] = __builtin_fma(xms[k], s1[k], a[0]);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(WAVE * K3B_WPC) void rounds_k3b_kernel(RunParams P,
             cr[k] = rr[k];
         }
         double acc[2];
-        chain_allreduce<2>(wave, lane, xch, red, [&](double (&a)[2]) {
+        chain_allreduce<2, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[2]) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 a[0] = __builtin_fma(pas[k], rr[k], a[0]);
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WAVE * K3B_WPC) void rounds_k3b_kernel(RunParams P,
     const uint32_t j = jleaf;
     const int depth0 = depth;
     double kin[1];
-    chain_allreduce<1>(wave, lane, xch, red, [&](double (&a)[1]) {
+    chain_allreduce<1, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[1]) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) a[0] = __builtin_fma(p[k], ps[k], a[0]);
     }, kin);

@@ -80,10 +80,12 @@ int dev_alloc(dhmc_ctx* c, Tp** p, size_t count) {
     return DHMC_OK;
 }
 
-int npl_for_dim(int D) {
+// slots per lane: the register/LDS-resident kernels go up to 16 (D <= 1024); the streaming round-engine kernels
+// of an external model up to 64 (D <= 4096)
+int npl_for_dim(int D, bool big) {
     int npl = (D + WAVE - 1) / WAVE;
-    for (int cand : {1, 2, 4, 8, 16})
-        if (npl <= cand) return cand;
+    for (int cand : {1, 2, 4, 8, 16, 32, 64})
+        if (npl <= cand) return (cand <= 16 || big) ? cand : 0;
     return 0;
 }
 
@@ -96,7 +98,9 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
     case 2: hipLaunchKernelGGL((KERNEL<2>), g, b, 0, s, __VA_ARGS__); break;                      \
     case 4: hipLaunchKernelGGL((KERNEL<4>), g, b, 0, s, __VA_ARGS__); break;                      \
     case 8: hipLaunchKernelGGL((KERNEL<8>), g, b, 0, s, __VA_ARGS__); break;                      \
-    default: hipLaunchKernelGGL((KERNEL<16>), g, b, 0, s, __VA_ARGS__); break;                    \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), g, b, 0, s, __VA_ARGS__); break;                    \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), g, b, 0, s, __VA_ARGS__); break;                    \
+    default: hipLaunchKernelGGL((KERNEL<64>), g, b, 0, s, __VA_ARGS__); break;                    \
     }
     switch (which) {
     case 0: DHMC_NPL_SWITCH(rounds_momentum_diag_kernel, a.P, a.R) break;
@@ -148,7 +152,9 @@ void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
     case 2: hipLaunchKernelGGL((metric_diag_kernel<2>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
     case 4: hipLaunchKernelGGL((metric_diag_kernel<4>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
     case 8: hipLaunchKernelGGL((metric_diag_kernel<8>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    default: hipLaunchKernelGGL((metric_diag_kernel<16>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    case 16: hipLaunchKernelGGL((metric_diag_kernel<16>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    case 32: hipLaunchKernelGGL((metric_diag_kernel<32>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
+    default: hipLaunchKernelGGL((metric_diag_kernel<64>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
     }
 }
 
@@ -250,7 +256,12 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (!c) return DHMC_ERR_HIP;
     c->cfg = *cfg;
     c->cfg.target_params = nullptr;
-    c->NPL = npl_for_dim(D);
+    c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL);
+    if (cfg->target == DHMC_TARGET_EXTERNAL)
+        if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels
+            const int f = std::atoi(e);
+            if ((f == 32 || f == 64) && f >= c->NPL) c->NPL = f;
+        }
     if (c->NPL == 0) { delete c; return DHMC_ERR_UNSUPPORTED; }
     c->Dpad = c->NPL * WAVE;
     // Round engines pay ≈8 launches per leapfrog round; they win once a round carries enough chains to fill the
@@ -416,7 +427,9 @@ int external_eval(dhmc_ctx* c, const double* q) {
     case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
     case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
     case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
-    default: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    default: hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
     }
 }  // namespace
 
@@ -442,7 +455,9 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
         if (rc) return rc;
     }
     InitParams P{c->cfg.dim, c->Dpad, c->cfg.chains, c->cfg.chain_offset, c->cfg.seed, (const double*)s.dev, c->st, c->tp};
-    int rc = dispatch(c, Op::Init, &P);
+    int rc = DHMC_OK;
+    if (c->external) { DHMC_EXT_NPL(external_init_positions_kernel, dim3(c->cfg.chains), P) }
+    else rc = dispatch(c, Op::Init, &P);
     if (rc) { stage_free(c, &s); return rc; }
     HIP_TRY(c, hipGetLastError());
     stage_free(c, &s);

@@ -14,19 +14,23 @@
 
 namespace dhmc {
 
+// All kernels here stream a chain's row slot by slot (no register arrays), so they serve up to 64 slots per lane
+// (D <= 4096): external models are the one family not tied to the register-resident kernels' D <= 1024.
+
 // evaluate_ℓ (hamiltonian.jl:202-217) on what the callback returned for one chain: the row's position must be finite
 // (else the reference throws, :203), then (ℓ finite ∧ ∇ℓ finite) ∨ ℓ == -Inf keeps ℓ, anything else demotes to -Inf.
-template <int NPL>
+// `each(e, g_e)` is called for every slot with the gradient element (0 in the padding columns).
+template <int NPL, class Each>
 __device__ __forceinline__ double external_evaluate(const double* __restrict__ qrow, const double* __restrict__ grow, int lane, int D,
-                                                    double lq_in, double (&g)[NPL], bool& pos_finite, bool& valid) {
+                                                    double lq_in, bool& pos_finite, bool& valid, Each each) {
     bool qfin = true, gfin = true;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
         const double gv = e < D ? grow[e] : 0.0;      // padding columns of the callback's output are ignored
-        g[k] = gv;
         qfin = qfin && dm_isfinite(qrow[e]);
         gfin = gfin && dm_isfinite(gv);
+        each(e, gv);
     }
     pos_finite = wave_all(qfin);
     const bool grad_finite = wave_all(gfin);
@@ -35,16 +39,53 @@ __device__ __forceinline__ double external_evaluate(const double* __restrict__ q
     return valid ? lq : -dm_inf();
 }
 
+// initialize_warmup_state (mcmc.jl:129-132) without the density: positions (given, or random_position mcmc.jl:108 from
+// the chain's stream exactly as init_kernel does), unit metric, ϵ unspecified, counters cleared
+template <int NPL>
+__global__ __launch_bounds__(64) void external_init_positions_kernel(InitParams P) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const int D = P.D;
+    const size_t row = (size_t)chain * P.Dpad;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+    if (P.q0) {
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            P.st.q[row + e] = e < D ? P.q0[(size_t)chain * D + e] : 0.0;
+        }
+    } else {
+#pragma unroll 2
+        for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+            uint64_t r1, r2;
+            stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_INIT_POSITION, 0u, r1, r2);
+            const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
+            P.st.q[row + e0] = e0 < D ? u01_closed_open(r1) * 4 - 2 : 0.0;
+            if (2 * kk + 1 < NPL) P.st.q[row + e1] = e1 < D ? u01_closed_open(r2) * 4 - 2 : 0.0;
+        }
+    }
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        P.st.minv[row + e] = 1.0;                 // GaussianKineticEnergy(N) (hamiltonian.jl:87)
+        P.st.W[row + e] = e < D ? 1.0 : 0.0;
+    }
+    if (lane == 0) {
+        P.st.eps[chain] = dm_nan();               // ϵ = nothing (mcmc.jl:130)
+        P.st.transition[chain] = 0;
+        P.st.status[chain] = 0;
+    }
+}
+
 // initialize_warmup_state's strict evaluation (mcmc.jl:131 -> hamiltonian.jl:212-216)
 template <int NPL>
 __global__ __launch_bounds__(64) void external_init_finish_kernel(int D, int Dpad, ChainArrays st, const double* __restrict__ lq_in,
                                                                  const double* __restrict__ grad_in) {
     const int chain = blockIdx.x, lane = threadIdx.x;
     const size_t row = (size_t)chain * Dpad;
-    double g[NPL];
     bool pos_finite, valid;
-    const double lq = external_evaluate<NPL>(st.q + row, grad_in + row, lane, D, lq_in[chain], g, pos_finite, valid);
-    stv<NPL>(st.g + row, lane, g);
+    double* gdst = st.g + row;
+    const double lq = external_evaluate<NPL>(st.q + row, grad_in + row, lane, D, lq_in[chain], pos_finite, valid,
+                                             [&](int e, double gv) { gdst[e] = gv; });
     if (lane == 0) {
         st.lq[chain] = lq;
         uint32_t s = 0;
@@ -62,16 +103,17 @@ __global__ __launch_bounds__(64) void rounds_k2_external_kernel(RunParams P, Rou
     if (S.phase != PH_LEAF) return;
     const size_t row = (size_t)chain * P.Dpad;
     const double h = S.eps_s / 2;
-    double g[NPL], p[NPL];
     bool pos_finite, valid;
-    const double lq = external_evaluate<NPL>(P.st.q + row, R.tbuf + row, lane, P.D, L.S1[chain], g, pos_finite, valid);
-    ldv<NPL>(R.cp + row, lane, p);
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];                      // hamiltonian.jl:280
-    stv<NPL>(P.st.g + row, lane, g);
-    stv<NPL>(R.cp + row, lane, p);
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) R.cps[row + lane + WAVE * k] = P.st.minv[row + lane + WAVE * k] * p[k];
+    double* gdst = P.st.g + row;
+    double* cp = R.cp + row;
+    double* cps = R.cps + row;
+    const double* minv = P.st.minv + row;
+    const double lq = external_evaluate<NPL>(P.st.q + row, R.tbuf + row, lane, P.D, L.S1[chain], pos_finite, valid, [&](int e, double gv) {
+        gdst[e] = gv;
+        const double p1 = cp[e] + h * gv;                                  // hamiltonian.jl:280
+        cp[e] = p1;
+        cps[e] = minv[e] * p1;
+    });
     if (lane == 0) {
         S.lq_leaf = lq;
         if (!pos_finite) S.status |= DHMC_ST_NONFINITE_POSITION;
@@ -100,7 +142,7 @@ struct ExtSearchParams {
 template <int NPL>
 __device__ __forceinline__ void ext_search_propose(const ExtSearchParams& P, size_t row, int lane, double eps) {
     const double h = eps / 2;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
         const double pm = P.p0[row + e] + h * P.st.g[row + e];              // hamiltonian.jl:277
@@ -114,12 +156,25 @@ __global__ __launch_bounds__(64) void ext_search_begin_kernel(ExtSearchParams P)
     const int chain = blockIdx.x, lane = threadIdx.x;
     const size_t row = (size_t)chain * P.Dpad;
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
-    double p0[NPL];
-    sample_momentum<NPL>(key, PURPOSE_SEARCH_MOMENTUM, P.st.transition[chain], P.st.W + row, lane, p0);
-    stv<NPL>(P.p0 + row, lane, p0);
+    // p = W∘z (sample_momentum's stream and order), K = ½ p·M⁻¹p in the ABI's order, slot by slot
+    const uint32_t tr = P.st.transition[chain];
     double kacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p0[k], P.st.minv[row + lane + WAVE * k] * p0[k], kacc);
+#pragma unroll 2
+    for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+        uint64_t r1, r2;
+        stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_SEARCH_MOMENTUM, tr, r1, r2);
+        double z0, z1;
+        det_randn2(r1, r2, &z0, &z1);
+        const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
+        const double pa = P.st.W[row + e0] * z0;
+        P.p0[row + e0] = pa;
+        kacc = __builtin_fma(pa, P.st.minv[row + e0] * pa, kacc);
+        if (2 * kk + 1 < NPL) {
+            const double pb = P.st.W[row + e1] * z1;
+            P.p0[row + e1] = pb;
+            kacc = __builtin_fma(pb, P.st.minv[row + e1] * pb, kacc);
+        }
+    }
     const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc) / 2.0));
     ExtSearchState s{l0, P.initial_eps, 0, -1, 1, 0};
     if (!dm_isfinite(l0)) {   // stepsize.jl:77-79
@@ -138,18 +193,14 @@ __global__ __launch_bounds__(64) void ext_search_step_kernel(ExtSearchParams P) 
     ExtSearchState s = P.ss[chain];
     if (!s.active) return;
     const size_t row = (size_t)chain * P.Dpad;
-    double g[NPL];
     bool pos_finite, valid;
-    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], g, pos_finite, valid);
     const double h = s.eps / 2;
     double kacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        const int e = lane + WAVE * k;
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int e, double gv) {
         const double pm = P.p0[row + e] + h * P.st.g[row + e];
-        const double p1 = pm + h * g[k];                                     // hamiltonian.jl:280
+        const double p1 = pm + h * gv;                                       // hamiltonian.jl:280
         kacc = __builtin_fma(p1, P.st.minv[row + e] * p1, kacc);
-    }
+    });
     const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc) / 2.0)) - s.l0;   // stepsize.jl:81-83
     uint32_t st = 0;
     if (!pos_finite) st |= DHMC_ST_NONFINITE_POSITION;

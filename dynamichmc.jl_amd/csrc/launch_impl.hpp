@@ -45,15 +45,27 @@ void launch_round_op(int which, const RoundArgs& a, hipStream_t s) {
     case 1: hipLaunchKernelGGL((rounds_k0_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     case 2: hipLaunchKernelGGL((rounds_k2_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     default:
-        // chains of 512+ coordinates: a workgroup (4 waves) per chain; DHMC_K3_BLOCK=0 (read at dhmc_create) keeps the one-wave kernel
+        // chains of 512+ coordinates: a workgroup (4+ waves) per chain; DHMC_K3_BLOCK=0 (read at dhmc_create) keeps the one-wave kernel
         if constexpr (NPL >= 8) {
-            if (a.P.k3_block) {
-                hipLaunchKernelGGL((rounds_k3b_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE * K3B_WPC), 0, s, a.P, a.R);
+            if (a.P.k3_block || NPL > 16) {
+                hipLaunchKernelGGL((rounds_k3b_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE * k3b_waves(NPL)), 0, s, a.P, a.R);
                 break;
             }
         }
-        hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R);
+        if constexpr (NPL <= 16) hipLaunchKernelGGL((rounds_k3_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R);
         break;
+    }
+}
+
+// 32 / 64 slots per lane (D <= 4096): only the streaming round-engine kernels exist at these widths
+template <class T, int NPL>
+int dispatch_op_big(Op op, const void* P, hipStream_t s) {
+    const RoundArgs& a = *(const RoundArgs*)P;
+    switch (op) {
+    case Op::RoundStart: hipLaunchKernelGGL((rounds_start_kernel<NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); return DHMC_OK;
+    case Op::RoundK0: hipLaunchKernelGGL((rounds_k0_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); return DHMC_OK;
+    case Op::RoundK3: hipLaunchKernelGGL((rounds_k3b_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE * k3b_waves(NPL)), 0, s, a.P, a.R); return DHMC_OK;
+    default: return DHMC_ERR_UNSUPPORTED;
     }
 }
 
@@ -93,6 +105,8 @@ int dispatch_family(int npl, Op op, const void* P, hipStream_t s, const DenseMet
     case 4: dispatch_op<T, 4>(op, P, s, M); return DHMC_OK;
     case 8: dispatch_op<T, 8>(op, P, s, M); return DHMC_OK;
     case 16: dispatch_op<T, 16>(op, P, s, M); return DHMC_OK;
+    case 32: if constexpr (T::kBigDims) return dispatch_op_big<T, 32>(op, P, s); else return DHMC_ERR_UNSUPPORTED;
+    case 64: if constexpr (T::kBigDims) return dispatch_op_big<T, 64>(op, P, s); else return DHMC_ERR_UNSUPPORTED;
     default: return DHMC_ERR_UNSUPPORTED;
     }
 }

@@ -803,37 +803,40 @@ __global__ __launch_bounds__(64) void metric_diag_kernel(int D, int Dpad, int64_
                                                          double* __restrict__ minv, double* __restrict__ W) {
     const int chain = blockIdx.x, lane = threadIdx.x;
     const double* base = draws + (size_t)chain * N * D;
-    double s[NPL], ss[NPL];
+    constexpr int KC = NPL < 16 ? NPL : 16;          // slots per pass (wide chains: several passes over the draws)
+    for (int k0 = 0; k0 < NPL; k0 += KC) {
+        double s[KC], ss[KC];
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) { s[k] = 0.0; ss[k] = 0.0; }
-    for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < KC; ++k) { s[k] = 0.0; ss[k] = 0.0; }
+        for (int64_t i = 0; i < N; ++i)
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            int e = lane + WAVE * k;
-            if (e < D) s[k] = s[k] + base[(size_t)i * D + e];
-        }
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) s[k] = s[k] / (double)N;
-    for (int64_t i = 0; i < N; ++i)
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            int e = lane + WAVE * k;
-            if (e < D) {
-                double d = base[(size_t)i * D + e] - s[k];
-                ss[k] = ss[k] + d * d;
+            for (int k = 0; k < KC; ++k) {
+                int e = lane + WAVE * (k0 + k);
+                if (e < D) s[k] = s[k] + base[(size_t)i * D + e];
             }
-        }
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        int e = lane + WAVE * k;
-        size_t o = (size_t)chain * Dpad + e;
-        if (e < D) {
-            double var = ss[k] / (double)(N - 1);
-            minv[o] = var;
-            W[o] = __builtin_sqrt(1.0 / var);
-        } else {
-            minv[o] = 1.0;
-            W[o] = 0.0;
+        for (int k = 0; k < KC; ++k) s[k] = s[k] / (double)N;
+        for (int64_t i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                int e = lane + WAVE * (k0 + k);
+                if (e < D) {
+                    double d = base[(size_t)i * D + e] - s[k];
+                    ss[k] = ss[k] + d * d;
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            int e = lane + WAVE * (k0 + k);
+            size_t o = (size_t)chain * Dpad + e;
+            if (e < D) {
+                double var = ss[k] / (double)(N - 1);
+                minv[o] = var;
+                W[o] = __builtin_sqrt(1.0 / var);
+            } else {
+                minv[o] = 1.0;
+                W[o] = 0.0;
+            }
         }
     }
 }

@@ -39,6 +39,7 @@ struct StdNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = true;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit StdNormalT(const TargetParams&) {}
@@ -60,6 +61,7 @@ struct DiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* mu;
@@ -85,6 +87,7 @@ struct TridiagNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* diag;
@@ -121,6 +124,7 @@ struct DenseNormalT {
     static constexpr bool kDeferred = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* mu;
@@ -150,6 +154,7 @@ struct FunnelT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |e^{-v} q_i| <= max(e^{-v}, e^{-v} q_i^2)
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit FunnelT(const TargetParams&) {}
@@ -185,6 +190,7 @@ struct LogisticT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |y - σ| <= 1, β finite when β·β is
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = false;              // the gradient is the expensive part: keep it with proposals
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     const double* X;
@@ -242,6 +248,7 @@ struct AlwaysDivergentT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = false;
     static constexpr bool kRecomputeGrad = true;
     static constexpr bool kFiniteLqImpliesFiniteQ = true;
     __device__ explicit AlwaysDivergentT(const TargetParams&) {}
@@ -265,6 +272,7 @@ struct ExternalT {
     static constexpr bool kDeferred = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = false;
     static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kBigDims = true;    // served by the streaming round-engine kernels up to 64 slots per lane (D <= 4096)
     static constexpr bool kRecomputeGrad = false;
     static constexpr bool kFiniteLqImpliesFiniteQ = false;
     __device__ explicit ExternalT(const TargetParams&) {}

@@ -70,3 +70,50 @@ def test_callback_errors_surface_as_python_exceptions(pkg):
         ctx.init()                                               # no callback registered
     with pytest.raises(ValueError):
         pkg.DeviceContext(3, 2).set_logdensity_callback(lambda q: None)   # not an external-target context
+
+
+def _with_env(env, f):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return f()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_wide_chain_kernels_reproduce_the_16_slot_path(pkg):
+    """External models are served up to D = 4096 (32 / 64 slots per lane) by the streaming round-engine kernels; forced
+    onto a 1000-dim model (DHMC_FORCE_NPL) they must give the bits of the 16-slot path: padding adds exact zeros."""
+    import torch
+    D, C = 1000, 8
+    scale = torch.linspace(0.5, 2.0, D, dtype=torch.float64, device="cuda")
+    l = pkg.TorchLogDensity(D, logdensity_and_gradient=lambda q: (-0.5 * ((q / scale) ** 2).sum(1), -q / scale ** 2))
+    run = lambda: pkg.mcmc_with_warmup(7, l, 30, chains=C, reporter=pkg.NoProgressReport(),
+                                       warmup_stages=pkg.default_warmup_stages(middle_steps=20, doubling_stages=2))
+    base = run()
+    for npl in ("32", "64"):
+        r = _with_env({"DHMC_FORCE_NPL": npl}, run)
+        assert np.array_equal(r["posterior_matrix"], base["posterior_matrix"]), npl
+        assert np.array_equal(r["tree_statistics"].steps, base["tree_statistics"].steps), npl
+        assert np.array_equal(r["eps"], base["eps"]) and np.array_equal(r["kappa"].Minv, base["kappa"].Minv), npl
+
+
+def test_model_with_more_than_1024_dimensions(pkg):
+    import torch
+    D, C = 3000, 48
+    sd = torch.linspace(0.5, 3.0, D, dtype=torch.float64, device="cuda")
+    l = pkg.TorchLogDensity(D, logdensity=lambda q: -0.5 * ((q / sd) ** 2).sum(1))
+    r = pkg.mcmc_with_warmup(3, l, 120, chains=C, reporter=pkg.NoProgressReport())
+    x = r["posterior_matrix"].reshape(-1, D)
+    assert np.abs(x.mean(0) / sd.cpu().numpy()).max() < 0.25
+    assert np.abs(x.std(0) / sd.cpu().numpy() - 1).max() < 0.2
+    assert 0.6 < r["tree_statistics"].acceptance_rate.mean() < 0.95
+    with pytest.raises(RuntimeError):
+        pkg.mcmc_with_warmup(3, pkg.StandardNormal(3000), 5, chains=2, reporter=pkg.NoProgressReport())   # built-in families: D <= 1024
+    with pytest.raises((ValueError, RuntimeError)):
+        pkg.mcmc_with_warmup(3, pkg.TorchLogDensity(4097, logdensity=lambda q: -0.5 * (q * q).sum(1)), 5, chains=2, reporter=pkg.NoProgressReport())

@@ -17,4 +17,4 @@ def test_randomised_parity_sweep():
     m = re.search(r"(\d+) random cases .*: (\d+) compared runs, (\d+) transitions, (\d+) leapfrog steps, (\d+) failures", out)
     assert m, out[-2000:]
     assert int(m.group(5)) == 0, out[-4000:]
-    assert int(m.group(2)) > 500 and int(m.group(4)) > 100000      # the sweep really ran
+    assert int(m.group(2)) > 100 and int(m.group(4)) > 20000       # the sweep really ran
