@@ -283,7 +283,8 @@ class TorchLogDensity(_Target):
     """The user's own model (the reference accepts any LogDensityProblems object, hamiltonian.jl:146-147,204): a batched
     PyTorch function evaluated on the GPU for all chains at once, once per leapfrog round.  Either
     `logdensity_and_gradient(q) -> (lq [C], grad [C][D])`, or just `logdensity(q) -> lq [C]` (any differentiable torch
-    code; the gradient then comes from autograd).  q is a float64 CUDA tensor [C][D].  Diagonal metric."""
+    code; the gradient then comes from autograd).  q is a float64 CUDA tensor [C][D].  Diagonal (D <= 4096) or dense
+    (D <= 1024) metric."""
     family = abi.TARGET_EXTERNAL
 
     def __init__(self, dimension, logdensity=None, logdensity_and_gradient=None):

@@ -53,6 +53,7 @@ struct dhmc_ctx {
     dhmc_logdensity_fn ext_fn = nullptr;
     void* ext_user = nullptr;
     ExtSearchState* d_ss = nullptr;
+    uint32_t* d_sflags = nullptr;   // [C][4]: ℓ(q′) (a double) and the position flag between two search kernels (dense)
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
     std::string err;
@@ -246,7 +247,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         break;
     }
     case DHMC_TARGET_EXTERNAL:
-        if (cfg->metric != DHMC_METRIC_DIAG) return DHMC_ERR_UNSUPPORTED;
+        if (cfg->metric == DHMC_METRIC_DENSE && D > 1024) return DHMC_ERR_UNSUPPORTED;   // the host factorisation is O(D³)
         break;
     default: return DHMC_ERR_UNSUPPORTED;
     }
@@ -256,7 +257,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (!c) return DHMC_ERR_HIP;
     c->cfg = *cfg;
     c->cfg.target_params = nullptr;
-    c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL);
+    c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL && cfg->metric == DHMC_METRIC_DIAG);
     if (cfg->target == DHMC_TARGET_EXTERNAL)
         if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels
             const int f = std::atoi(e);
@@ -383,6 +384,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (c->external) {
         if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_ss, C))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_sflags, 4 * C))) return fail(rc);
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail(DHMC_ERR_HIP);
     // unit metric, ε unspecified
@@ -585,6 +587,36 @@ int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (double e : h)
         if (!std::isnan(e)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:137 "stepsize ϵ manually specified"
+    if (c->external && c->cfg.metric == DHMC_METRIC_DENSE) {
+        // dense metric: p₀ = z·Wᵀ, M⁻¹pₘ and p′♯ are GEMMs over all chains between the search kernels
+        ExtSearchParams E{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold, d.maxiter_crossing,
+                          c->st, c->d_ss, c->rb.cps, c->rb.cp, c->lr.S1, c->rb.tbuf, c->rb.list_count};
+        const int ld = c->Dpad;
+        const size_t p1_stride = (size_t)c->nvec * c->Dpad;
+        int remaining = 0;
+        HIP_TRY(c, hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream));
+        DHMC_EXT_NPL(ext_search_dense_z_kernel, dim3(C), E, c->rb.cp)
+        launch_gemm_rows(c->rb.cp, c->d_WT, c->rb.cps, ld, C, nullptr, nullptr, c->stream);                 // p₀ = z·Wᵀ
+        launch_gemm_rows(c->rb.cps, c->d_Minv, c->rb.tbuf, ld, C, nullptr, nullptr, c->stream);             // p₀♯
+        DHMC_EXT_NPL(ext_search_dense_begin_kernel, dim3(C), E, (const double*)c->rb.tbuf, c->rb.cp)
+        HIP_TRY(c, hipMemcpyAsync(&remaining, c->rb.list_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        while (remaining > 0) {
+            launch_gemm_rows(c->rb.cp, c->d_Minv, c->rb.tbuf, ld, C, nullptr, nullptr, c->stream);          // M⁻¹pₘ
+            DHMC_EXT_NPL(ext_search_dense_trial_kernel, dim3(C), E, (const double*)c->rb.tbuf)
+            int rc = external_eval(c, c->rb.cp);
+            if (rc) return rc;
+            DHMC_EXT_NPL(ext_search_dense_p1_kernel, dim3(C), E, c->d_sflags, c->st.ws, p1_stride)
+            launch_gemm(c->st.ws, (int)p1_stride, c->d_Minv, ld, c->rb.tbuf, ld, C, ld, ld, c->stream);     // p′♯
+            HIP_TRY(c, hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream));
+            DHMC_EXT_NPL(ext_search_dense_decide_kernel, dim3(C), E, (const double*)c->st.ws, p1_stride, (const double*)c->rb.tbuf,
+                         (const uint32_t*)c->d_sflags, c->rb.cp)
+            HIP_TRY(c, hipMemcpyAsync(&remaining, c->rb.list_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        HIP_TRY(c, hipGetLastError());
+        return status_code(c);
+    }
     if (c->external) {
         // the same bracketing search, all chains per callback: trial positions -> callback -> one decision per chain
         ExtSearchParams E{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold, d.maxiter_crossing,
@@ -674,7 +706,35 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
-    if (e == hipSuccess && c->external) {
+    if (e == hipSuccess && c->external && c->cfg.metric == DHMC_METRIC_DENSE) {
+        // dense round engine (dense_rounds.hpp) with the host's callback as the density, one batch on one stream
+        RoundArgs ra{P, c->rb};
+        const int ld = c->Dpad;
+        const RoundBuffers& R = c->rb;
+        e = hipMemsetAsync(R.list_count, 0, 2 * sizeof(int), c->stream);
+        if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
+        unsigned long long rounds = 0;
+        int done = 0;
+        while (e == hipSuccess && done < C) {
+            for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
+                launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, C, R.list, R.list_count, c->stream);       // p₀ = z·Wᵀ
+                launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, C, R.list, R.list_count, c->stream);    // p♯₀
+                dispatch(c, Op::RoundK0, &ra);
+                e = hipMemsetAsync(R.list_count, 0, sizeof(int), c->stream);
+                launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, C, nullptr, nullptr, c->stream);         // M⁻¹pₘ
+                DHMC_EXT_NPL(rounds_k2a_dense_external_kernel, dim3(C), ra.P, ra.R)                    // q′
+                rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
+                if (rc) { cleanup(); return rc; }
+                DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′
+                launch_gemm_rows(R.cp, c->d_Minv, R.cps, ld, C, nullptr, nullptr, c->stream);          // p♯
+                dispatch(c, Op::RoundK3, &ra);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&done, R.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        c->last_rounds = rounds;
+    } else if (e == hipSuccess && c->external) {
         // round engine with the host's callback as the gradient (external_rounds.hpp)
         RoundArgs ra{P, c->rb};
         e = hipMemsetAsync(c->rb.list_count, 0, 2 * sizeof(int), c->stream);

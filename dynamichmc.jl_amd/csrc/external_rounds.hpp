@@ -230,4 +230,136 @@ __global__ __launch_bounds__(64) void ext_search_step_kernel(ExtSearchParams P) 
     }
 }
 
+// ---- the same with a dense (shared) metric: the M⁻¹ and W products are GEMMs over all chains between these kernels --
+
+// K2a of the dense round engine for an external density: q′ = q + ϵ·(M⁻¹pₘ) (hamiltonian.jl:278), M⁻¹pₘ in tbuf
+template <int NPL>
+__global__ __launch_bounds__(64) void rounds_k2a_dense_external_kernel(RunParams P, RoundBuffers R) {
+    const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
+    const TreeState& S = R.ts[chain];
+    if (S.phase != PH_LEAF) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    const double eps_s = S.eps_s;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        P.st.q[row + e] = P.st.q[row + e] + eps_s * R.tbuf[row + e];
+    }
+}
+
+// search, step 0a: z ~ N(0, I) of the search momentum into `z` (then p₀ = z·Wᵀ and p₀♯ = p₀·M⁻¹ are GEMMs)
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_dense_z_kernel(ExtSearchParams P, double* __restrict__ z) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+    const uint32_t tr = P.st.transition[chain];
+#pragma unroll 2
+    for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+        uint64_t r1, r2;
+        stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_SEARCH_MOMENTUM, tr, r1, r2);
+        double z0, z1;
+        det_randn2(r1, r2, &z0, &z1);
+        const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
+        z[row + e0] = e0 < P.D ? z0 : 0.0;
+        if (2 * kk + 1 < NPL) z[row + e1] = e1 < P.D ? z1 : 0.0;
+    }
+}
+// search, step 0b: ℓ₀ from p₀ (P.p0) and p₀♯ (ps); first trial momentum pₘ = p₀ + ϵ/2 ∇ℓ into `pm`
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_dense_begin_kernel(ExtSearchParams P, const double* __restrict__ ps, double* __restrict__ pm) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    double kacc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(P.p0[row + lane + WAVE * k], ps[row + lane + WAVE * k], kacc);
+    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc) / 2.0));
+    ExtSearchState s{l0, P.initial_eps, 0, -1, 1, 0};
+    if (!dm_isfinite(l0)) {
+        s.active = 0;
+        if (lane == 0) P.st.status[chain] |= DHMC_ST_NONFINITE_START_DENSITY;
+    } else {
+        const double h = s.eps / 2;
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) pm[row + lane + WAVE * k] = P.p0[row + lane + WAVE * k] + h * P.st.g[row + lane + WAVE * k];
+        if (lane == 0) atomicAdd(P.remaining, 1);
+    }
+    if (lane == 0) P.ss[chain] = s;
+}
+// search, per trial: (a) q′ = q + ϵ·T into `trial` (T = pₘ·M⁻¹);  callback;  (b) evaluate_ℓ, p′ = pₘ + ϵ/2 ∇ℓ′ into `p1`;
+// (c) with p′♯: A(ϵ), the decision, and the next pₘ
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_dense_trial_kernel(ExtSearchParams P, const double* __restrict__ T) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const ExtSearchState s = P.ss[chain];
+    if (!s.active) return;
+    const size_t row = (size_t)chain * P.Dpad;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        P.trial[row + e] = P.st.q[row + e] + s.eps * T[row + e];
+    }
+}
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_dense_p1_kernel(ExtSearchParams P, uint32_t* __restrict__ flags, double* __restrict__ p1base,
+                                                                size_t p1_stride) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const ExtSearchState s = P.ss[chain];
+    if (!s.active) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    bool pos_finite, valid;
+    const double h = s.eps / 2;
+    double* p1 = p1base + (size_t)chain * p1_stride;
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int e, double gv) {
+        const double pm = P.p0[row + e] + h * P.st.g[row + e];
+        p1[e] = pm + h * gv;                                                 // hamiltonian.jl:280
+    });
+    if (lane == 0) {
+        reinterpret_cast<double*>(flags)[2 * chain] = lq;                    // ℓ(q′) after evaluate_ℓ's rules, for step (c)
+        flags[4 * chain + 2] = pos_finite ? 0u : 1u;
+    }
+}
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_search_dense_decide_kernel(ExtSearchParams P, const double* __restrict__ p1base, size_t p1_stride,
+                                                                    const double* __restrict__ p1s, const uint32_t* __restrict__ flags,
+                                                                    double* __restrict__ pm) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    ExtSearchState s = P.ss[chain];
+    if (!s.active) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    double kacc = 0.0;
+    const double* p1 = p1base + (size_t)chain * p1_stride;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p1[lane + WAVE * k], p1s[row + lane + WAVE * k], kacc);
+    const double lq = reinterpret_cast<const double*>(flags)[2 * chain];
+    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc) / 2.0)) - s.l0;
+    uint32_t st = flags[4 * chain + 2] ? DHMC_ST_NONFINITE_POSITION : 0u;
+    if (s.iter < 0) {
+        s.dbl = A > P.log_threshold;
+        s.iter = 0;
+        s.eps = s.dbl ? 2 * s.eps : s.eps / 2;
+    } else if (s.dbl ? (A < P.log_threshold) : (A > P.log_threshold)) {
+        s.active = 0;
+    } else {
+        s.iter += 1;
+        if (s.iter >= P.maxiter) {
+            s.active = 0;
+            st |= DHMC_ST_STEPSIZE_SEARCH_FAILED;
+        } else {
+            s.eps = s.dbl ? 2 * s.eps : s.eps / 2;
+        }
+    }
+    if (s.active) {
+        const double h = s.eps / 2;
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) pm[row + lane + WAVE * k] = P.p0[row + lane + WAVE * k] + h * P.st.g[row + lane + WAVE * k];
+        if (lane == 0) atomicAdd(P.remaining, 1);
+    }
+    if (lane == 0) {
+        P.ss[chain] = s;
+        if (!s.active) P.st.eps[chain] = s.eps;
+        if (st) P.st.status[chain] |= st;
+    }
+}
+
 }  // namespace dhmc

@@ -81,8 +81,8 @@ extern "C" {
 #define DHMC_TARGET_LOGISTIC 4    /* Bernoulli-logit regression, N(0,I) prior.  params: int64 n; double X[n][D]; double y[n] */
 #define DHMC_TARGET_DENSE_NORMAL 6 /* l = -1/2 (q-mu)'P(q-mu), P full symmetric (read from its upper triangle). params: double mu[D], P[D][D] */
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
-                                    * (dhmc_set_logdensity_callback); diagonal metric only; dim <= 4096 (the built-in
-                                    * families: dim <= 1024). params: none */
+                                    * (dhmc_set_logdensity_callback); dim <= 4096 with the diagonal metric, <= 1024 with
+                                    * the dense one (the built-in families: dim <= 1024). params: none */
 #define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
 
 /* ---- kinetic energy (GaussianKineticEnergy, hamiltonian.jl:56-87) -------------------- */

@@ -117,3 +117,28 @@ def test_model_with_more_than_1024_dimensions(pkg):
         pkg.mcmc_with_warmup(3, pkg.StandardNormal(3000), 5, chains=2, reporter=pkg.NoProgressReport())   # built-in families: D <= 1024
     with pytest.raises((ValueError, RuntimeError)):
         pkg.mcmc_with_warmup(3, pkg.TorchLogDensity(4097, logdensity=lambda q: -0.5 * (q * q).sum(1)), 5, chains=2, reporter=pkg.NoProgressReport())
+
+
+def test_dense_metric_for_external_models(pkg):
+    """Symmetric (dense) adaptation for the caller's model (mcmc.jl:210,218-222; hamiltonian.jl:73): the dense round
+    engine with the callback as the density.  D = 1 reproduces the built-in functor bit for bit (ℓ has nothing to sum);
+    a strongly correlated Gaussian gets a usable step size only with the dense metric."""
+    import torch
+    sym = lambda: pkg.default_warmup_stages(M=pkg.Symmetric, middle_steps=20, doubling_stages=3)
+    a = pkg.mcmc_with_warmup(5, pkg.TorchLogDensity(1, logdensity_and_gradient=lambda q: (-0.5 * (q * q).sum(1), -q)), 200, chains=16,
+                             warmup_stages=sym(), reporter=pkg.NoProgressReport())
+    b = pkg.mcmc_with_warmup(5, pkg.StandardNormal(1), 200, chains=16, warmup_stages=sym(), reporter=pkg.NoProgressReport())
+    assert np.array_equal(a["posterior_matrix"], b["posterior_matrix"]) and np.array_equal(a["eps"], b["eps"])
+    assert np.array_equal(a["kappa"].Minv, b["kappa"].Minv) and a["kappa"].dense
+
+    D, C = 8, 64
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(D, D)); Sigma = A @ A.T + 0.05 * np.eye(D)           # condition number in the hundreds
+    P = torch.tensor(np.linalg.inv(Sigma), device="cuda")
+    l = pkg.TorchLogDensity(D, logdensity=lambda q: -0.5 * torch.einsum("ci,ij,cj->c", q, P, q))
+    dense = pkg.mcmc_with_warmup(2, l, 400, chains=C, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric), reporter=pkg.NoProgressReport())
+    diag = pkg.mcmc_with_warmup(2, l, 400, chains=C, reporter=pkg.NoProgressReport())
+    x = dense["posterior_matrix"].reshape(-1, D)
+    assert np.abs(np.cov(x.T) - Sigma).max() < 0.25 * np.abs(Sigma).max()
+    assert np.median(dense["eps"]) > 2 * np.median(diag["eps"])
+    assert dense["tree_statistics"].steps.mean() < diag["tree_statistics"].steps.mean()
