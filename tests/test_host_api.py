@@ -123,3 +123,18 @@ def test_shard_chains(pkg):
         assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
         for (o1, c1), (o2, _) in zip(blocks, blocks[1:]):
             assert o1 + c1 == o2
+
+
+def test_external_target_host_side(pkg):
+    """TorchLogDensity: exactly one of logdensity / logdensity_and_gradient; the family id and the callback contract."""
+    with pytest.raises(ValueError):
+        pkg.TorchLogDensity(3)
+    with pytest.raises(ValueError):
+        pkg.TorchLogDensity(3, logdensity=lambda q: q.sum(1), logdensity_and_gradient=lambda q: (q.sum(1), q))
+    l = pkg.TorchLogDensity(3, logdensity_and_gradient=lambda q: (q.sum(1), q))
+    assert l.family == pkg.abi.TARGET_EXTERNAL and l.dimension() == 3 and l.params() is None and l.capabilities() >= 1
+    import torch
+    f = pkg.TorchLogDensity(2, logdensity=lambda q: -0.5 * (q * q).sum(1)).callback()     # gradient by autograd, on any device
+    q = torch.tensor([[1.0, -2.0], [0.5, 0.0]], dtype=torch.float64)
+    lq, g = f(q)
+    assert torch.equal(lq, torch.tensor([-2.5, -0.125], dtype=torch.float64)) and torch.equal(g, -q)
