@@ -203,7 +203,6 @@ class DeviceContext:
         """`fn(q) -> (lq, grad)` with q a CUDA torch tensor [C][D] (a view of the library's buffer: do not keep it),
         lq [C], grad [C][D]: the LogDensityProblems.logdensity_and_gradient of all chains at once (hamiltonian.jl:204).
         Called once per leapfrog round on the context's stream."""
-        import contextlib
         import torch
 
         class _Dev:     # a raw device pointer as a zero-copy torch tensor
@@ -214,7 +213,8 @@ class DeviceContext:
 
         def trampoline(user, q_ptr, chains, ld, dim, lq_ptr, grad_ptr, stream):
             try:
-                ctxm = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)) if stream else contextlib.nullcontext()
+                # run the model on the stream the library's kernels are on (a null handle is the device's default stream)
+                ctxm = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev))
                 with ctxm:
                     q = torch.as_tensor(_Dev(q_ptr, (chains, ld), (ld * 8, 8)), device=dev)[:, :dim]
                     lq_out = torch.as_tensor(_Dev(lq_ptr, (chains,), (8,)), device=dev)
