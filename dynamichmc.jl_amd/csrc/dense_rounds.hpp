@@ -262,7 +262,6 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
 
     // ---- the leaf (NUTS.jl:148-159) -----------------------------------------------------------
     const bool fwd = S.dir == 1;
-    const int dir = S.dir;
     const int64_t di = fwd ? 1 : -1;
     const uint32_t j = S.j, nleaf = S.nleaf;
     const int depth0 = S.depth;

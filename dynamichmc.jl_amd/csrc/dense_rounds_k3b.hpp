@@ -208,7 +208,6 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
             if (!sub && !top) break;
             auto a_cf = [&](int k) { return cf[k]; };
             auto a_cfs = [&](int k) { return cfs[k]; };
-            auto a_p = [&](int k) { return p[k]; };
             auto a_ps = [&](int k) { return ps[k]; };
             auto a_cr = [&](int k) { return cr[k]; };
             bool turning;
