@@ -121,18 +121,18 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
     // streamed slot by slot (no register arrays: chains of up to 64 slots per lane come through here)
     const double* __restrict__ p0row = R.tbuf + row;
     const double* __restrict__ psrow = R.cps + row;
-    double kacc = 0.0;
-#pragma unroll 4
+    LaneAcc<1, NPL> kacc;
+#pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
         const double pk = p0row[e], psk = psrow[e];
-        kacc = __builtin_fma(pk, psk, kacc);
+        kacc.add(0, k, pk, psk);
         wsv(wd_top(0))[e] = pk; wsv(wd_top(1))[e] = psk;              // leaf τ of z₀ (NUTS.jl:120-123)
         wsv(wd_top(2))[e] = pk; wsv(wd_top(3))[e] = psk;
         wsv(wd_top(4))[e] = pk;
     }
     const double lq_cur = S.lq_cur;
-    const double pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
+    const double pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     uint32_t w[4];
     philox4x32_10(0u, PURPOSE_DIRECTIONS, S.tr, key.seed_hi, key.k0, key.k1, w);
@@ -265,11 +265,11 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     const int64_t di = fwd ? 1 : -1;
     const uint32_t j = S.j, nleaf = S.nleaf;
     const int depth0 = S.depth;
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], ps[k], kacc);
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], ps[k]);
     const double lq_leaf = S.lq_leaf;
-    const double pi_leaf = uni_f64(joint_logdensity(lq_leaf, wave_allreduce1(kacc) / 2.0));
+    const double pi_leaf = uni_f64(joint_logdensity(lq_leaf, wave_allreduce1(kacc.fold(0)) / 2.0));
     int64_t i = S.i + di;
     S.total_steps += 1;
     const double delta = pi_leaf - S.pi0;

@@ -1,15 +1,15 @@
-// K3 of the round engines (dense_rounds.hpp) as a WORKGROUP per chain: four (NPL 8, 16), eight (NPL 32) or sixteen
-// (NPL 64) waves, each owning NT consecutive slots of the chain (wave w: slots k = w·NT … w·NT+NT-1), for chains of
-// 512+ coordinates.
+// K3 of the round engines (dense_rounds.hpp) as a WORKGROUP per chain: one wave per 256-coordinate BLOCK of the chain
+// (NPL 8: two waves, 16: four, 32: eight, 64: sixteen), wave w owning slots k = 4w … 4w+3, for chains of 512+
+// coordinates.
 //
 // Why: the one-wave-per-chain K3 needs the whole 512-register budget of a SIMD lane at NPL = 16 (one wave per SIMD),
 // so it can neither hide its HBM latency behind other waves nor share a CU with the other half-batch's GEMM.  This
-// form holds 5 × NT doubles per lane (≈100 VGPRs), runs 4+ waves per SIMD and co-resides with the MFMA waves.
+// form holds 5 × 4 doubles per lane (≈100 VGPRs), runs 4+ waves per SIMD and co-resides with the MFMA waves.
 //
-// The bits do not change.  A dot product in the ABI's order is, per lane, ONE fma chain over the slots k ascending,
-// then the 64-lane butterfly: here wave 0 runs the chain over its slots, hands the 64 partial accumulators to wave 1
-// through LDS, … and wave 3 finishes the chain and does the butterfly (chain_allreduce) — serial across the four
-// waves, but only NT fma's per wave, and the operands were loaded by all waves in parallel beforehand.
+// The bits do not change: the ABI's dot product (wave.hpp LaneAcc) is, per lane, one fma chain per 256-coordinate
+// block, the blocks' partial sums combined per lane by an adjacent-pairs tree, then the 64-lane butterfly — so every
+// wave runs its own block's chain in parallel with the others, leaves 64 partial sums in LDS, and after one barrier
+// every wave folds the blocks and does the butterfly itself (block_allreduce): no serial hand-over between waves.
 // Every thread executes the scalar tree logic redundantly on private copies of the chain's mutable scalars (a
 // read-modify-write of the shared TreeState by four unsynchronised waves would race); arrays of the TreeState are
 // only ever overwritten with values every thread computes identically.  Gradients of suspended points are always
@@ -20,45 +20,42 @@
 
 namespace dhmc {
 
-// waves per chain: four slots per lane and wave (NPL 16 -> 4 waves, 32 -> 8, 64 -> 16 = a 1024-thread workgroup)
-__host__ __device__ constexpr int k3b_waves(int NPL) { return NPL >= 16 ? NPL / 4 : 4; }
+// waves per chain: one per block of four slots per lane (NPL 8 -> 2 waves, 16 -> 4, 32 -> 8, 64 -> 16 = a 1024-thread workgroup)
+__host__ __device__ constexpr int k3b_waves(int NPL) { return NPL / 4; }
 
 template <int N, int WPC, class Step>
-__device__ __forceinline__ void chain_allreduce(int wave, int lane, double (*xch)[WAVE], double* red, Step step, double (&out)[N]) {
+__device__ __forceinline__ void block_allreduce(int wave, int lane, double (*xch)[WPC][WAVE], Step step, double (&out)[N]) {
     double acc[N];
-    for (int w = 0; w < WPC; ++w) {
-        if (wave == w) {
 #pragma unroll
-            for (int n = 0; n < N; ++n) acc[n] = w == 0 ? 0.0 : xch[n][lane];
-            step(acc);
-            if (w + 1 < WPC) {
+    for (int n = 0; n < N; ++n) acc[n] = 0.0;
+    step(acc);                                   // this wave's block: one fma chain per dot
 #pragma unroll
-                for (int n = 0; n < N; ++n) xch[n][lane] = acc[n];
-            } else {
-                wave_allreduce<N>(acc);
-                if (lane == 0) {
-#pragma unroll
-                    for (int n = 0; n < N; ++n) red[n] = acc[n];
-                }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) out[n] = red[n];
+    for (int n = 0; n < N; ++n) xch[n][wave][lane] = acc[n];
     __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        double t[WPC];
+#pragma unroll
+        for (int w = 0; w < WPC; ++w) t[w] = xch[n][w][lane];
+#pragma unroll
+        for (int s = 1; s < WPC; s *= 2)
+#pragma unroll
+            for (int w = 0; w + s < WPC; w += 2 * s) t[w] = t[w] + t[w + s];
+        out[n] = t[0];
+    }
+    wave_allreduce<N>(out);
+    __syncthreads();                             // xch is free again
 }
 
 template <class T, int NPL>
 __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunParams P, RoundBuffers R) {
     constexpr int K3B_WPC = k3b_waves(NPL);
-    static_assert(NPL % (2 * K3B_WPC) == 0, "each wave owns an even number of slots (the momentum stream yields pairs)");
     constexpr int NT = NPL / K3B_WPC;
+    static_assert(NT == 4, "one 256-coordinate block of the ABI's dot product per wave");
     const int chain = P.chain_base + blockIdx.x;
     if (R.ts[chain].phase != PH_LEAF) return;
     __shared__ TreeState S;
-    __shared__ double xch[6][WAVE];
-    __shared__ double red[6];
+    __shared__ double xch[6][K3B_WPC][WAVE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&R.ts[chain]);
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
 #pragma unroll
         for (int k = 0; k < NT; ++k) { cf[k] = nf[k]; cfs[k] = nfs[k]; cr[k] = rr[k]; }
         double acc[6];
-        chain_allreduce<6, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[6]) {
+        block_allreduce<6, K3B_WPC>(wave, lane, xch, [&](double (&a)[6]) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 a[0] = __builtin_fma(xms[k], s1[k], a[0]);
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
             cr[k] = rr[k];
         }
         double acc[2];
-        chain_allreduce<2, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[2]) {
+        block_allreduce<2, K3B_WPC>(wave, lane, xch, [&](double (&a)[2]) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 a[0] = __builtin_fma(pas[k], rr[k], a[0]);
@@ -181,7 +178,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     const uint32_t j = jleaf;
     const int depth0 = depth;
     double kin[1];
-    chain_allreduce<1, K3B_WPC>(wave, lane, xch, red, [&](double (&a)[1]) {
+    block_allreduce<1, K3B_WPC>(wave, lane, xch, [&](double (&a)[1]) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) a[0] = __builtin_fma(p[k], ps[k], a[0]);
     }, kin);

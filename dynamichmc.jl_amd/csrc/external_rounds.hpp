@@ -24,13 +24,13 @@ template <int NPL, class Each>
 __device__ __forceinline__ double external_evaluate(const double* __restrict__ qrow, const double* __restrict__ grow, int lane, int D,
                                                     double lq_in, bool& pos_finite, bool& valid, Each each) {
     bool qfin = true, gfin = true;
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
         const double gv = e < D ? grow[e] : 0.0;      // padding columns of the callback's output are ignored
         qfin = qfin && dm_isfinite(qrow[e]);
         gfin = gfin && dm_isfinite(gv);
-        each(e, gv);
+        each(k, e, gv);
     }
     pos_finite = wave_all(qfin);
     const bool grad_finite = wave_all(gfin);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void external_init_finish_kernel(int D, int Dpa
     bool pos_finite, valid;
     double* gdst = st.g + row;
     const double lq = external_evaluate<NPL>(st.q + row, grad_in + row, lane, D, lq_in[chain], pos_finite, valid,
-                                             [&](int e, double gv) { gdst[e] = gv; });
+                                             [&](int k, int e, double gv) { gdst[e] = gv; });
     if (lane == 0) {
         st.lq[chain] = lq;
         uint32_t s = 0;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void rounds_k2_external_kernel(RunParams P, Rou
     double* cp = R.cp + row;
     double* cps = R.cps + row;
     const double* minv = P.st.minv + row;
-    const double lq = external_evaluate<NPL>(P.st.q + row, R.tbuf + row, lane, P.D, L.S1[chain], pos_finite, valid, [&](int e, double gv) {
+    const double lq = external_evaluate<NPL>(P.st.q + row, R.tbuf + row, lane, P.D, L.S1[chain], pos_finite, valid, [&](int k, int e, double gv) {
         gdst[e] = gv;
         const double p1 = cp[e] + h * gv;                                  // hamiltonian.jl:280
         cp[e] = p1;
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(64) void ext_search_begin_kernel(ExtSearchParams P)
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     // p = W∘z (sample_momentum's stream and order), K = ½ p·M⁻¹p in the ABI's order, slot by slot
     const uint32_t tr = P.st.transition[chain];
-    double kacc = 0.0;
-#pragma unroll 2
+    LaneAcc<1, NPL> kacc;
+#pragma unroll
     for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_SEARCH_MOMENTUM, tr, r1, r2);
@@ -168,14 +168,14 @@ __global__ __launch_bounds__(64) void ext_search_begin_kernel(ExtSearchParams P)
         const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
         const double pa = P.st.W[row + e0] * z0;
         P.p0[row + e0] = pa;
-        kacc = __builtin_fma(pa, P.st.minv[row + e0] * pa, kacc);
+        kacc.add(0, 2 * kk, pa, P.st.minv[row + e0] * pa);
         if (2 * kk + 1 < NPL) {
             const double pb = P.st.W[row + e1] * z1;
             P.p0[row + e1] = pb;
-            kacc = __builtin_fma(pb, P.st.minv[row + e1] * pb, kacc);
+            kacc.add(0, 2 * kk + 1, pb, P.st.minv[row + e1] * pb);
         }
     }
-    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc) / 2.0));
+    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc.fold(0)) / 2.0));
     ExtSearchState s{l0, P.initial_eps, 0, -1, 1, 0};
     if (!dm_isfinite(l0)) {   // stepsize.jl:77-79
         s.active = 0;
@@ -195,13 +195,13 @@ __global__ __launch_bounds__(64) void ext_search_step_kernel(ExtSearchParams P) 
     const size_t row = (size_t)chain * P.Dpad;
     bool pos_finite, valid;
     const double h = s.eps / 2;
-    double kacc = 0.0;
-    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int e, double gv) {
+    LaneAcc<1, NPL> kacc;
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int k, int e, double gv) {
         const double pm = P.p0[row + e] + h * P.st.g[row + e];
         const double p1 = pm + h * gv;                                       // hamiltonian.jl:280
-        kacc = __builtin_fma(p1, P.st.minv[row + e] * p1, kacc);
+        kacc.add(0, k, p1, P.st.minv[row + e] * p1);
     });
-    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc) / 2.0)) - s.l0;   // stepsize.jl:81-83
+    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc.fold(0)) / 2.0)) - s.l0;   // stepsize.jl:81-83
     uint32_t st = 0;
     if (!pos_finite) st |= DHMC_ST_NONFINITE_POSITION;
     if (s.iter < 0) {                       // A(initial ϵ): which way to go (stepsize.jl:49-50)
@@ -270,10 +270,10 @@ template <int NPL>
 __global__ __launch_bounds__(64) void ext_search_dense_begin_kernel(ExtSearchParams P, const double* __restrict__ ps, double* __restrict__ pm) {
     const int chain = blockIdx.x, lane = threadIdx.x;
     const size_t row = (size_t)chain * P.Dpad;
-    double kacc = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(P.p0[row + lane + WAVE * k], ps[row + lane + WAVE * k], kacc);
-    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc) / 2.0));
+    LaneAcc<1, NPL> kacc;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, P.p0[row + lane + WAVE * k], ps[row + lane + WAVE * k]);
+    const double l0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc.fold(0)) / 2.0));
     ExtSearchState s{l0, P.initial_eps, 0, -1, 1, 0};
     if (!dm_isfinite(l0)) {
         s.active = 0;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void ext_search_dense_p1_kernel(ExtSearchParams
     bool pos_finite, valid;
     const double h = s.eps / 2;
     double* p1 = p1base + (size_t)chain * p1_stride;
-    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int e, double gv) {
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int k, int e, double gv) {
         const double pm = P.p0[row + e] + h * P.st.g[row + e];
         p1[e] = pm + h * gv;                                                 // hamiltonian.jl:280
     });
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(64) void ext_search_dense_decide_kernel(ExtSearchPa
     ExtSearchState s = P.ss[chain];
     if (!s.active) return;
     const size_t row = (size_t)chain * P.Dpad;
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
     const double* p1 = p1base + (size_t)chain * p1_stride;
-#pragma unroll 4
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p1[lane + WAVE * k], p1s[row + lane + WAVE * k], kacc);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, p1[lane + WAVE * k], p1s[row + lane + WAVE * k]);
     const double lq = reinterpret_cast<const double*>(flags)[2 * chain];
-    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc) / 2.0)) - s.l0;
+    const double A = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc.fold(0)) / 2.0)) - s.l0;
     uint32_t st = flags[4 * chain + 2] ? DHMC_ST_NONFINITE_POSITION : 0u;
     if (s.iter < 0) {
         s.dbl = A > P.log_threshold;

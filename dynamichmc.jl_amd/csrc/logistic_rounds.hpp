@@ -109,13 +109,13 @@ __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, Rou
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(R.tbuf + row, lane, g);     // (Xᵀ r)
     ldv<NPL>(R.cp + row, lane, p);
-    double qq = 0.0;
+    LaneAcc<1, NPL> qq;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
-        qq = __builtin_fma(q[k], q[k], qq);
+        qq.add(0, k, q[k], q[k]);
         g[k] = g[k] - q[k];
     }
-    double lq = uni_f64(L.S1[chain] - 0.5 * wave_allreduce1(qq));
+    double lq = uni_f64(L.S1[chain] - 0.5 * wave_allreduce1(qq.fold(0)));
     bool pos_finite = true;
     if (!dm_isfinite(lq)) pos_finite = all_finite<LogisticT, NPL>(q);
     lq = demote_lq(lq, pos_finite, true);

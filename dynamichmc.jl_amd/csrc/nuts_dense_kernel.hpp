@@ -66,18 +66,18 @@ __device__ __forceinline__ void leapfrog_leaf_dense(const T& tgt, const DenseMet
 #pragma unroll
     for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];        // :280
     sym_matvec<NPL>(M.Minv, Dpad, D, lane, p, ps);               // p♯ = M⁻¹ p′
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], ps[k], kacc);
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], ps[k]);
     double lq, K;
     if constexpr (T::kDeferred) {
-        double r[2] = {lres, kacc};
+        double r[2] = {lres, kacc.fold(0)};
         wave_allreduce<2>(r);
         lq = tgt.finish(r[0]);
         K = r[1] / 2.0;
     } else {
         lq = lres;
-        K = wave_allreduce1(kacc) / 2.0;
+        K = wave_allreduce1(kacc.fold(0)) / 2.0;
     }
     lq = uni_f64(lq);
     pos_finite = true;
@@ -95,7 +95,7 @@ template <int NPL, class XM, class XMS, class XP, class XPS, class XR, class YM,
 __device__ __forceinline__ bool merge_core_dense(XM xm_, XMS xms_, XP xp_, XPS xps_, XR xr_, YM ym_, YMS yms_, YP yp_,
                                                  YPS yps_, YR yr_, NF nf_, NFS nfs_, double (&cf)[NPL],
                                                  double (&cfs)[NPL], double (&cr)[NPL]) {
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    LaneAcc<6, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double xms = xms_(k), xp = xp_(k), xps = xps_(k), xr = xr_(k);
@@ -105,16 +105,18 @@ __device__ __forceinline__ bool merge_core_dense(XM xm_, XMS xms_, XP xp_, XPS x
         const double s1 = xr + ym;
         const double s2 = xp + yr;
         const double r = xr + yr;
-        acc[0] = __builtin_fma(xms, s1, acc[0]);
-        acc[1] = __builtin_fma(yms, s1, acc[1]);
-        acc[2] = __builtin_fma(xps, s2, acc[2]);
-        acc[3] = __builtin_fma(yps, s2, acc[3]);
-        acc[4] = __builtin_fma(xms, r, acc[4]);
-        acc[5] = __builtin_fma(yps, r, acc[5]);
+        A.add(0, k, xms, s1);
+        A.add(1, k, yms, s1);
+        A.add(2, k, xps, s2);
+        A.add(3, k, yps, s2);
+        A.add(4, k, xms, r);
+        A.add(5, k, yps, r);
         cf[k] = nf;
         cfs[k] = nfs;
         cr[k] = r;
     }
+    double acc[6];
+    A.fold_all(acc);
     wave_allreduce<6>(acc);
     return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
 }
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         const uint32_t directions0 = dirs;
         double pi0;
         {
-            double kacc = 0.0;
+            LaneAcc<1, NPL> kacc;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], ps[k], kacc);
-            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
+            for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], ps[k]);
+            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
         }
         // leaf τ of z₀ (NUTS.jl:120-123)
         stv<NPL>(wsv(wd_top(0)), lane, p); stv<NPL>(wsv(wd_top(1)), lane, ps);
@@ -442,10 +444,10 @@ __global__ __launch_bounds__(64, 1) void stepsize_search_dense_kernel(SearchPara
     const double lq0 = P.st.lq[chain];
     uint32_t status = P.st.status[chain];
     sample_momentum_dense<NPL>(key, PURPOSE_SEARCH_MOMENTUM, P.st.transition[chain], M, Dpad, D, lane, p0, ps);
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p0[k], ps[k], kacc);
-    const double l0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc) / 2.0));
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, p0[k], ps[k]);
+    const double l0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc.fold(0)) / 2.0));
     if (!dm_isfinite(l0)) {
         if (lane == 0) P.st.status[chain] = status | DHMC_ST_NONFINITE_START_DENSITY;
         return;

@@ -147,22 +147,22 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
         p[k] = pm;
     }
     const double lres = tgt.eval(q, g, lane, D);     // :279 -> hamiltonian.jl:204
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         p[k] = p[k] + h * g[k];                      // :280
         double ps = m_lds[lane + WAVE * k] * p[k];   // p♯ = M⁻¹ p'
-        kacc = __builtin_fma(p[k], ps, kacc);
+        kacc.add(0, k, p[k], ps);
     }
     double lq, K;
     if constexpr (T::kDeferred) {
-        double r[2] = {lres, kacc};
+        double r[2] = {lres, kacc.fold(0)};
         wave_allreduce<2>(r);
         lq = tgt.finish(r[0]);
         K = r[1] / 2.0;
     } else {
         lq = lres;
-        K = wave_allreduce1(kacc) / 2.0;
+        K = wave_allreduce1(kacc.fold(0)) / 2.0;
     }
     // evaluate_ℓ's checks (hamiltonian.jl:203-211).  Every shipped family has "ℓq finite =>
     // all q finite" (kFiniteLqImpliesFiniteQ), so the coordinate scan runs only on the rare
@@ -190,7 +190,7 @@ template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, c
 __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_,
                                            const double* __restrict__ m_lds, int lane,
                                            double (&cf)[NPL], double (&cr)[NPL]) {
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    LaneAcc<6, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double xm = xm_(k), xp = xp_(k), xr = xr_(k);
@@ -204,15 +204,17 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
         const double b = mk * ym;       // y.p♯₋
         const double c = mk * xp;       // x.p♯₊
         const double d = mk * yp;       // y.p♯₊
-        acc[0] = __builtin_fma(a, s1, acc[0]);
-        acc[1] = __builtin_fma(b, s1, acc[1]);
-        acc[2] = __builtin_fma(c, s2, acc[2]);
-        acc[3] = __builtin_fma(d, s2, acc[3]);
-        acc[4] = __builtin_fma(a, r, acc[4]);
-        acc[5] = __builtin_fma(d, r, acc[5]);
+        A.add(0, k, a, s1);
+        A.add(1, k, b, s1);
+        A.add(2, k, c, s2);
+        A.add(3, k, d, s2);
+        A.add(4, k, a, r);
+        A.add(5, k, d, r);
         cf[k] = nf;
         cr[k] = r;
     }
+    double acc[6];
+    A.fold_all(acc);
     wave_allreduce<6>(acc);
     return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
 }
@@ -225,17 +227,19 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
 template <int NPL, class PA>
 __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, const double* __restrict__ m_lds, int lane,
                                                 double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL]) {
-    double acc[2] = {0.0, 0.0};
+    LaneAcc<2, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double pa = pa_(k);
         const double mk = m_lds[lane + WAVE * k];
         const double r = pa + pb[k];
-        acc[0] = __builtin_fma(mk * pa, r, acc[0]);
-        acc[1] = __builtin_fma(mk * pb[k], r, acc[1]);
+        A.add(0, k, mk * pa, r);
+        A.add(1, k, mk * pb[k], r);
         cf[k] = pa;
         cr[k] = r;
     }
+    double acc[2];
+    A.fold_all(acc);
     wave_allreduce<2>(acc);
     return acc[0] < 0 || acc[1] < 0;
 }
@@ -357,10 +361,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         const uint32_t directions0 = dirs;
         double pi0;
         {
-            double kacc = 0.0;
+            LaneAcc<1, NPL> kacc;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p[k], m_lds[lane + WAVE * k] * p[k], kacc);
-            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc) / 2.0));
+            for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], m_lds[lane + WAVE * k] * p[k]);
+            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; trho[k] = p[k]; }   // leaf τ of z₀ (NUTS.jl:120-123)
@@ -755,10 +759,10 @@ __global__ __launch_bounds__(64) void stepsize_search_kernel(SearchParams P) {
     const double lq0 = P.st.lq[chain];
     uint32_t status = P.st.status[chain];
     sample_momentum<NPL>(key, PURPOSE_SEARCH_MOMENTUM, P.st.transition[chain], P.st.W + row, lane, p0);
-    double kacc = 0.0;
+    LaneAcc<1, NPL> kacc;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) kacc = __builtin_fma(p0[k], m_lds[lane + WAVE * k] * p0[k], kacc);
-    const double l0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc) / 2.0));
+    for (int k = 0; k < NPL; ++k) kacc.add(0, k, p0[k], m_lds[lane + WAVE * k] * p0[k]);
+    const double l0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc.fold(0)) / 2.0));
     if (!dm_isfinite(l0)) {  // stepsize.jl:77-79
         if (lane == 0) P.st.status[chain] = status | DHMC_ST_NONFINITE_START_DENSITY;
         return;

@@ -88,13 +88,13 @@ __global__ __launch_bounds__(64, 1) void probe_kernel(ProbeParams P, DenseMetric
             if constexpr (DENSE) sample_momentum_dense<NPL>(key, PURPOSE_PROBE_MOMENTUM, P.momentum_index + (uint32_t)m, M, Dpad, D, lane, p0, ps0);
             else sample_momentum<NPL>(key, PURPOSE_PROBE_MOMENTUM, P.momentum_index + (uint32_t)m, P.st.W + row, lane, p0);
         }
-        double kacc = 0.0;
+        LaneAcc<1, NPL> kacc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             if constexpr (!DENSE) ps0[k] = lds[lane + WAVE * k] * p0[k];
-            kacc = __builtin_fma(p0[k], ps0[k], kacc);
+            kacc.add(0, k, p0[k], ps0[k]);
         }
-        const double pi0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc) / 2.0));
+        const double pi0 = uni_f64(joint_logdensity(lq0, wave_allreduce1(kacc.fold(0)) / 2.0));
         auto restart = [&]() {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) { S.q[k] = q0[k]; S.p[k] = p0[k]; S.g[k] = g0[k]; S.ps[k] = ps0[k]; }

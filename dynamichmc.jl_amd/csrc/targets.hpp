@@ -45,13 +45,13 @@ struct StdNormalT {
     __device__ explicit StdNormalT(const TargetParams&) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int, int) const {
-        double acc = 0.0;
+        LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            acc = __builtin_fma(q[k], q[k], acc);
+            acc.add(0, k, q[k], q[k]);
             g[k] = -q[k];
         }
-        return acc;
+        return acc.fold(0);
     }
     __device__ __forceinline__ double grad1(double qk, int) const { return -qk; }   // element e of ∇ℓ from q_e alone
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
@@ -69,15 +69,15 @@ struct DiagNormalT {
     __device__ explicit DiagNormalT(const TargetParams& p) : mu(p.a), prec(p.b) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int) const {
-        double acc = 0.0;
+        LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             double d = q[k] - mu[lane + WAVE * k];
             double w = prec[lane + WAVE * k] * d;
-            acc = __builtin_fma(d, w, acc);
+            acc.add(0, k, d, w);
             g[k] = -w;
         }
-        return acc;
+        return acc.fold(0);
     }
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
 };
@@ -95,7 +95,7 @@ struct TridiagNormalT {
     __device__ explicit TridiagNormalT(const TargetParams& p) : diag(p.a), off(p.b) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
-        double acc = 0.0;
+        LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             int e = lane + WAVE * k;
@@ -109,10 +109,10 @@ struct TridiagNormalT {
             double t = diag[e] * q[k];
             if (e > 0 && e < D) t = t + off[e - 1] * qm;
             if (e < D - 1) t = t + off[e] * qp;
-            acc = __builtin_fma(q[k], t, acc);
+            acc.add(0, k, q[k], t);
             g[k] = -t;
         }
-        return acc;
+        return acc.fold(0);
     }
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
 };
@@ -137,13 +137,13 @@ struct DenseNormalT {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) d[k] = q[k] - mu[lane + WAVE * k];
         sym_matvec<NPL>(P, Dpad, D, lane, d, Pd);
-        double acc = 0.0;
+        LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            acc = __builtin_fma(d[k], Pd[k], acc);
+            acc.add(0, k, d[k], Pd[k]);
             g[k] = -Pd[k];
         }
-        return acc;
+        return acc.fold(0);
     }
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
 };
@@ -162,13 +162,13 @@ struct FunnelT {
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
         double v = readlane_f64(q[0], 0);
         double ev = det_exp(-v);
-        double acc = 0.0;
+        LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             double x = (k == 0 && lane == 0) ? 0.0 : q[k];
-            acc = __builtin_fma(x, x, acc);
+            acc.add(0, k, x, x);
         }
-        double S = wave_allreduce1(acc);
+        double S = wave_allreduce1(acc.fold(0));
         double hd = 0.5 * (double)(D - 1);
         double hes = (0.5 * ev) * S;
         double lq = ((-(v * v) / 18.0) - hes) - hd * v;
@@ -230,13 +230,13 @@ struct LogisticT {
                 for (int k = 0; k < NPL; ++k) g[k] = __builtin_fma(xrow[lane + WAVE * k], rn, g[k]);
             }
         }
-        double qq = 0.0;
+        LaneAcc<1, NPL> qq;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            qq = __builtin_fma(q[k], q[k], qq);
+            qq.add(0, k, q[k], q[k]);
             g[k] = g[k] - q[k];
         }
-        double red[2] = {lpart, qq};
+        double red[2] = {lpart, qq.fold(0)};
         wave_allreduce<2>(red);
         return red[0] - 0.5 * red[1];
     }

@@ -78,6 +78,42 @@ __device__ __forceinline__ double wave_allreduce1(double x) {
 
 __device__ __forceinline__ bool wave_all(bool pred) { return __ballot(pred) == ~0ull; }
 
+// The ABI's per-lane part of a dot product (include/dhmc.h "Summation order"): a padded row is cut into BLOCKS of
+// 256 coordinates (4 slots per lane); inside a block lane l accumulates its slots k ascending with fma; the blocks'
+// partial sums are then combined PER LANE by an adjacent-pairs binary tree, and the 64 lane values by the xor
+// butterfly (wave_allreduce).  One block (D <= 256) is the plain fma chain.  The block structure is what lets a
+// chain of 512+ coordinates be spread over several waves (one block per wave: nuts_mw_kernel.hpp,
+// dense_rounds_k3b.hpp) without serialising the chain across them; a single wave holding the whole row keeps one
+// accumulator per block instead (more independent fma chains, same bits).
+template <int N, int NPL>
+struct LaneAcc {
+    static constexpr int NB = NPL >= 4 ? NPL / 4 : 1;
+    double a[N][NB];
+    __device__ __forceinline__ LaneAcc() {
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) a[n][b] = 0.0;
+    }
+    // slot k (compile-time after unrolling) of dot n
+    __device__ __forceinline__ void add(int n, int k, double x, double y) { a[n][k / 4] = __builtin_fma(x, y, a[n][k / 4]); }
+    __device__ __forceinline__ void plus(int n, int k, double x) { a[n][k / 4] = a[n][k / 4] + x; }
+    __device__ __forceinline__ double fold(int n) const {
+        double t[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) t[b] = a[n][b];
+#pragma unroll
+        for (int w = 1; w < NB; w *= 2)
+#pragma unroll
+            for (int b = 0; b + w < NB; b += 2 * w) t[b] = t[b] + t[b + w];
+        return t[0];
+    }
+    __device__ __forceinline__ void fold_all(double (&out)[N]) const {
+#pragma unroll
+        for (int n = 0; n < N; ++n) out[n] = fold(n);
+    }
+};
+
 // Coalesced vector access: slot k of lane l <-> element l + 64 k of a padded [Dpad] row.
 template <int NPL>
 __device__ __forceinline__ void ldv(const double* __restrict__ row, int lane, double (&v)[NPL]) {

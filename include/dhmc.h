@@ -46,6 +46,15 @@
  *              the momentum's index in the `transition` word.
  * A Julia `TapeRNG <: AbstractRNG` that replays this stream makes the real reference
  * reproduce these draws.
+ *
+ * Summation order (LinearAlgebra.dot, hamiltonian.jl:103 and NUTS.jl:130-137, is BLAS-dependent and unpinned; the ABI
+ * fixes one so that CPU checker and device agree bit for bit).  Every dot product over the D coordinates of a chain
+ * is computed as follows.  The row, zero padded to Dpad = 64*2^j >= D, is cut into BLOCKS of 256 coordinates.  In
+ * block B, partial sum (B, l), l = 0..63, accumulates the products of coordinates 256 B + l, + 64, + 128, + 192 in
+ * that order with fma, starting from +0.  Per l, the blocks' partial sums are combined by an adjacent-pairs binary
+ * tree ((B0 + B1) + (B2 + B3)) ...; the 64 resulting values are combined by the xor butterfly 1, 2, 4, 8, 16, 32
+ * (adjacent pairs first).  For D <= 256 this is one fma chain per l and the butterfly.  A block is what one 64-lane
+ * wavefront holds at four coordinates per lane: chains of 512+ coordinates are spread over one wavefront per block.
  */
 #ifndef DHMC_H
 #define DHMC_H

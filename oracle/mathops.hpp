@@ -6,12 +6,13 @@
 //   LIBM — glibc's exp/log/log1p/sincos/pow, i.e. the class of functions the reference itself
 //          calls through Julia; used to show that DET stays inside the reference's tolerance.
 // Also the wave-ordered reductions: the ABI fixes the summation order of every dot product
-// (64 interleaved partial sums accumulated with fma, combined by an adjacent-pairs binary
-// tree), because LinearAlgebra.dot's order (src/hamiltonian.jl:103, src/NUTS.jl:130) is
+// (256-coordinate blocks of 64 interleaved fma chains, combined per lane by an adjacent-pairs
+// tree over the blocks and then over the lanes), because LinearAlgebra.dot's order (src/hamiltonian.jl:103, src/NUTS.jl:130) is
 // BLAS-dependent and unpinned.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <vector>
 #include "../include/dhmc_detmath.h"
 
 namespace oracle {
@@ -45,21 +46,34 @@ struct MathOps {
     }
 };
 
-// Σ_e a[e]*b[e] in wave order: lane l (of 64) accumulates e = l, l+64, ... with fma, then the
-// 64 partials are combined by the xor-butterfly 1,2,4,8,16,32 (adjacent pairs first).
+// Σ_e a[e]*b[e] in the ABI's order (include/dhmc.h "Summation order"; device: csrc/wave.hpp LaneAcc +
+// wave_allreduce).  The row is cut into blocks of 256 coordinates; in block B lane l (of 64) accumulates
+// e = 256 B + l, + 64, + 128, + 192 with fma; the blocks' partial sums are combined per lane by an adjacent-pairs
+// binary tree over the power-of-two number of blocks of the padded row (missing blocks are +0.0); the 64 lane
+// values are combined by the xor-butterfly 1,2,4,8,16,32 (adjacent pairs first).  For n <= 256 this is one fma chain
+// per lane followed by the butterfly.
 inline double wave_tree(double* partial) {
     for (int off = 1; off < 64; off <<= 1)
         for (int l = 0; l < 64; l += 2 * off) partial[l] = partial[l] + partial[l + off];
     return partial[0];
 }
 inline double wave_dot(const double* a, const double* b, int n) {
-    double partial[64];
-    for (int l = 0; l < 64; ++l) {
-        double acc = 0.0;
-        for (int e = l; e < n; e += 64) acc = __builtin_fma(a[e], b[e], acc);
-        partial[l] = acc;
-    }
-    return wave_tree(partial);
+    int nblk = 1;
+    while (256 * nblk < n) nblk *= 2;
+    std::vector<double> blk((size_t)nblk * 64, 0.0);
+    for (int B = 0; B < nblk; ++B)
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                const int e = 256 * B + 64 * k + l;
+                if (e < n) acc = __builtin_fma(a[e], b[e], acc);
+            }
+            blk[(size_t)B * 64 + l] = acc;
+        }
+    for (int w = 1; w < nblk; w *= 2)
+        for (int B = 0; B + w < nblk; B += 2 * w)
+            for (int l = 0; l < 64; ++l) blk[(size_t)B * 64 + l] = blk[(size_t)B * 64 + l] + blk[(size_t)(B + w) * 64 + l];
+    return wave_tree(blk.data());
 }
 
 }  // namespace oracle
