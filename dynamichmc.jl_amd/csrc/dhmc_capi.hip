@@ -39,6 +39,7 @@ struct dhmc_ctx {
     unsigned long long last_leapfrogs = 0;
     int l1_in_lds = 1;
     int k3_block = 1;
+    int mw = 1;                // multi-wave per-chain kernel for 512+ coordinates (DHMC_MW=0: the one-wave kernel)
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
@@ -276,6 +277,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_MW")) c->mw = std::atoi(e) != 0;
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
     const size_t C = cfg->chains, Dp = c->Dpad;
@@ -672,6 +674,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
     P.l1_in_lds = c->l1_in_lds;
     P.k3_block = c->k3_block;
+    P.mw = c->mw;
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;

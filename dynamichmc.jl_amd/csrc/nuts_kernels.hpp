@@ -70,6 +70,7 @@ struct ChainArrays {
 struct RunParams {
     int D, Dpad, C, chain_offset, max_depth, nvec;
     int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
+    int mw;                      // diagonal metric, 512+ coordinates, coordinate-wise target: a workgroup per chain (nuts_mw_kernel.hpp)
     int k3_block;                // round engines: K3 as a workgroup per chain (dense_rounds_k3b.hpp) where it applies
     double min_delta;
     uint64_t seed;

@@ -9,6 +9,9 @@
 //                                the reduction that gives ℓ (kDeferred = true; the caller
 //                                batches the wave reduction with the kinetic energy's and then
 //                                calls finish()), or ℓ itself (kDeferred = false).
+//   kElementwise                 element e of ∇ℓ and of the summand of ℓ depend on q_e alone (and eval takes any element base
+//                                as its `lane` argument): such targets can be cut into 256-coordinate blocks, one wave
+//                                each (nuts_mw_kernel.hpp).
 //   kRecomputeGrad               ∇ℓ is cheap enough that a stored proposal keeps only q and the
 //                                gradient is re-evaluated when the proposal becomes the chain's position.
 //   kPointwiseGrad               element e of ∇ℓ is a function of q_e alone at no memory cost (grad1): the kernels then
@@ -37,6 +40,7 @@ struct TargetParams {
 
 struct StdNormalT {
     static constexpr bool kDeferred = true;
+    static constexpr bool kElementwise = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = true;
     static constexpr bool kBigDims = false;
@@ -59,6 +63,7 @@ struct StdNormalT {
 
 struct DiagNormalT {
     static constexpr bool kDeferred = true;
+    static constexpr bool kElementwise = true;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -85,6 +90,7 @@ struct DiagNormalT {
 // ℓ = -1/2 q'Pq, P symmetric tridiagonal: (Pq)_i = diag_i q_i + off_{i-1} q_{i-1} + off_i q_{i+1}
 struct TridiagNormalT {
     static constexpr bool kDeferred = true;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -122,6 +128,7 @@ struct TridiagNormalT {
 // meant for the small correlated targets of the statistical tests, not for large D.
 struct DenseNormalT {
     static constexpr bool kDeferred = true;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -152,6 +159,7 @@ struct DenseNormalT {
 //   ℓ = -v²/18 - 1/2 e^{-v} Σ_{i>=1} q_i² - (D-1)/2 v
 struct FunnelT {
     static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |e^{-v} q_i| <= max(e^{-v}, e^{-v} q_i^2)
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -188,6 +196,7 @@ struct FunnelT {
 // production form shares X tiles across a workgroup's chains and contracts with fp64 MFMA.
 struct LogisticT {
     static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;   // |y - σ| <= 1, β finite when β·β is
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -246,6 +255,7 @@ struct LogisticT {
 // The reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73)
 struct AlwaysDivergentT {
     static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = true;
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = false;
@@ -270,6 +280,7 @@ struct AlwaysDivergentT {
 // for it (their use of the functor is limited to kRecomputeGrad == false: gradients are stored, never recomputed).
 struct ExternalT {
     static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
     static constexpr bool kFiniteLqImpliesFiniteGrad = false;
     static constexpr bool kPointwiseGrad = false;
     static constexpr bool kBigDims = true;    // served by the streaming round-engine kernels up to 64 slots per lane (D <= 4096)
