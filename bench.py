@@ -7,9 +7,15 @@ step size search, 900 dual-averaging transitions with per-chain diagonal metric 
 25/50/100/200/400 windows, mcmc.jl:415-425) so the timed region runs at adapted per-chain ϵ and M⁻¹.
 
 One "step" = one dhmc_run call = one pass of the per-draw loop (mcmc.jl:374-379) of
-`--transitions` NUTS transitions for every chain, draws and tree statistics written to
-buffers already resident in HBM.  value = Σ leapfrog steps of all chains and ranks ÷ wall time
-of the K timed steps (barrier + synchronize on both sides, max over ranks).
+`--transitions` NUTS transitions (default 500: ≈0.1 s of GPU work, so that K = 10..20 timed steps
+are a second or more) for every chain, draws and tree statistics written to buffers already
+resident in HBM.  value = Σ leapfrog steps of all chains and ranks ÷ wall time of the K timed steps
+(barrier + synchronize on both sides, max over ranks).  The warmup phase (adaptation on, metric
+updates included) is timed separately during setup and reported as `warmup_phase`.
+
+roofline: the chain state is register/LDS-resident, so the bound that applies is the fp64 vector
+unit (≈30·D useful flops per leapfrog against 78.6 TFLOP/s); the 48·D-byte streaming
+model and the measured HBM traffic are kept as secondary keys inside `roofline`.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -30,6 +36,8 @@ D = 1000
 CHAINS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_LEAPFROG = 48 * D   # read q,p,∇ℓ + write q',p',∇ℓ' in fp64
+VALU_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: fp64 vector peak
+ALGO_FLOPS_PER_LEAPFROG = 30 * D   # 6D integrator + 3D density + 3D kinetic + D p♯ + D ρ + ≈15D amortised turn checks
 
 
 ALL_RUN_LEAPFROGS = [0]   # every dhmc_run of this process (setup + warmup + timed + ESS), for the PMC summaries
@@ -60,13 +68,22 @@ def setup_context(pkg, torch, rank, chains, seed, short):
     # default_warmup_stages (mcmc.jl:415-425): 75 stepsize-only, metric windows 25/50/100/200/400, 50 stepsize-only
     stages = [(20, False), (25, True), (20, False)] if short else \
         [(75, False), (25, True), (50, True), (100, True), (200, True), (400, True), (50, False)]
+    bufs = {n: torch.empty((chains, n, D), dtype=torch.float64, device="cuda") for n, metric in stages if metric}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); lf0 = ALL_RUN_LEAPFROGS[0]; kms = 0.0
     for n, metric in stages:
-        draws = torch.empty((chains, n, D), dtype=torch.float64, device="cuda") if metric else None
-        _run(ctx, n, {"draws": draws} if metric else {}, da={})
+        _run(ctx, n, {"draws": bufs[n]} if metric else {}, da={})
+        kms += ctx.last_run_kernel_ms()
         if metric:
-            ctx.update_metric_diag(draws)
-        del draws
-    return ctx
+            ctx.update_metric_diag(bufs[n])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lf = ALL_RUN_LEAPFROGS[0] - lf0
+    warm = {"value": lf / dt, "unit": "leapfrog-steps/s", "seconds": dt, "leapfrogs": lf, "transitions": sum(n for n, _ in stages),
+            "kernel_ms": kms, "note": "TuningNUTS stages with dual averaging on, draws of the metric windows kept in HBM, "
+                                       "per-chain diagonal metric updates included; this rank"}
+    del bufs
+    return ctx, warm
 
 
 def bulk_ess_min(pkg, torch, draws, ncoord=16):
@@ -211,7 +228,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--transitions", type=int, default=20, help="NUTS transitions per chain per step")
+    ap.add_argument("--transitions", type=int, default=None, help="NUTS transitions per chain per step (default 500 for config 2, 20 otherwise)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--short-warmup", action="store_true", help="65-transition adaptive setup instead of the reference's 900")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,12 +254,14 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    if args.transitions is None:
+        args.transitions = 500 if args.config == 2 else 20
     if args.config == 3:
         return bench_config3(args, pkg, torch)
     if args.config in (4, 5):
         return bench_config45(args, pkg, torch)
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
-    ctx = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
+    ctx, warm = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
     out = {
         "draws": torch.empty((C, T, D), dtype=torch.float64, device="cuda"),
         "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
@@ -270,20 +289,15 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    # untimed: statistics of the last step, ESS from a continuation run, gather over RCCL
+    # untimed: statistics and ESS of the last timed step's draws, gather over RCCL
     mean_depth = float(out["depth"].double().mean())
     mean_acc = float(out["acceptance_rate"].mean())
     mean_steps = float(out["steps"].double().mean())
     q = out["draws"]
-    mom = (float(q.mean()), float(q.var()))
-    ess_T = 100
-    ess_draws = torch.empty((C, ess_T, D), dtype=torch.float64, device="cuda")
-    e0 = time.perf_counter()
-    _run(ctx, ess_T, {"draws": ess_draws})
-    torch.cuda.synchronize()
-    ess_dt = time.perf_counter() - e0
-    ess = bulk_ess_min(pkg, torch, ess_draws)
-    del ess_draws
+    mom = (float(q[:, -20:].mean()), float(q[:, -20:].var()))
+    ess_T = min(T, 1000)
+    ess_dt = dt / K * ess_T / T
+    ess = bulk_ess_min(pkg, torch, q[:, T - ess_T:].contiguous() if ess_T < T else q)
 
     t_max, total_leapfrogs, ess_rate = dt, leapfrogs, ess / ess_dt
     if dist is not None:
@@ -302,6 +316,8 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         per_launch = leapfrogs / K
         achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
+        valu_ach = per_launch * ALGO_FLOPS_PER_LEAPFROG / (k_ms * 1e-3) / 1e12
+        kernel_name = "nuts_run_kernel<StdNormalT,16> (DHMC_MW=0)" if os.environ.get("DHMC_MW") == "0" else "nuts_run_mw_kernel<StdNormalT,4>"
         tpl, tsrc = measured_traffic_per_leapfrog()
         line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",
@@ -318,22 +334,23 @@ def main():
                        "parallelism": f"chains sharded x{world}, no data-path collective"},
             "ess_per_sec": ess_rate,
             "ess_note": f"min rank-normalised split-chain bulk ESS (Vehtari et al. 2021; dhmc_ess_bulk) over 16 coordinates, "
-                        f"{ess_T} further draws x all chains, untimed continuation",
+                        f"the last {ess_T} draws x all chains of the last timed step, over that share of the step's time",
             "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
                      "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
+            "warmup_phase": warm,
+            "roofline": {"bound": "valu", "achieved": valu_ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": valu_ach / VALU_PEAK_TFLOPS,
                          "traffic": None if tpl is None else tpl * per_launch, "traffic_source": tsrc,
-                         "kernel": "nuts_run_kernel<StdNormalT,16>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_leapfrog": ALGO_BYTES_PER_LEAPFROG,
+                         "kernel": kernel_name, "kernel_ms": k_ms,
+                         "algorithmic_flops_per_leapfrog": ALGO_FLOPS_PER_LEAPFROG,
                          "leapfrogs_per_launch": per_launch,
-                         "note": "state is register/LDS-resident, so achieved (algorithmic bytes / time) can exceed "
-                                 "the HBM peak; traffic = real HBM bytes per launch from the PMC passes",
-                         # a path that beats the streaming bound is priced against fp64 VALU instead
-                         "valu": {"flops_per_leapfrog": 30 * D, "achieved": per_launch * 30 * D / (k_ms * 1e-3) / 1e12,
-                                  "peak": 78.6, "unit": "TFLOP/s", "frac": per_launch * 30 * D / (k_ms * 1e-3) / 1e12 / 78.6,
-                                  "note": "≈30·D useful flops per leapfrog (6D integrator, 3D density, 4D kinetic terms, ≈15D "
-                                          "amortised turn checks) against the fp64 vector peak"}},
+                         "note": "≈30·D useful flops per leapfrog (6D integrator, 3D density, 4D kinetic terms, ≈15D amortised "
+                                 "turn checks; an unfused multiply or add counts 1, the peak counts an fma as 2) x leapfrogs per "
+                                 "launch / kernel time (HIP events on the launch stream) against the fp64 vector peak; "
+                                 "traffic = real HBM bytes per launch from the PMC passes",
+                         # the streaming model SURVEY.md §8(d) starts from: the chain state never leaves the CU, so this exceeds 1
+                         "hbm_model": {"algorithmic_bytes_per_leapfrog": ALGO_BYTES_PER_LEAPFROG, "achieved": achieved,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}},
             "all_run_leapfrogs": ALL_RUN_LEAPFROGS[0],
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only

@@ -20,6 +20,7 @@
 #include "ess_kernels.hpp"
 #include "logistic_rounds.hpp"
 #include "metric_dense_adapt.hpp"
+#include "treestat_kernels.hpp"
 #include "launch.hpp"
 #include "util_kernels.hpp"
 
@@ -1060,6 +1061,60 @@ int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t cha
         if (hipMemcpyAsync(rhat + j, dr.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
     }
     if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
+    return DHMC_OK;
+}
+
+int dhmc_summarize_tree_statistics(int32_t device, void* stream, const double* pi, const double* acceptance_rate,
+                                   const int64_t* term_left, const int64_t* term_right, const int32_t* depth,
+                                   int64_t chains, int64_t n, int on_device, dhmc_tree_statistics_summary* summary,
+                                   double* ebfmi) {
+    if (!pi || !acceptance_rate || !term_left || !term_right || !depth || !summary || chains < 1 || n < 1) return DHMC_ERR_INVALID_ARGUMENT;
+    const int64_t total = chains * n;
+    if (total > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
+    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf in[5], dsum, deb, dcnt, dsorted, dtmp, dout;
+    const void* src[5] = {pi, acceptance_rate, term_left, term_right, depth};
+    const size_t esz[5] = {8, 8, 8, 8, 4};
+    const void* dev[5];
+    for (int i = 0; i < 5; ++i) {
+        dev[i] = src[i];
+        if (!on_device) {
+            if (hipMalloc(&in[i].p, esz[i] * total) != hipSuccess) return DHMC_ERR_HIP;
+            if (hipMemcpyAsync(in[i].p, src[i], esz[i] * total, hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
+            dev[i] = in[i].p;
+        }
+    }
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (int)total, 0, 64, s) != hipSuccess)
+        return DHMC_ERR_HIP;
+    const size_t ncnt = 3 + TS_DEPTH_BINS;
+    if (hipMalloc(&dsum.p, sizeof(double) * chains) != hipSuccess || hipMalloc(&deb.p, sizeof(double) * chains) != hipSuccess ||
+        hipMalloc(&dcnt.p, sizeof(unsigned long long) * ncnt) != hipSuccess || hipMalloc(&dsorted.p, sizeof(double) * total) != hipSuccess ||
+        hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess || hipMalloc(&dout.p, sizeof(double) * 6) != hipSuccess)
+        return DHMC_ERR_HIP;
+    if (hipMemsetAsync(dcnt.p, 0, sizeof(unsigned long long) * ncnt, s) != hipSuccess) return DHMC_ERR_HIP;
+    hipLaunchKernelGGL(treestat_chain_kernel, dim3((unsigned)chains), dim3(WAVE), 0, s, (const double*)dev[0], (const double*)dev[1],
+                       (const int64_t*)dev[2], (const int64_t*)dev[3], (const int32_t*)dev[4], n, (double*)deb.p, (double*)dsum.p,
+                       (unsigned long long*)dcnt.p);
+    if (hipcub::DeviceRadixSort::SortKeys(dtmp.p, tmp_bytes, (const double*)dev[1], (double*)dsorted.p, (int)total, 0, 64, s) != hipSuccess)
+        return DHMC_ERR_HIP;
+    hipLaunchKernelGGL(treestat_finish_kernel, dim3(1), dim3(WAVE), 0, s, (const double*)dsum.p, chains, total, (const double*)dsorted.p,
+                       (double*)dout.p);
+    if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
+    double out6[6];
+    unsigned long long cnt[3 + TS_DEPTH_BINS];
+    if (hipMemcpyAsync(out6, dout.p, sizeof(out6), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(cnt, dcnt.p, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (ebfmi && hipMemcpyAsync(ebfmi, deb.p, sizeof(double) * chains, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
+    summary->n = total;
+    summary->a_mean = out6[0];
+    for (int i = 0; i < 5; ++i) summary->a_quantiles[i] = out6[1 + i];
+    summary->max_depth = (int64_t)cnt[0];
+    summary->divergence = (int64_t)cnt[1];
+    summary->turning = (int64_t)cnt[2];
+    for (int d = 0; d < TS_DEPTH_BINS; ++d) summary->depth_counts[d] = (int64_t)cnt[3 + d];
     return DHMC_OK;
 }
 

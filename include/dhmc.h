@@ -252,6 +252,24 @@ int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t cha
 int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
 
+/* Post-hoc NUTS diagnostics over the SoA tree statistics of dhmc_run (DynamicHMC.Diagnostics, diagnostics.jl:29-106), all
+ * [chains][n] arrays as dhmc_outputs writes them (device pointers if on_device, so 4096 x 1000 statistics need not
+ * cross PCIe): EBFMI per chain (:29-32; n >= 2), count_terminations (:65-82) and count_depths (:87-95) pooled over the
+ * chains, and summarize_tree_statistics' mean and ACCEPTANCE_QUANTILES of the pooled acceptance rates (:100-106, Julia's
+ * default quantile definition).  `summary` and `ebfmi` ([chains], may be NULL) are HOST buffers.  Summation orders:
+ * csrc/treestat_kernels.hpp. */
+typedef struct dhmc_tree_statistics_summary {
+    int64_t n;                 /* chains * n: "Sample length" */
+    double a_mean;
+    double a_quantiles[5];     /* 0.05, 0.25, 0.5, 0.75, 0.95 */
+    int64_t max_depth, divergence, turning;
+    int64_t depth_counts[33];  /* depth 0 .. 32 (the reference trims trailing zeros) */
+} dhmc_tree_statistics_summary;
+int dhmc_summarize_tree_statistics(int32_t device, void* stream, const double* pi, const double* acceptance_rate,
+                                   const int64_t* term_left, const int64_t* term_right, const int32_t* depth,
+                                   int64_t chains, int64_t n, int on_device, dhmc_tree_statistics_summary* summary,
+                                   double* ebfmi);
+
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);
 int dhmc_export_state(dhmc_ctx* ctx, void* host_blob, uint64_t nbytes);
