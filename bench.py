@@ -317,7 +317,7 @@ def main():
         per_launch = leapfrogs / K
         achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
         valu_ach = per_launch * ALGO_FLOPS_PER_LEAPFROG / (k_ms * 1e-3) / 1e12
-        kernel_name = "nuts_run_kernel<StdNormalT,16> (DHMC_MW=0)" if os.environ.get("DHMC_MW") == "0" else "nuts_run_mw_kernel<StdNormalT,4>"
+        kernel_name = "nuts_run_mw_kernel<StdNormalT,4> (DHMC_MW=1)" if os.environ.get("DHMC_MW") == "1" else "nuts_run_kernel<StdNormalT,16,true>"
         tpl, tsrc = measured_traffic_per_leapfrog()
         line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",

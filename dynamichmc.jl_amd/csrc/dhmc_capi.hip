@@ -40,7 +40,7 @@ struct dhmc_ctx {
     unsigned long long last_leapfrogs = 0;
     int l1_in_lds = 1;
     int k3_block = 1;
-    int mw = 1;                // multi-wave per-chain kernel for 512+ coordinates (DHMC_MW=0: the one-wave kernel)
+    int mw = 0;                // DHMC_MW=1: the multi-wave per-chain kernel for 512+ coordinates (nuts_mw_kernel.hpp; slower, kept as the measured alternative)
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;

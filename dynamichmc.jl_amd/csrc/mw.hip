@@ -7,12 +7,12 @@ namespace dhmc {
 
 template <class T, int NW>
 void launch_run_mw(const RunParams& P, hipStream_t s) {
-    static bool once = [] {   // up to 55 KB of dynamic LDS per chain (mw_lds_bytes at max_depth = 32)
+    static bool once = [] {   // 53 KB of dynamic LDS per chain
         (void)hipFuncSetAttribute((const void*)nuts_run_mw_kernel<T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((nuts_run_mw_kernel<T, NW>), dim3(P.C), dim3(WAVE * (NW + 1)), mw_lds_bytes(P.Dpad, NW, P.max_depth), s, P);
+    hipLaunchKernelGGL((nuts_run_mw_kernel<T, NW>), dim3(P.C), dim3(WAVE * (NW + 1)), mw_lds_bytes(P.Dpad, NW), s, P);
 }
 
 template void launch_run_mw<StdNormalT, 2>(const RunParams&, hipStream_t);
@@ -21,3 +21,16 @@ template void launch_run_mw<DiagNormalT, 2>(const RunParams&, hipStream_t);
 template void launch_run_mw<DiagNormalT, 4>(const RunParams&, hipStream_t);
 
 }  // namespace dhmc
+
+#ifdef MW_TRACE
+extern "C" int dhmc_debug_mw_trace(unsigned long long* out, unsigned int* counts, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(dhmc::g_mw_trace), sizeof(unsigned long long) * 8 * 4096) != hipSuccess) return 1;
+    if (counts && hipMemcpyFromSymbol(counts, HIP_SYMBOL(dhmc::g_mw_trace_n), sizeof(unsigned int) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dhmc::g_mw_trace_n), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+

@@ -102,9 +102,13 @@ constexpr int LDS_SLOTS = 36;
 // (≈2 µs, more than a whole small-D leapfrog) every time a subtree of that size is merged — 1/8 of all leaves for
 // levels ≥ 3 — and a wave-per-chain kernel on a short chain has nothing else to hide it behind.
 __host__ __device__ constexpr int lds_extra_levels(int NPL) { return NPL == 1 ? 6 : NPL == 2 ? 3 : NPL == 4 ? 1 : 0; }
+// The per-level / per-slot scalars of the tree logic live in the lanes of a few registers (wave.hpp LaneArr), not in LDS.
+// Wide chains (16 slots per lane, kTrajInLds): M⁻¹ stays in registers and the rows are (level 0, level 1 first / last,
+// trajectory p₋ / p₊) — 40 KB per wave, four waves fill the CU's 160 KB exactly.
+__host__ __device__ constexpr bool traj_in_lds(int NPL, bool l1_in_lds) { return NPL == 16 && l1_in_lds; }
 __host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds, int extra_levels) {
-    return sizeof(double) * ((size_t)Dpad * ((l1_in_lds ? 4 : 2) + 3 * extra_levels) + 3 * LDS_LEVELS + 2 * LDS_SLOTS) +
-           sizeof(int) * LDS_LEVELS;
+    if (traj_in_lds(Dpad / 64, l1_in_lds)) return sizeof(double) * (size_t)Dpad * 5;
+    return sizeof(double) * ((size_t)Dpad * ((l1_in_lds ? 4 : 2) + 3 * extra_levels));
 }
 
 __device__ __forceinline__ double joint_logdensity(double lq, double K) {  // hamiltonian.jl:251-256
@@ -132,10 +136,10 @@ __device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool gra
 
 // One leapfrog step in registers (hamiltonian.jl:273-282) followed by the leaf's joint log
 // density.  eps is signed (backward motion = negative ϵ, NUTS.jl:30).
-template <class T, int NPL>
-__device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __restrict__ m_lds, int lane, int D,
-                                              double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
-                                              double eps, double& lq_out, double& pi_out, bool& pos_finite) {
+template <class T, int NPL, class MK>
+__device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, int D,
+                                                double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
+                                                double eps, double& lq_out, double& pi_out, bool& pos_finite) {
     const double h = eps / 2;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -143,7 +147,7 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
         if constexpr (T::kPointwiseGrad) gk = tgt.grad1(q[k], lane + WAVE * k);   // ∇ℓq recomputed, not carried
         else gk = g[k];
         double pm = p[k] + h * gk;                   // :277
-        double t = m_lds[lane + WAVE * k] * pm;      // ∇kinetic_energy(κ, pₘ) = M⁻¹ pₘ
+        double t = mk_(k) * pm;                      // ∇kinetic_energy(κ, pₘ) = M⁻¹ pₘ
         q[k] = q[k] + eps * t;                       // :278
         p[k] = pm;
     }
@@ -152,7 +156,7 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         p[k] = p[k] + h * g[k];                      // :280
-        double ps = m_lds[lane + WAVE * k] * p[k];   // p♯ = M⁻¹ p'
+        double ps = mk_(k) * p[k];                   // p♯ = M⁻¹ p'
         kacc.add(0, k, p[k], ps);
     }
     double lq, K;
@@ -183,13 +187,20 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
     pi_out = uni_f64(joint_logdensity(lq, K));
 }
 
+// M⁻¹ staged in LDS (or any lane-strided row)
+template <class T, int NPL>
+__device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __restrict__ m_lds, int lane, int D,
+                                              double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
+                                              double eps, double& lq_out, double& pi_out, bool& pos_finite) {
+    leapfrog_leaf_m<T, NPL>(tgt, LdsRow{m_lds, lane}, lane, D, q, p, g, eps, lq_out, pi_out, pos_finite);
+}
+
 // combine_turn_statistics (NUTS.jl:132-139) of two adjacent subtrees, time-ordered
 // (trees.jl:135-141): x = earlier in time, y = later, each given as accessors k -> slot k of
 // its (p₋, p₊, ρ).  nf(k) is what becomes the merged summary's build-order first momentum.
 // On return cf = nf, cr = ρ of the merge.  Returns turning.
-template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, class NF>
-__device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_,
-                                           const double* __restrict__ m_lds, int lane,
+template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, class NF, class MK>
+__device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_, MK mk_,
                                            double (&cf)[NPL], double (&cr)[NPL]) {
     LaneAcc<6, NPL> A;
 #pragma unroll
@@ -197,7 +208,7 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
         const double xm = xm_(k), xp = xp_(k), xr = xr_(k);
         const double ym = ym_(k), yp = yp_(k), yr = yr_(k);
         const double nf = nf_(k);
-        const double mk = m_lds[lane + WAVE * k];
+        const double mk = mk_(k);
         const double s1 = xr + ym;      // x.ρ + y.p₋      (:134)
         const double s2 = xp + yr;      // x.p₊ + y.ρ      (:135)
         const double r = xr + yr;       // ρ               (:136)
@@ -225,14 +236,14 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
 // all pa + pb (IEEE addition commutes, so the build direction does not matter) and the six
 // dots are two distinct values, (M⁻¹pa)·ρ and (M⁻¹pb)·ρ, each appearing three times: the
 // result is bit-identical to merge_core.  Half of all merges of a tree are of this kind.
-template <int NPL, class PA>
-__device__ __forceinline__ bool merge_leaf_leaf(PA pa_, const double* __restrict__ m_lds, int lane,
+template <int NPL, class PA, class MK>
+__device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
                                                 double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL]) {
     LaneAcc<2, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double pa = pa_(k);
-        const double mk = m_lds[lane + WAVE * k];
+        const double mk = mk_(k);
         const double r = pa + pb[k];
         A.add(0, k, mk * pa, r);
         A.add(1, k, mk * pb[k], r);
@@ -282,36 +293,51 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     const int D = P.D, Dpad = P.Dpad;
 
     extern __shared__ double lds[];
-    double* m_lds = lds;                                   // [Dpad]
-    double* l0_lds = lds + Dpad;                           // [Dpad]   level-0 suspended momentum
-    double* l1f_lds = lds + 2 * Dpad;                      // [Dpad]   level-1 first   (L1LDS only)
-    double* l1l_lds = lds + 3 * Dpad;                      // [Dpad]   level-1 last    (L1LDS only)
+    constexpr bool TPL = traj_in_lds(NPL, L1LDS);          // M⁻¹ in registers; trajectory edges p₋, p₊ in LDS
+    double* m_lds = lds;                                   // [Dpad]   (!TPL)
+    double* l0_lds = lds + (TPL ? 0 : 1) * Dpad;           // [Dpad]   level-0 suspended momentum
+    double* l1f_lds = lds + (TPL ? 1 : 2) * Dpad;          // [Dpad]   level-1 first   (L1LDS only)
+    double* l1l_lds = lds + (TPL ? 2 : 3) * Dpad;          // [Dpad]   level-1 last    (L1LDS only)
+    double* tpm_lds = lds + 3 * Dpad;                      // [Dpad]   trajectory p₋   (TPL only)
+    double* tpp_lds = lds + 4 * Dpad;                      // [Dpad]   trajectory p₊   (TPL only)
     constexpr int NXL = L1LDS ? lds_extra_levels(NPL) : 0; // levels 2 .. 1+NXL in LDS too (short chains)
     double* xl_lds = lds + 4 * Dpad;                       // [NXL][3][Dpad]  first, last, ρ
-    double* lv_omega = lds + ((L1LDS ? 4 : 2) + 3 * NXL) * Dpad;   // [LDS_LEVELS]
-    double* lv_vlsa = lv_omega + LDS_LEVELS;
-    double* lv_vsteps = lv_vlsa + LDS_LEVELS;
-    double* sl_lq = lv_vsteps + LDS_LEVELS;                // [LDS_SLOTS]
-    double* sl_pi = sl_lq + LDS_SLOTS;
-    int* lv_zeta = (int*)(sl_pi + LDS_SLOTS);              // [LDS_LEVELS]
+    LaneArrF64 lv_omega, lv_vlsa, lv_vsteps;               // per suspended level (lane = level): ω, visited statistic
+    LaneArrI32 lv_zeta;                                    //   … and the proposal slot
+    LaneArrF64 sl_lq, sl_pi;                               // per proposal slot (lane = slot): ℓq and π of the point stored there
 
     const T tgt(P.tp);
     const size_t row = (size_t)chain * Dpad;
     double* const ws = P.st.ws + (size_t)chain * P.nvec * Dpad;
     auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
 
-    {
+    double mreg[TPL ? NPL : 1];
+    if constexpr (TPL) {
+        ldv<NPL>(P.st.minv + row, lane, mreg);
+    } else {
         const double* mrow = P.st.minv + row;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) m_lds[lane + WAVE * k] = mrow[lane + WAVE * k];
     }
+    auto mk = [&](int k) -> double {                       // slot k of M⁻¹
+        if constexpr (TPL) return mreg[k];
+        else return m_lds[lane + WAVE * k];
+    };
     const double* Wrow = P.st.W + row;
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     const int max_depth = P.max_depth;
     const int nslots = ws_nslots(max_depth);
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
-    double tpm[NPL], tpp[NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+    double tpm[TPL ? 1 : NPL], tpp[TPL ? 1 : NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+    auto a_tm = [&](int k) -> double {
+        if constexpr (TPL) return tpm_lds[lane + WAVE * k];
+        else return tpm[k];
+    };
+    auto a_tp = [&](int k) -> double {
+        if constexpr (TPL) return tpp_lds[lane + WAVE * k];
+        else return tpp[k];
+    };
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(P.st.g + row, lane, g);
     double lq_cur = P.st.lq[chain];
@@ -342,8 +368,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         free_mask &= ~(1ull << s);
         stv<NPL>(wsv(ws_slot(max_depth, s, 0)), lane, q);
         if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, s, 1)), lane, g);
-        sl_lq[s] = lq_leaf;
-        sl_pi[s] = pi_leaf;
+        sl_lq.set(s, lq_leaf, lane);
+        sl_pi.set(s, pi_leaf, lane);
         return s;
     };
 
@@ -364,13 +390,21 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         {
             LaneAcc<1, NPL> kacc;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], m_lds[lane + WAVE * k] * p[k]);
+            for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], mk(k) * p[k]);
             pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
         }
+        // leaf τ of z₀ (NUTS.jl:120-123)
+        if constexpr (TPL) {
+            stv<NPL>(tpm_lds, lane, p);
+            stv<NPL>(tpp_lds, lane, p);
+        } else {
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; trho[k] = p[k]; }   // leaf τ of z₀ (NUTS.jl:120-123)
-        sl_lq[init_slot] = lq_cur;
-        sl_pi[init_slot] = pi0;
+            for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) trho[k] = p[k];
+        sl_lq.set(init_slot, lq_cur, lane);
+        sl_pi.set(init_slot, pi0, lane);
 
         // Exp(1) draws of this transition, 64 at a time: lane l holds draw (rexp_base + l)
         uint32_t nrand = 0, rexp_base = 0;
@@ -424,10 +458,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 else ldv<NPL>(wsv(gsrc), lane, g);
                 if (fwd) {
 #pragma unroll
-                    for (int k = 0; k < NPL; ++k) p[k] = tpp[k];
+                    for (int k = 0; k < NPL; ++k) p[k] = a_tp(k);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NPL; ++k) p[k] = tpm[k];
+                    for (int k = 0; k < NPL; ++k) p[k] = a_tm(k);
                 }
             }
             reg_edge = dir;
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
-                leapfrog_leaf<T, NPL>(tgt, m_lds, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite);
+                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite);
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
                 total_steps += 1;
@@ -468,13 +502,13 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         bool turning;
                         if (sub) {
                             if (level == 0) {
-                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, m_lds, lane, cf, cr, p);
+                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p);
                             } else if (L1LDS && level == 1) {
                                 auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
                             } else if (NXL > 0 && level < 2 + NXL) {
                                 const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
                                 const double* Ll = Lf + Dpad;
@@ -482,8 +516,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
                             } else {
                                 const double* Lf = wsv(ws_stack(level, 0));
                                 const double* Ll = wsv(ws_stack(level, 1));
@@ -491,14 +525,14 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, m_lds, lane, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, m_lds, lane, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
                             }
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
-                            const double wl = lv_omega[level];
+                            const double wl = lv_omega.get(level);
                             double w;
-                            logaddexp_pair(lv_vlsa[level], v_lsa, wl, c_omega, lane, v_lsa, w);
-                            v_steps += (int64_t)lv_vsteps[level];
+                            logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
+                            v_steps += (int64_t)lv_vsteps.get(level);
                             if (turning) {                       // trees.jl:255
                                 term_left = i - di * (((int64_t)2 << level) - 1);
                                 term_right = i;
@@ -509,7 +543,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             // combine_proposals_and_logweights(…, is_doubling = false) (trees.jl:258)
                             const double logprob2 = c_omega - w;
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
-                            const int lz = lv_zeta[level];
+                            const int lz = lv_zeta.get(level);
                             if (pick) {
                                 free_mask |= (1ull << lz);
                             } else {
@@ -521,14 +555,12 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         } else {
                             // top level (trees.jl:294-316): merge with τ of the whole trajectory, which is
                             // time-ordered (tpm, tpp, trho) whatever the direction
-                            auto a_tm = [&](int k) { return tpm[k]; };
-                            auto a_tp = [&](int k) { return tpp[k]; };
                             auto a_tr = [&](int k) { return trho[k]; };
                             if (depth == 0) {
-                                turning = merge_leaf_leaf<NPL>(a_tr, m_lds, lane, cf, cr, p);
+                                turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p);
                             } else {
-                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, m_lds, lane, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, m_lds, lane, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr);
                             }
                             double w;
                             logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
@@ -551,13 +583,17 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 finished = true;
                             } else if (depth < max_depth) {
                                 // τ of the doubled trajectory: the new edge momentum and Σp
-                                if (fwd) {
+                                if constexpr (TPL) {
+                                    stv<NPL>(fwd ? tpp_lds : tpm_lds, lane, p);
+                                } else if (fwd) {
 #pragma unroll
-                                    for (int k = 0; k < NPL; ++k) { tpp[k] = p[k]; trho[k] = cr[k]; }
+                                    for (int k = 0; k < NPL; ++k) tpp[k] = p[k];
                                 } else {
 #pragma unroll
-                                    for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; trho[k] = cr[k]; }
+                                    for (int k = 0; k < NPL; ++k) tpm[k] = p[k];
                                 }
+#pragma unroll
+                                for (int k = 0; k < NPL; ++k) trho[k] = cr[k];
                             }
                             level = -1;  // handled
                             break;
@@ -581,10 +617,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
                             stv<NPL>(wsv(ws_stack(level, 2)), lane, cr);
                         }
-                        lv_omega[level] = c_omega;
-                        lv_vlsa[level] = v_lsa;
-                        lv_vsteps[level] = (double)v_steps;
-                        lv_zeta[level] = c_zeta;
+                        lv_omega.set(level, c_omega, lane);
+                        lv_vlsa.set(level, v_lsa, lane);
+                        lv_vsteps.set(level, (double)v_steps, lane);
+                        lv_zeta.set(level, c_zeta, lane);
                     }
                 }
                 if (invalid) {
@@ -592,8 +628,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                     // statistic (trees.jl:244,249-250)
                     for (int l2 = level; l2 < depth; ++l2) {
                         if ((j >> l2) & 1u) {
-                            v_lsa = uni_f64(det_logaddexp(lv_vlsa[l2], v_lsa));
-                            v_steps += (int64_t)lv_vsteps[l2];
+                            v_lsa = uni_f64(det_logaddexp(lv_vlsa.get(l2), v_lsa));
+                            v_steps += (int64_t)lv_vsteps.get(l2);
                         }
                     }
                     vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));   // trees.jl:294
@@ -613,8 +649,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         if constexpr (T::kPointwiseGrad) {}
         else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
         else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
-        lq_cur = uni_f64(sl_lq[init_slot]);
-        const double pi_stat = uni_f64(sl_pi[init_slot]);
+        lq_cur = sl_lq.get(init_slot);
+        const double pi_stat = sl_pi.get(init_slot);
 
         const size_t o = (size_t)chain * P.N + n;
         if (P.out.draws) {

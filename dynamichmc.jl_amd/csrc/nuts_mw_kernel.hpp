@@ -3,27 +3,36 @@
 //
 // Why.  The one-wave-per-chain kernel (nuts_kernels.hpp) holds a 1000-dim chain as 16 slots per lane: eight live
 // D-vectors fill all 512 registers of a SIMD lane, so a SIMD runs ONE wave and every dependent-latency chain of the
-// tree logic (the 45-deep deterministic logaddexp, the DPP butterflies, LDS and L2 round trips) is exposed: the
-// kernel sat at 49 % VALU-active / 10 % of the fp64 vector peak.  The chip's on-chip capacity still allows only four
-// such chains per CU (8 vectors × 8 KB + LDS each), so the way to hide latency is not more chains per CU but the
-// SAME four chains spread over all four SIMDs: each chain's vector work is cut into NW = Dpad/256 waves of four
-// slots per lane (≈ 90 VGPRs), and every SIMD holds waves of several different chains that cover for each other.
+// tree logic (the ≈75-deep deterministic logaddexp with its two fp64 divisions, the DPP butterflies, LDS and L2 round
+// trips) is exposed: the kernel sat at 49 % VALU-active / 10 % of the fp64 vector peak.  Here each chain's vector work
+// is cut into NW = Dpad/256 waves of four slots per lane (128 VGPRs), three chains (15 waves) share a CU, every SIMD
+// holds waves of different chains that cover for each other — and the scalar chain is taken off the vector waves'
+// critical path altogether:
 //
 //  * vector wave w owns coordinates 256 w + lane + 64 k, k = 0..3 — exactly one block of the ABI's dot product
 //    (include/dhmc.h "Summation order", wave.hpp LaneAcc), so its per-lane partial sums are final: no wave-to-wave
-//    fma chain.  It keeps (q, p, [∇ℓ]), the running subtree summary (first, Σp), the trajectory's (p₋, p₊, ρ) and
-//    its part of M⁻¹ in registers, levels 0 and 1 of the suspended stack in LDS, deeper levels / parked edges /
-//    proposal slots in the HBM workspace, and only ever touches its own coordinates of any of those;
-//  * the control wave owns everything scalar of sample_tree (reference src/NUTS.jl:232-241, src/trees.jl:231-319):
-//    it folds the blocks' partial sums and does the 64-lane butterfly, then the leaf's Δ / divergence test, the
-//    acceptance statistic, both logaddexp's of a merge, the Exp(1) draws and proposal selection, slot bookkeeping,
-//    termination, dual averaging and the per-transition outputs.  The two logaddexp's of a merge do not depend on
-//    the dots, so they run WHILE the vector waves compute that merge's partial sums;
-//  * they meet at SYNCHRONISATION POINTS (one per leaf, one per merge, one per transition start): the vector waves
-//    leave partial sums in LDS, barrier, the control wave reduces and publishes a 32-bit VERDICT (divergent /
-//    turning, a proposal slot to materialise the leaf in, the trajectory's current proposal), barrier.  Both sides
-//    run the same replicated integer control (direction bits, depth, leaf counter, cascade level) from the verdicts,
-//    so they execute the same barrier sequence by construction.
+//    fma chain.  It keeps (q, p, [∇ℓ]), the running subtree summary (first, Σp), the trajectory's ρ, its part of M⁻¹
+//    and the previous leaf's position in registers; levels 0 and 1 of the suspended stack and the trajectory's edge
+//    momenta in LDS; deeper levels / parked edges / proposal slots in the HBM workspace — and only ever touches its own
+//    coordinates of any of those;
+//  * the control wave owns everything scalar of sample_tree (reference src/NUTS.jl:232-241, src/trees.jl:231-319).
+//    Its per-level / per-slot arrays live in the LANES of a few VGPRs (v_readlane / v_writelane), not in memory;
+//  * they meet at SYNCHRONISATION POINTS: the vector waves leave per-lane partial sums in LDS, barrier, each vector
+//    wave folds the blocks and does the 64-lane butterfly for ITS SHARE of the dots (value n belongs to wave n mod NW:
+//    the reductions of one merge run in parallel on four SIMDs instead of one after the other on one), leaves the
+//    scalars in LDS, barrier.  Every wave then reads the scalars and takes the same decisions from them — divergent?
+//    turning? — with a few uniform instructions: a single wave issues one instruction every four cycles, so a control
+//    wave in the decision loop was the bottleneck, not a help.  The control wave reads the same scalars and does
+//    everything slow (both logaddexp's of the merge, the Exp(1) draw, proposal selection, slot bookkeeping,
+//    termination, acceptance statistic) while the vector waves are already integrating the next leapfrog.  The one
+//    thing the vector waves need from it — whether the leaf they just left must be kept as a proposal, and in which
+//    slot — reaches them one leaf late through a mailbox word: they hold a copy of that leaf's position (qkeep) until
+//    the next leaf's synchronisation says where to store it, if anywhere;
+//  * one synchronisation per leaf (which also carries the level-0 / depth-0 leaf+leaf merge: half of all merges, two
+//    dots, computed speculatively with the leapfrog), one per higher merge, one per transition (final proposal, next
+//    ϵ and directions; the next momentum is sampled before it, while the control wave does dual averaging).
+//    Both sides run the same replicated integer control (direction bits, depth, leaf counter, cascade level) from
+//    the same scalars, so they execute the same barrier sequence by construction.
 //
 // Arithmetic, RNG consumption and every output bit equal nuts_run_kernel's and the oracle's (DHMC_MW=0 selects the
 // one-wave kernel; tests/test_gpu_engines.py compares the two).
@@ -33,32 +42,27 @@
 namespace dhmc {
 
 constexpr int MW_NK = 4;                                     // slots per lane of a vector wave: one 256-coordinate block
-enum : uint32_t { MWV_DIV = 1u, MWV_TURN = 2u, MWV_SCAN = 4u };
-// verdict: bits 0-7 flags; 8-15: 1 + proposal slot the leaf held in registers must be written to now (0: none);
-//          16-23: ζ of the whole trajectory (the slot that becomes the chain's position if the transition ends here)
+// mailbox words (control wave -> vector waves): pend = 1 + proposal slot the PREVIOUS leaf's position (qkeep) must be
+// written to (0: none), read at every leaf and at the end of a transition; zeta = ζ of the trajectory = the slot that
+// becomes the chain's position, read at the end of a transition.
 
 // LDS of one chain: five Dpad-rows (suspended levels 0 and 1, the trajectory's two edge momenta), the vector waves'
-// partial sums, and the control wave's per-level / per-slot scalars (sized by max_depth): 53.8 KB at Dpad = 1024,
-// max_depth = 10 — three chains (15 waves) per CU.
-__host__ __device__ inline int mw_nlev(int max_depth) { return max_depth; }
-__host__ __device__ inline int mw_nslot(int max_depth) { return ws_nslots(max_depth); }
-__host__ __device__ inline size_t mw_lds_bytes(int Dpad, int NW, int max_depth) {
-    return sizeof(double) * ((size_t)5 * Dpad + 6 * NW * WAVE + 3 * mw_nlev(max_depth) + 2 * mw_nslot(max_depth) + 2) +
-           sizeof(int) * (mw_nlev(max_depth) + 8);
+// per-lane partial sums, the reduced scalars and a small mailbox: 53.3 KB at Dpad = 1024.
+__host__ __device__ inline size_t mw_lds_bytes(int Dpad, int NW) {
+    return sizeof(double) * ((size_t)5 * Dpad + 6 * NW * WAVE + 6 + 2) + sizeof(uint32_t) * (4 + NW);
 }
 
 struct MwLds {
     double *l0, *l1f, *l1l;          // [Dpad] each: suspended level 0 momentum, level 1 (first, last)
     double *tpm, *tpp;               // [Dpad] each: p₋ and p₊ of the whole trajectory (its ρ stays in registers)
-    double* part;                    // [6][NW][64] partial sums of the vector waves
-    double *lv_omega, *lv_vlsa, *lv_vsteps, *sl_lq, *sl_pi;   // control wave's per-level / per-slot scalars
-    double* mb_f;                    // mailbox: [0] ϵ of the transition
-    int* lv_zeta;
-    uint32_t* mb_u;                  // mailbox: [0] verdict, [1] directions, [2 + w] position-scan flag of vector wave w
+    double* part;                    // [6][NW][64] per-lane partial sums of the vector waves
+    double* red;                     // [6] the reduced dots of the current synchronisation point
+    double* mb_f;                    // mailbox: [0] ϵ of the transition, [1] ℓq of the chain's position
+    uint32_t* mb_u;                  // mailbox: [0], [1] pend (by parity of the synchronisation point), [2] zeta, [3] directions,
+                                     //          [4 + w] position-scan flag of vector wave w
 };
 
-__device__ __forceinline__ MwLds mw_carve(double* lds, int Dpad, int NW, int max_depth) {
-    const int nlev = mw_nlev(max_depth), nslot = mw_nslot(max_depth);
+__device__ __forceinline__ MwLds mw_carve(double* lds, int Dpad, int NW) {
     MwLds L;
     L.l0 = lds;
     L.l1f = lds + Dpad;
@@ -66,16 +70,27 @@ __device__ __forceinline__ MwLds mw_carve(double* lds, int Dpad, int NW, int max
     L.tpm = lds + 3 * Dpad;
     L.tpp = lds + 4 * Dpad;
     L.part = lds + 5 * Dpad;
-    L.lv_omega = L.part + 6 * NW * WAVE;
-    L.lv_vlsa = L.lv_omega + nlev;
-    L.lv_vsteps = L.lv_vlsa + nlev;
-    L.sl_lq = L.lv_vsteps + nlev;
-    L.sl_pi = L.sl_lq + nslot;
-    L.mb_f = L.sl_pi + nslot;
-    L.lv_zeta = (int*)(L.mb_f + 2);
-    L.mb_u = (uint32_t*)(L.lv_zeta + nlev);
+    L.red = L.part + 6 * NW * WAVE;
+    L.mb_f = L.red + 6;
+    L.mb_u = (uint32_t*)(L.mb_f + 2);
     return L;
 }
+
+// Timeline instrumentation for tools/experiments (compiled in with -DMW_TRACE only): chain 0's waves append
+// (event << 56 | clock) words to a device array that dhmc_debug_mw_trace copies out.
+#ifdef MW_TRACE
+__device__ unsigned long long g_mw_trace[8][4096];
+__device__ unsigned int g_mw_trace_n[8];
+#define MW_T(wave_, ev_)                                                                                   \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                                  \
+            const unsigned int i_ = g_mw_trace_n[wave_]++;                                                 \
+            if (i_ < 4096u) g_mw_trace[wave_][i_] = ((unsigned long long)(ev_) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+        }                                                                                                  \
+    } while (0)
+#else
+#define MW_T(wave_, ev_) do {} while (0)
+#endif
 
 // Workgroup barrier that orders LDS traffic only (outstanding global stores — draws, proposal slots — keep flying).
 __device__ __forceinline__ void mw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -124,8 +139,58 @@ __device__ __forceinline__ void mw_merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP
     for (int i = 0; i < 6; ++i) my_part[i * PS] = a[i];
 }
 
+// One vector wave's share of a synchronisation point's reductions: value n (n < N) belongs to wave n mod NW.  Blocks
+// folded per lane by adjacent pairs, then the 64-lane butterfly (the ABI's order); the scalar goes to red[n].
+template <int NW>
+__device__ __forceinline__ double mw_fold_blocks(const double* __restrict__ part, int n, int lane) {
+    double t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = part[(n * NW + w) * WAVE + lane];
+#pragma unroll
+    for (int s = 1; s < NW; s *= 2)
+#pragma unroll
+        for (int w = 0; w + s < NW; w += 2 * s) t[w] = t[w] + t[w + s];
+    return t[0];
+}
+template <int NW>
+__device__ __forceinline__ void mw_reduce_share(const MwLds& L, int N, int wv, int lane) {
+    for (int n0 = wv; n0 < N; n0 += 2 * NW) {
+        const int n1 = n0 + NW;
+        if (n1 < N) {                 // two values on this wave: their butterflies interleave
+            double r[2] = {mw_fold_blocks<NW>(L.part, n0, lane), mw_fold_blocks<NW>(L.part, n1, lane)};
+            wave_allreduce<2>(r);
+            if (lane == 0) { L.red[n0] = r[0]; L.red[n1] = r[1]; }
+        } else {
+            const double r = wave_allreduce1(mw_fold_blocks<NW>(L.part, n0, lane));
+            if (lane == 0) L.red[n0] = r;
+        }
+    }
+}
+
+// What every wave derives from the scalars of a leaf synchronisation (same data, same code: same decisions everywhere).
+struct MwLeaf {
+    double lq, pi;
+    bool div, turning, pos_finite;
+};
+// leaf (NUTS.jl:148-159) from ℓ's reduced sum and p·M⁻¹p; evaluate_ℓ's demotion rules (hamiltonian.jl:202-217)
+template <class T>
+__device__ __forceinline__ MwLeaf mw_leaf_decide(const T& tgt, const double* red, bool fused, bool pos_finite, double pi0, double min_delta) {
+    MwLeaf R;
+    double lq = uni_f64(tgt.finish(uni_f64(red[0])));
+    const double K = uni_f64(red[1]) / 2.0;
+    lq = demote_lq(lq, pos_finite, true);
+    R.lq = lq;
+    R.pi = uni_f64(joint_logdensity(lq, K));
+    R.div = (R.pi - pi0) < min_delta;                               // NUTS.jl:150-151
+    R.turning = fused && (uni_f64(red[2]) < 0 || uni_f64(red[3]) < 0);
+    R.pos_finite = pos_finite;
+    return R;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Vector wave `wv` of the chain: every D-vector operation of the transition on coordinates 256 wv + lane + 64 k.
+// Partial sums of a leaf synchronisation: [0] Σ of ℓ's summand, [1] p·M⁻¹p, [2], [3] the two dots of the leaf+leaf
+// merge that follows (odd leaves, and the first leaf of a transition), [4] p₀·M⁻¹p₀ (first leaf of a transition).
 // ------------------------------------------------------------------------------------------------------------
 template <class T, int NW>
 __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& L, const int chain, const int wv, const int lane) {
@@ -148,25 +213,25 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
     const uint32_t idx_base = (uint32_t)(lane + 2 * WAVE * wv);  // momentum stream call index of slots (0,1); +64 for (2,3)
     const uint32_t tr0 = P.st.transition[chain];
 
-    double m[NK], q[NK], p[NK], g[NK], cf[NK], cr[NK], trho[NK];
+    double m[NK], q[NK], p[NK], g[NK], cf[NK], cr[NK], trho[NK], qkeep[NK];
     ldk<NK>(P.st.minv + row, m);
     ldk<NK>(P.st.q + row, q);
     ldk<NK>(P.st.g + row, g);
 #pragma unroll
-    for (int k = 0; k < NK; ++k) { cf[k] = 0.0; cr[k] = 0.0; }
+    for (int k = 0; k < NK; ++k) { cf[k] = 0.0; cr[k] = 0.0; qkeep[k] = q[k]; }
 
-    auto sync = [&]() -> uint32_t {   // partial sums are in LDS: wait for the control wave's verdict
+    uint32_t par = 0;                 // parity of the synchronisation point: which pend word the control wave wrote for it
+    auto sync = [&](int N) {          // N per-lane partial sums are in LDS: reduce my share, leave the scalars in L.red
+        par ^= 1u;
+        MW_T(wv, 1);
         mw_barrier();
+        MW_T(wv, 2);
+        mw_reduce_share<NW>(L, N, wv, lane);
+        MW_T(wv, 3);
         mw_barrier();
-        return uni_u32(L.mb_u[0]);
+        MW_T(wv, 4);
     };
-
-    int init_slot = 0;
-    stk<NK>(wsv(ws_slot(max_depth, init_slot, 0)), q);
-
-    for (int64_t n = 0; n < P.N; ++n) {
-        const uint32_t tr = tr0 + (uint32_t)n;
-        // ---- rand_p (hamiltonian.jl:124) and this block's part of K(p) for π₀ ---------------------------
+    auto sample_momentum_block = [&](uint32_t tr) {             // rand_p (hamiltonian.jl:124) on this block
 #pragma unroll
         for (int kk = 0; kk < NK / 2; ++kk) {
             uint64_t r1, r2;
@@ -176,17 +241,28 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
             p[2 * kk] = Wrow[WAVE * (2 * kk)] * z0;
             p[2 * kk + 1] = Wrow[WAVE * (2 * kk + 1)] * z1;
         }
-        {
-            double kacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) kacc = __builtin_fma(p[k], m[k] * p[k], kacc);
-            my_part[0] = kacc;
-        }
-        mw_barrier();
-        mw_barrier();
+    };
+    auto flush_keep = [&]() -> uint32_t {                       // the previous leaf became a proposal: materialise it
+        const uint32_t slot = uni_u32(L.mb_u[par]);
+        if (slot) stk<NK>(wsv(ws_slot(max_depth, (int)slot - 1, 0)), qkeep);
+        return slot;
+    };
+
+    int init_slot = 0;
+    stk<NK>(wsv(ws_slot(max_depth, init_slot, 0)), q);
+    sample_momentum_block(tr0);
+    sync(0);                                                     // ϵ, directions and ℓq of the first transition
+
+    for (int64_t n = 0; n < P.N; ++n) {
+        const uint32_t tr = tr0 + (uint32_t)n;
         const double eps = uni_f64(L.mb_f[0]);
-        uint32_t dirs = uni_u32(L.mb_u[1]);
-        stk<NK>(tpm, p);                                                   // leaf τ of z₀ (NUTS.jl:120-123)
+        const double lq_cur = uni_f64(L.mb_f[1]);
+        uint32_t dirs = uni_u32(L.mb_u[3]);
+        double pi0 = 0.0;
+        double kin0 = 0.0;                                       // this block's part of K(p₀) for π₀
+#pragma unroll
+        for (int k = 0; k < NK; ++k) kin0 = __builtin_fma(p[k], m[k] * p[k], kin0);
+        stk<NK>(tpm, p);                                         // leaf τ of z₀ (NUTS.jl:120-123)
         stk<NK>(tpp, p);
 #pragma unroll
         for (int k = 0; k < NK; ++k) trho[k] = p[k];
@@ -196,7 +272,6 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
         int reg_edge = 2;
         int depth = 0;
         bool finished = false;
-        uint32_t verdict = 0;
         while (!finished && depth < max_depth) {
             const bool fwd = (dirs & 1u) != 0;
             dirs >>= 1;
@@ -235,39 +310,58 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
                 }
                 my_part[0] = lres;
                 my_part[PS] = kacc;
-                verdict = sync();
-                if (verdict & MWV_SCAN) {   // ℓq came out non-finite: evaluate_ℓ's position scan (hamiltonian.jl:203)
+                // an odd leaf is followed by its level-0 merge, the first leaf of a transition by the depth-0 top merge:
+                // both subtrees are single leaves (merge_leaf_leaf of nuts_kernels.hpp: two distinct dots) — computed
+                // now, speculatively, so that the leaf and that merge cost one synchronisation
+                const bool fused = (j & 1u) != 0 || depth == 0;
+                if (fused) {
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const double pa = depth == 0 ? trho[k] : l0[WAVE * k];
+                        const double r = pa + p[k];
+                        a0 = __builtin_fma(m[k] * pa, r, a0);
+                        a1 = __builtin_fma(m[k] * p[k], r, a1);
+                        cf[k] = pa;
+                        cr[k] = r;
+                    }
+                    my_part[2 * PS] = a0;
+                    my_part[3 * PS] = a1;
+                    if (depth == 0) my_part[4 * PS] = kin0;
+                }
+                sync(depth == 0 ? 5 : (fused ? 4 : 2));
+                if (depth == 0) pi0 = uni_f64(joint_logdensity(lq_cur, uni_f64(L.red[4]) / 2.0));   // logdensity(H, z₀) (NUTS.jl:234)
+                bool pos_finite = true;
+                if (!dm_isfinite(uni_f64(tgt.finish(uni_f64(L.red[0]))))) {
+                    // ℓq came out non-finite: evaluate_ℓ's position scan (hamiltonian.jl:203), every wave for its block
                     bool fin = true;
 #pragma unroll
                     for (int k = 0; k < NK; ++k) fin = fin && dm_isfinite(q[k]);
                     const bool all = wave_all(fin);
-                    if (lane == 0) L.mb_u[2 + wv] = all ? 1u : 0u;
-                    verdict = sync();
+                    if (lane == 0) L.mb_u[4 + wv] = all ? 1u : 0u;
+                    mw_barrier();
+                    mw_barrier();
+                    uint32_t ok = 1u;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) ok &= uni_u32(L.mb_u[4 + w]);
+                    pos_finite = ok != 0u;
                 }
+                const MwLeaf lf = mw_leaf_decide(tgt, L.red, fused, pos_finite, pi0, P.min_delta);
+                MW_T(wv, 5);
+                (void)flush_keep();                                         // where the previous leaf goes, if anywhere
+#pragma unroll
+                for (int k = 0; k < NK; ++k) qkeep[k] = q[k];               // this leaf's position, until its fate is known
                 int level = 0;
-                if (verdict & MWV_DIV) {
+                if (lf.div) {
                     invalid = true;
                 } else {
+                    bool first = fused;
+                    bool turning = lf.turning;
                     for (;;) {
                         const bool sub = ((j >> level) & 1u) != 0;
                         const bool top = !sub && (j == nleaf - 1) && (level == depth);
                         if (!sub && !top) break;
-                        const bool leafleaf = sub ? (level == 0) : (depth == 0);
-                        if (leafleaf) {
-                            // both subtrees are single leaves (merge_leaf_leaf of nuts_kernels.hpp): two distinct dots
-                            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                            for (int k = 0; k < NK; ++k) {
-                                const double pa = sub ? l0[WAVE * k] : trho[k];
-                                const double r = pa + p[k];
-                                a0 = __builtin_fma(m[k] * pa, r, a0);
-                                a1 = __builtin_fma(m[k] * p[k], r, a1);
-                                cf[k] = pa;
-                                cr[k] = r;
-                            }
-                            my_part[0] = a0;
-                            my_part[PS] = a1;
-                        } else {
+                        if (!first) {
                             // combine_turn_statistics (NUTS.jl:132-139): x earlier in time, y later (trees.jl:135-141)
                             auto a_cf = [&](int k) { return cf[k]; };
                             auto a_p = [&](int k) { return p[k]; };
@@ -297,15 +391,16 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
                                 if (fwd) mw_merge_core(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, m, cf, cr, my_part, PS);
                                 else mw_merge_core(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, m, cf, cr, my_part, PS);
                             }
+                            MW_T(wv, 6);
+                            sync(6);
+                            turning = uni_f64(L.red[0]) < 0 || uni_f64(L.red[1]) < 0 || uni_f64(L.red[2]) < 0 ||
+                                      uni_f64(L.red[3]) < 0 || uni_f64(L.red[4]) < 0 || uni_f64(L.red[5]) < 0;
                         }
-                        verdict = sync();
-                        const bool turning = (verdict & MWV_TURN) != 0;
+                        first = false;
                         if (sub) {
                             level += 1;
                             if (turning) { invalid = true; break; }      // trees.jl:255
                         } else {
-                            const uint32_t slot = (verdict >> 8) & 0xffu;  // the new leaf won the doubling: materialise it
-                            if (slot) stk<NK>(wsv(ws_slot(max_depth, (int)slot - 1, 0)), q);
                             depth += 1;
                             if (turning) {                                 // trees.jl:315-316
                                 finished = true;
@@ -320,8 +415,6 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
                     }
                     if (level >= 0 && !invalid) {
                         // suspend the running subtree at `level` until its right sibling is built
-                        const uint32_t slot = (verdict >> 8) & 0xffu;
-                        if (slot) stk<NK>(wsv(ws_slot(max_depth, (int)slot - 1, 0)), q);
                         if (level == 0) {
                             stk<NK>(l0, p);
                         } else if (level == 1) {
@@ -338,9 +431,20 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
             }
         }
 
-        // ---- the new position (NUTS.jl:238-240) and the draw (mcmc.jl:275,376) ---------------------------
-        init_slot = (int)((verdict >> 16) & 0xffu);
-        ldk<NK>(wsv(ws_slot(max_depth, init_slot, 0)), q);
+        // ---- the next momentum (while the control wave finishes the transition), then the new position
+        //      (NUTS.jl:238-240) and the draw (mcmc.jl:275,376) ----------------------------------------------
+        MW_T(wv, 7);
+        if (n + 1 < P.N) sample_momentum_block(tr + 1u);
+        MW_T(wv, 8);
+        sync(0);
+        const uint32_t last_slot = flush_keep();
+        init_slot = (int)uni_u32(L.mb_u[2]);
+        if (last_slot == (uint32_t)(init_slot + 1)) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) q[k] = qkeep[k];                   // the last leaf is the draw: no round trip
+        } else {
+            ldk<NK>(wsv(ws_slot(max_depth, init_slot, 0)), q);
+        }
         if constexpr (!T::kPointwiseGrad) (void)tgt.eval(q, g, eb, D);
         if (P.out.draws) {
             double* drow = P.out.draws + ((size_t)chain * P.N + n) * D + eb;
@@ -357,22 +461,6 @@ __device__ __forceinline__ void mw_vector_wave(const RunParams& P, const MwLds& 
 // ------------------------------------------------------------------------------------------------------------
 // Control wave: every scalar of the transition.
 // ------------------------------------------------------------------------------------------------------------
-template <int N, int NW>
-__device__ __forceinline__ void mw_reduce(const double* __restrict__ part, int lane, double (&r)[N]) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        double t[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t[w] = part[(n * NW + w) * WAVE + lane];
-#pragma unroll
-        for (int s = 1; s < NW; s *= 2)
-#pragma unroll
-            for (int w = 0; w + s < NW; w += 2 * s) t[w] = t[w] + t[w + s];   // blocks folded per lane, adjacent pairs
-        r[n] = t[0];
-    }
-    wave_allreduce<N>(r);
-}
-
 template <class T, int NW>
 __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds& L, const int chain, const int lane) {
     const int max_depth = P.max_depth;
@@ -393,60 +481,73 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
         da.logeps = le;
         da.logeps_bar = 0.0;
     }
+    LaneArrF64 lv_omega, lv_vlsa, lv_vsteps;      // per suspended level (lane = level): ω, visited statistic
+    LaneArrI32 lv_zeta;                           //   … and the proposal slot
+    LaneArrF64 sl_lq, sl_pi;                      // per proposal slot (lane = slot): ℓq and π of the point stored there
     int init_slot = 0;
     uint64_t free_mask = 0;
-    auto publish = [&](uint32_t verdict) {
-        if (lane == 0) L.mb_u[0] = verdict;
+    uint32_t pend = 0;                            // 1 + slot the vector waves must write the leaf they last left to
+    uint32_t par = 0;
+    // a synchronisation point seen from here: say where the leaf the vector waves last left goes (if this is a point
+    // where they look), then wait for them to reduce; the scalars are in L.red afterwards
+    auto csync = [&](bool leaf_or_final) {
+        par ^= 1u;
+        if (lane == 0) L.mb_u[par] = leaf_or_final ? pend : 0u;
+        if (leaf_or_final) pend = 0;
+        MW_T(NW, 11);
         mw_barrier();
+        MW_T(NW, 12);
+        mw_barrier();
+        MW_T(NW, 13);
     };
     auto alloc_slot = [&](double lq_leaf, double pi_leaf) -> int {   // bookkeeping of save_leaf: the vector waves store q
         const int s = __builtin_ctzll(free_mask);
         free_mask &= ~(1ull << s);
-        if (lane == 0) { L.sl_lq[s] = lq_leaf; L.sl_pi[s] = pi_leaf; }
+        sl_lq.set(s, lq_leaf, lane);
+        sl_pi.set(s, pi_leaf, lane);
+        pend = (uint32_t)(s + 1);
         return s;
     };
 
-    for (int64_t n = 0; n < P.N; ++n) {
-        const uint32_t tr = tr0 + (uint32_t)n;
-        const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
-        uint32_t dirs;
-        {
-            uint32_t w[4];
-            philox4x32_10(0u, PURPOSE_DIRECTIONS, tr, key.seed_hi, key.k0, key.k1, w);
-            dirs = uni_u32(w[0]);
-        }
-        const uint32_t directions0 = dirs;
+    // ϵ and the directions of a transition (stepsize.jl:163; trees.jl:23), left in the mailbox for the vector waves
+    double eps = 0.0;
+    uint32_t dirs = 0, directions0 = 0;
+    uint32_t nrand = 0, rexp_base = 0;
+    double rexp_vals = 0.0;
+    uint32_t tr = tr0;
+    auto rexp_fill = [&](uint32_t base) {         // Exp(1) draws of this transition, 64 at a time: lane l holds draw (base + l)
+        uint64_t r1, r2;
+        stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
+        rexp_vals = det_randexp(r1);
+        rexp_base = base;
+    };
+    auto randexp = [&]() -> double {              // Random.randexp at NUTS.jl:44
+        if (nrand - rexp_base >= 64u) rexp_fill(nrand & ~63u);
+        const double v = readlane_f64(rexp_vals, (int)(nrand & 63u));
+        nrand += 1;
+        return v;
+    };
+    auto begin_transition = [&]() {
+        eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);
+        uint32_t w[4];
+        philox4x32_10(0u, PURPOSE_DIRECTIONS, tr, key.seed_hi, key.k0, key.k1, w);
+        dirs = uni_u32(w[0]);
+        directions0 = dirs;
         if (lane == 0) {
             L.mb_f[0] = eps;
-            L.mb_u[1] = dirs;
-            L.sl_lq[init_slot] = lq_cur;
+            L.mb_u[3] = dirs;
         }
-        // Exp(1) draws of this transition, 64 at a time: lane l holds draw (rexp_base + l)
-        uint32_t nrand = 0, rexp_base = 0;
-        double rexp_vals;
-        auto rexp_fill = [&](uint32_t base) {
-            uint64_t r1, r2;
-            stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
-            rexp_vals = det_randexp(r1);
-            rexp_base = base;
-        };
+        nrand = 0;
         rexp_fill(0);
-        auto randexp = [&]() -> double {  // Random.randexp at NUTS.jl:44
-            if (nrand - rexp_base >= 64u) rexp_fill(nrand & ~63u);
-            const double v = readlane_f64(rexp_vals, (int)(nrand & 63u));
-            nrand += 1;
-            return v;
-        };
-        double pi0;
-        mw_barrier();                                   // the blocks' parts of p·M⁻¹p are in LDS
-        {
-            double r[1];
-            mw_reduce<1, NW>(L.part, lane, r);
-            pi0 = uni_f64(joint_logdensity(lq_cur, r[0] / 2.0));
-            if (lane == 0) L.sl_pi[init_slot] = pi0;
-        }
-        mw_barrier();                                   // ϵ and the directions are published
+    };
 
+    begin_transition();
+    if (lane == 0) { L.mb_f[1] = lq_cur; L.mb_u[2] = 0u; }
+    csync(true);
+
+    for (int64_t n = 0; n < P.N; ++n) {
+        sl_lq.set(init_slot, lq_cur, lane);
+        double pi0 = 0.0;
         free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
         int zeta_top = init_slot;
         double omega_top = 0.0;
@@ -466,70 +567,62 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
             double v_lsa = 0.0;
             int64_t v_steps = 0;
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
-                // ---- the leaf (NUTS.jl:148-159) ---------------------------------------------------------
-                mw_barrier();
-                double lq_leaf, pi_leaf;
-                {
-                    double r[2];
-                    mw_reduce<2, NW>(L.part, lane, r);
-                    double lq = uni_f64(tgt.finish(r[0]));
-                    const double K = r[1] / 2.0;
-                    bool pos_finite = true;
-                    if (!dm_isfinite(lq)) {      // evaluate_ℓ's position scan is the vector waves' (hamiltonian.jl:203)
-                        publish(MWV_SCAN);
-                        mw_barrier();
-                        uint32_t all = 1u;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) all &= uni_u32(L.mb_u[2 + w]);
-                        pos_finite = all != 0u;
-                    }
-                    lq = demote_lq(lq, pos_finite, true);
-                    if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
-                    lq_leaf = lq;
-                    pi_leaf = uni_f64(joint_logdensity(lq, K));
+                // ---- the leaf (NUTS.jl:148-159), and the leaf+leaf merge's turn test when it follows at once -----
+                const bool fused = (j & 1u) != 0 || depth == 0;
+                csync(true);
+                if (depth == 0) {
+                    pi0 = uni_f64(joint_logdensity(lq_cur, uni_f64(L.red[4]) / 2.0));   // logdensity(H, z₀) (NUTS.jl:234)
+                    sl_pi.set(init_slot, pi0, lane);
                 }
+                bool pos_finite = true;
+                if (!dm_isfinite(uni_f64(tgt.finish(uni_f64(L.red[0]))))) {   // evaluate_ℓ's position scan is the vector waves' (hamiltonian.jl:203)
+                    mw_barrier();
+                    mw_barrier();
+                    uint32_t ok = 1u;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) ok &= uni_u32(L.mb_u[4 + w]);
+                    pos_finite = ok != 0u;
+                }
+                const MwLeaf lf = mw_leaf_decide(tgt, L.red, fused, pos_finite, pi0, P.min_delta);
+                if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
+                const double lq_leaf = lf.lq, pi_leaf = lf.pi;
+                bool turning = lf.turning;
+                const double delta = pi_leaf - pi0;             // NUTS.jl:150
+                const bool div = lf.div;                        // divergent leaf (NUTS.jl:151; trees.jl:236-237)
+                MW_T(NW, 14);
+                // ---- from here on the vector waves are already integrating the next leapfrog ---------------
                 i += di;
                 total_steps += 1;
-                const double delta = pi_leaf - pi0;             // NUTS.jl:150
                 v_lsa = delta < 0.0 ? delta : 0.0;              // min(Δ, 0)   (NUTS.jl:79)
                 v_steps = 1;
                 int level = 0;
-                const bool div = delta < P.min_delta;           // divergent leaf (NUTS.jl:151; trees.jl:236-237)
-                publish((div ? MWV_DIV : 0u) | ((uint32_t)(__builtin_ctzll(free_mask) + 1) << 8) | ((uint32_t)zeta_top << 16));
                 if (div) {
                     term_left = term_right = i;
                     invalid = true;
                 } else {
                     double c_omega = delta;
-                    int c_zeta = -1;  // -1: the proposal is the leaf the vector waves hold in registers
+                    int c_zeta = -1;  // -1: the proposal is the leaf the vector waves keep in qkeep
+                    bool first = fused;
                     for (;;) {
                         const bool sub = ((j >> level) & 1u) != 0;
                         const bool top = !sub && (j == nleaf - 1) && (level == depth);
                         if (!sub && !top) break;
-                        const bool leafleaf = sub ? (level == 0) : (depth == 0);
-                        // v = v₋ ⊕ v₊ (trees.jl:249 / :294) and ω = logaddexp(ω₋, ω₊) (trees.jl:145): independent of the
-                        // dots, so computed while the vector waves are still producing them
-                        double v_new, w;
-                        if (sub) logaddexp_pair(uni_f64(L.lv_vlsa[level]), v_lsa, uni_f64(L.lv_omega[level]), c_omega, lane, v_new, w);
-                        else logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, v_new, w);
-                        mw_barrier();
-                        bool turning;
-                        if (leafleaf) {
-                            double r[2];
-                            mw_reduce<2, NW>(L.part, lane, r);
-                            turning = r[0] < 0 || r[1] < 0;
-                        } else {
-                            double r[6];
-                            mw_reduce<6, NW>(L.part, lane, r);
-                            turning = r[0] < 0 || r[1] < 0 || r[2] < 0 || r[3] < 0 || r[4] < 0 || r[5] < 0;
+                        if (!first) {
+                            csync(false);
+                            turning = uni_f64(L.red[0]) < 0 || uni_f64(L.red[1]) < 0 || uni_f64(L.red[2]) < 0 ||
+                                      uni_f64(L.red[3]) < 0 || uni_f64(L.red[4]) < 0 || uni_f64(L.red[5]) < 0;
                         }
+                        first = false;
+                        // v = v₋ ⊕ v₊ (trees.jl:249 / :294) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass on even / odd lanes
+                        double v_new, w;
+                        if (sub) logaddexp_pair(lv_vlsa.get(level), v_lsa, lv_omega.get(level), c_omega, lane, v_new, w);
+                        else logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, v_new, w);
                         if (sub) {
                             v_lsa = v_new;
-                            v_steps += (int64_t)uni_f64(L.lv_vsteps[level]);
+                            v_steps += (int64_t)lv_vsteps.get(level);
                             if (turning) {                       // trees.jl:255
                                 term_left = i - di * (((int64_t)2 << level) - 1);
                                 term_right = i;
-                                publish(MWV_TURN | ((uint32_t)zeta_top << 16));
                                 invalid = true;
                                 level += 1;
                                 break;
@@ -537,7 +630,7 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
                             // combine_proposals_and_logweights(…, is_doubling = false) (trees.jl:258)
                             const double logprob2 = c_omega - w;
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
-                            const int lz = uni_i32(L.lv_zeta[level]);
+                            const int lz = lv_zeta.get(level);
                             if (pick) {
                                 free_mask |= (1ull << lz);
                             } else {
@@ -546,19 +639,14 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
                             }
                             c_omega = w;
                             level += 1;
-                            publish((c_zeta < 0 ? (uint32_t)(__builtin_ctzll(free_mask) + 1) << 8 : 0u) | ((uint32_t)zeta_top << 16));
                         } else {
                             // top level (trees.jl:294-316)
                             vtop_lsa = v_new;
                             vtop_steps += v_steps;
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
-                            uint32_t save = 0;
                             if (pick) {
-                                if (c_zeta < 0) {
-                                    c_zeta = alloc_slot(lq_leaf, pi_leaf);
-                                    save = (uint32_t)(c_zeta + 1);
-                                }
+                                if (c_zeta < 0) c_zeta = alloc_slot(lq_leaf, pi_leaf);
                                 if (zeta_top != init_slot) free_mask |= (1ull << zeta_top);
                                 zeta_top = c_zeta;
                             } else if (c_zeta >= 0) {
@@ -572,29 +660,25 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
                                 term_right = i_plus;
                                 finished = true;
                             }
-                            publish((turning ? MWV_TURN : 0u) | (save << 8) | ((uint32_t)zeta_top << 16));
                             level = -1;  // handled
                             break;
                         }
                     }
                     if (level >= 0 && !invalid) {
-                        // the running subtree is suspended at `level`: the vector waves store its vectors (and the leaf, into
-                        // the slot announced by the last verdict = the lowest free one)
+                        // the running subtree is suspended at `level` (the vector waves store its vectors)
                         if (c_zeta < 0) c_zeta = alloc_slot(lq_leaf, pi_leaf);
-                        if (lane == 0) {
-                            L.lv_omega[level] = c_omega;
-                            L.lv_vlsa[level] = v_lsa;
-                            L.lv_vsteps[level] = (double)v_steps;
-                            L.lv_zeta[level] = c_zeta;
-                        }
+                        lv_omega.set(level, c_omega, lane);
+                        lv_vlsa.set(level, v_lsa, lane);
+                        lv_vsteps.set(level, (double)v_steps, lane);
+                        lv_zeta.set(level, c_zeta, lane);
                     }
                 }
                 if (invalid) {
                     // unwind the recursion: every suspended left sibling contributes its visited statistic (trees.jl:244,249-250)
                     for (int l2 = level; l2 < depth; ++l2) {
                         if ((j >> l2) & 1u) {
-                            v_lsa = uni_f64(det_logaddexp(uni_f64(L.lv_vlsa[l2]), v_lsa));
-                            v_steps += (int64_t)uni_f64(L.lv_vsteps[l2]);
+                            v_lsa = uni_f64(det_logaddexp(lv_vlsa.get(l2), v_lsa));
+                            v_steps += (int64_t)lv_vsteps.get(l2);
                         }
                     }
                     vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));   // trees.jl:294
@@ -610,8 +694,8 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
             return uni_f64(a < 1.0 ? a : 1.0);
         }();
         init_slot = zeta_top;
-        lq_cur = uni_f64(L.sl_lq[init_slot]);
-        const double pi_stat = uni_f64(L.sl_pi[init_slot]);
+        lq_cur = sl_lq.get(init_slot);
+        const double pi_stat = sl_pi.get(init_slot);
         if (lane == 0) {
             const size_t o = (size_t)chain * P.N + n;
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;
@@ -631,6 +715,12 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
             da.logeps = da.mu - __builtin_sqrt(m) / P.gamma * da.Hbar;
             da.logeps_bar += det_pow_pos(m, -P.kappa) * (da.logeps - da.logeps_bar);
         }
+        // ---- the end of the transition for the vector waves: where the last leaf goes, the new position's slot and
+        //      ℓq; the next ϵ and directions
+        tr += 1u;
+        if (n + 1 < P.N) begin_transition();
+        if (lane == 0) { L.mb_f[1] = lq_cur; L.mb_u[2] = (uint32_t)zeta_top; }
+        csync(true);
     }
 
     if (lane == 0) {
@@ -646,11 +736,11 @@ __device__ __forceinline__ void mw_control_wave(const RunParams& P, const MwLds&
 }
 
 template <class T, int NW>
-__global__ __launch_bounds__(WAVE * (NW + 1), 4) void nuts_run_mw_kernel(RunParams P) {
+__global__ __launch_bounds__(WAVE * (NW + 1), 5) void nuts_run_mw_kernel(RunParams P) {
     static_assert(T::kElementwise && T::kDeferred && T::kRecomputeGrad && T::kFiniteLqImpliesFiniteQ && T::kFiniteLqImpliesFiniteGrad,
                   "the multi-wave kernel serves coordinate-wise targets whose position scan is needed only on a non-finite ℓq");
     extern __shared__ double lds[];
-    const MwLds L = mw_carve(lds, P.Dpad, NW, P.max_depth);
+    const MwLds L = mw_carve(lds, P.Dpad, NW);
     const int chain = blockIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = uni_i32((int)(threadIdx.x >> 6));

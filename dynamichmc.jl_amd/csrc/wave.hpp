@@ -88,26 +88,33 @@ __device__ __forceinline__ bool wave_all(bool pred) { return __ballot(pred) == ~
 template <int N, int NPL>
 struct LaneAcc {
     static constexpr int NB = NPL >= 4 ? NPL / 4 : 1;
-    double a[N][NB];
+    static constexpr int LG = NB >= 16 ? 4 : NB >= 8 ? 3 : NB >= 4 ? 2 : NB >= 2 ? 1 : 0;
+    // cur: the block being accumulated; t[l]: the folded sum of a completed, left-aligned group of 2^l blocks that still
+    // waits for its right neighbour (a binary counter over the blocks: the adjacent-pairs tree, built as the blocks
+    // complete, so that at most 1 + log2(NB) partial sums per dot are alive instead of NB)
+    double cur[N];
+    double t[N][LG + 1];
     __device__ __forceinline__ LaneAcc() {
 #pragma unroll
-        for (int n = 0; n < N; ++n)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) a[n][b] = 0.0;
+        for (int n = 0; n < N; ++n) cur[n] = 0.0;
     }
-    // slot k (compile-time after unrolling) of dot n
-    __device__ __forceinline__ void add(int n, int k, double x, double y) { a[n][k / 4] = __builtin_fma(x, y, a[n][k / 4]); }
-    __device__ __forceinline__ void plus(int n, int k, double x) { a[n][k / 4] = a[n][k / 4] + x; }
-    __device__ __forceinline__ double fold(int n) const {
-        double t[NB];
+    // slot k (compile-time after unrolling, ascending) of dot n
+    __device__ __forceinline__ void add(int n, int k, double x, double y) {
+        cur[n] = __builtin_fma(x, y, cur[n]);
+        if (NB > 1 && (k % 4) == 3) {              // block k / 4 is complete
+            const int b = k / 4;
+            double v = cur[n];
+            int l = 0;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) t[b] = a[n][b];
-#pragma unroll
-        for (int w = 1; w < NB; w *= 2)
-#pragma unroll
-            for (int b = 0; b + w < NB; b += 2 * w) t[b] = t[b] + t[b + w];
-        return t[0];
+            for (; l < LG; ++l) {
+                if (((b >> l) & 1) == 0) break;
+                v = t[n][l] + v;                    // left group + right group
+            }
+            t[n][l] = v;
+            cur[n] = 0.0;
+        }
     }
+    __device__ __forceinline__ double fold(int n) const { return NB > 1 ? t[n][LG] : cur[n]; }
     __device__ __forceinline__ void fold_all(double (&out)[N]) const {
 #pragma unroll
         for (int n = 0; n < N; ++n) out[n] = fold(n);
@@ -125,6 +132,31 @@ __device__ __forceinline__ void stv(double* __restrict__ row, int lane, const do
 #pragma unroll
     for (int k = 0; k < NPL; ++k) row[lane + WAVE * k] = v[k];
 }
+
+// Slot k of a chain's D-vector as a functor: from an LDS / HBM row (lane-strided) or from the lane's registers.
+struct LdsRow {
+    const double* row;
+    int lane;
+    __device__ __forceinline__ double operator()(int k) const { return row[lane + WAVE * k]; }
+};
+template <int NPL>
+struct RegRow {
+    const double (&v)[NPL];
+    __device__ __forceinline__ double operator()(int k) const { return v[k]; }
+};
+
+// A small array of wave-uniform scalars held in the LANES of one register: element i lives in lane i (i < 64).
+// v_readlane / v_cndmask instead of an LDS round trip, and no LDS bytes.
+struct LaneArrF64 {
+    double v = 0.0;
+    __device__ __forceinline__ double get(int i) const { return readlane_f64(v, i); }
+    __device__ __forceinline__ void set(int i, double x, int lane) { v = (lane == i) ? x : v; }
+};
+struct LaneArrI32 {
+    int v = 0;
+    __device__ __forceinline__ int get(int i) const { return (int)__builtin_amdgcn_readlane((uint32_t)v, i); }
+    __device__ __forceinline__ void set(int i, int x, int lane) { v = (lane == i) ? x : v; }
+};
 
 // out = S v for symmetric S (rows streamed, coalesced): out_i = Σ_k fma(S[k][i], v_k, ·), k ascending.
 template <int NPL>
