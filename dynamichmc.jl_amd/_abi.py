@@ -48,6 +48,11 @@ class Outputs(C.Structure):
                 ("term_right", C.c_void_p), ("depth", C.c_void_p), ("directions", C.c_void_p)]
 
 
+class TreeStatisticsSummaryABI(C.Structure):
+    _fields_ = [("n", C.c_int64), ("a_mean", C.c_double), ("a_quantiles", C.c_double * 5), ("max_depth", C.c_int64),
+                ("divergence", C.c_int64), ("turning", C.c_int64), ("depth_counts", C.c_int64 * 33)]
+
+
 # int fn(void* user, const double* q, int64 chains, int64 ld, int64 dim, double* lq, double* grad, void* stream)
 LOGDENSITY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
 
@@ -64,7 +69,7 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
            "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes",
            "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
-           "dhmc_set_logdensity_callback", "dhmc_ess_bulk"]
+           "dhmc_set_logdensity_callback", "dhmc_ess_bulk", "dhmc_summarize_tree_statistics"]
 
 _lib = None
 

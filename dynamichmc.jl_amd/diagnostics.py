@@ -1,5 +1,7 @@
-"""Post-hoc NUTS diagnostics over the SoA tree statistics, after DynamicHMC.Diagnostics
-(src/diagnostics.jl) — cold path, host side, per chain."""
+"""Post-hoc NUTS diagnostics over the SoA tree statistics, after DynamicHMC.Diagnostics (src/diagnostics.jl): host
+flavours (numpy, per chain) and the device entry points that read statistics and draws where they lie in HBM
+(`summarize_tree_statistics_device`, `ess_bulk_device`).  The reference estimators the ESS kernels are checked
+against live with the tests (tests/ess_reference.py), not here."""
 from collections import Counter
 
 import numpy as np
@@ -33,48 +35,53 @@ def summarize_tree_statistics(tree_statistics):
                 termination_counts=count_terminations(tree_statistics), depth_counts=count_depths(tree_statistics))
 
 
-def ess_rhat(x):
-    """Multi-chain bulk ESS and R-hat of one scalar, x [C][N] (Vehtari et al. 2021 estimator with
-    Geyer's initial monotone sequence; no rank normalisation).  The reference's tests use
-    MCMCDiagnosticTools.ess_rhat (test/sample-correctness_utilities.jl:40-43), not vendored."""
-    x = np.asarray(x, np.float64)
-    C, N = x.shape
-    xm = x - x.mean(axis=1, keepdims=True)
-    nfft = 1 << (2 * N - 1).bit_length()
-    f = np.fft.rfft(xm, n=nfft, axis=1)
-    acov = np.fft.irfft(f * np.conj(f), n=nfft, axis=1)[:, :N] / N
-    W = (acov[:, 0] * N / (N - 1)).mean()
-    B = x.mean(axis=1).var(ddof=1) * N if C > 1 else 0.0
-    var_plus = W * (N - 1) / N + B / N
-    rho = 1 - (W - acov.mean(axis=0)) / var_plus
-    rho[0] = 1
-    T = N // 2
-    pair = rho[0:2 * T:2] + rho[1:2 * T:2]
-    k = np.argmax(pair <= 0) if (pair <= 0).any() else len(pair)
-    pair = np.minimum.accumulate(np.clip(pair[:k], 0, None))
-    tau = max(-1 + 2 * pair.sum(), 1 / np.log10(C * N))
-    return C * N / tau, float(np.sqrt(var_plus / W))
+class TreeStatisticsSummary(dict):
+    """summarize_tree_statistics' result (diagnostics.jl:47-58): N, a_mean, a_quantiles, termination_counts, depth_counts."""
 
 
-def ess_bulk(x):
-    """Bulk ESS and rank-normalised split-R-hat of one scalar, x [C][N] (Vehtari et al. 2021; the default kind of
-    MCMCDiagnosticTools.ess_rhat, which the reference's tests call): split every chain in two, replace the draws by the
-    normal scores of their average ranks, then the estimator of ess_rhat.  Host flavour (scipy) of `dhmc_ess_bulk`."""
-    from scipy.special import ndtri
-    from scipy.stats import rankdata
-    x = np.asarray(x, np.float64)
-    C, N = x.shape
-    h = N // 2
-    xs = x[:, :2 * h].reshape(2 * C, h)
-    r = rankdata(xs.ravel(), method="average").reshape(xs.shape)
-    return ess_rhat(ndtri((r - 0.375) / (xs.size + 0.25)))
+def summarize_tree_statistics_device(pi, acceptance_rate, term_left, term_right, depth, device=None, stream=None):
+    """EBFMI per chain (diagnostics.jl:29-32) and summarize_tree_statistics (:100-106: mean and ACCEPTANCE_QUANTILES of the
+    acceptance rates, count_terminations :65-82, count_depths :87-95; chains pooled) computed by `dhmc_summarize_tree_statistics`
+    (csrc/treestat_kernels.hpp).  The five [C][N] arrays are the SoA tree statistics of a run: CUDA torch tensors are read
+    where they lie in HBM, numpy arrays are staged by the library.  Returns (summary, ebfmi [C])."""
+    import ctypes as C_
+    from . import _abi as abi
+    arrs = [pi, acceptance_rate, term_left, term_right, depth]
+    on_dev = all(hasattr(a, "is_cuda") and a.is_cuda for a in arrs)
+    if on_dev:
+        import torch
+        want = [torch.float64, torch.float64, torch.int64, torch.int64, torch.int32]
+        if not all(a.is_contiguous() and a.dtype == w for a, w in zip(arrs, want)):
+            raise ValueError("tree statistics must be contiguous [C][N] CUDA tensors (float64, float64, int64, int64, int32)")
+        Cn, N = pi.shape
+        ptrs = [C_.c_void_p(a.data_ptr()) for a in arrs]
+        dev = pi.device.index or 0
+        strm = torch.cuda.current_stream(pi.device).cuda_stream if stream is None else stream
+    else:
+        want = [np.float64, np.float64, np.int64, np.int64, np.int32]
+        arrs = [np.ascontiguousarray(np.asarray(a), w) for a, w in zip(arrs, want)]
+        Cn, N = arrs[0].shape
+        ptrs = [C_.c_void_p(a.ctypes.data) for a in arrs]
+        dev, strm = (0 if device is None else device), stream
+    out = abi.TreeStatisticsSummaryABI()
+    ebfmi = np.zeros(Cn)
+    rc = abi.lib().dhmc_summarize_tree_statistics(C_.c_int32(dev), C_.c_void_p(strm), *ptrs, C_.c_int64(Cn), C_.c_int64(N),
+                                                  C_.c_int(1 if on_dev else 0), C_.byref(out), C_.c_void_p(ebfmi.ctypes.data))
+    if rc != abi.OK:
+        raise RuntimeError(f"dhmc_summarize_tree_statistics: {abi.ERROR_NAMES.get(rc, rc)}")
+    dc = list(out.depth_counts)
+    last = max((i for i, v in enumerate(dc) if v), default=-1)
+    return TreeStatisticsSummary(N=int(out.n), a_mean=float(out.a_mean), a_quantiles=list(out.a_quantiles),
+                                 termination_counts=dict(max_depth=int(out.max_depth), divergence=int(out.divergence),
+                                                         turning=int(out.turning)),
+                                 depth_counts=dc[:last + 1]), ebfmi
 
 
 def ess_bulk_device(draws, coords=None, kind="bulk"):
     """ESS and R-hat per coordinate for draws [C][N][D] held in HBM (a CUDA torch tensor), computed where they lie by
     the library's HIP kernels (csrc/ess_kernels.hpp), so ESS/s can be reported without shipping the draws to the host
     (SURVEY.md §8 f-3).  kind = "bulk": rank-normalised split-chain bulk ESS (`dhmc_ess_bulk`, the estimator of
-    ess_bulk above); "plain": no split, no rank normalisation (`dhmc_ess_rhat`, ess_rhat above).
+    tests/ess_reference.py ess_bulk); "plain": no split, no rank normalisation (`dhmc_ess_rhat`).
     Returns numpy arrays (ess [k], rhat [k])."""
     import ctypes as C_
     from . import _abi as abi
@@ -93,29 +100,6 @@ def ess_bulk_device(draws, coords=None, kind="bulk"):
     if rc != abi.OK:
         raise RuntimeError(f"dhmc_ess_{'bulk' if kind == 'bulk' else 'rhat'}: {abi.ERROR_NAMES.get(rc, rc)}")
     return ess, rhat
-
-
-def ess_bulk_torch(draws, coords=None):
-    """The same estimator with torch FFTs — an independent cross-check of the HIP kernels (tests only)."""
-    import torch
-    C, N, D = draws.shape
-    idx = torch.arange(D, device=draws.device) if coords is None else torch.as_tensor(coords, device=draws.device)
-    x = draws[:, :, idx].permute(2, 0, 1).contiguous()                  # [k][C][N]
-    xm = x - x.mean(dim=2, keepdim=True)
-    nfft = 1 << (2 * N - 1).bit_length()
-    f = torch.fft.rfft(xm, n=nfft, dim=2)
-    acov = torch.fft.irfft(f * f.conj(), n=nfft, dim=2)[:, :, :N] / N
-    W = (acov[:, :, 0] * N / (N - 1)).mean(dim=1)
-    B = x.mean(dim=2).var(dim=1, unbiased=True) * N if C > 1 else torch.zeros_like(W)
-    var_plus = W * (N - 1) / N + B / N
-    rho = 1 - (W[:, None] - acov.mean(dim=1)) / var_plus[:, None]
-    rho[:, 0] = 1
-    T = N // 2
-    pair = rho[:, 0:2 * T:2] + rho[:, 1:2 * T:2]
-    keep = torch.cumprod((pair > 0).to(pair.dtype), dim=1)
-    pair = torch.cummin(pair.clamp(min=0) * keep, dim=1).values * keep
-    tau = torch.clamp(-1 + 2 * pair.sum(dim=1), min=1.0 / np.log10(C * N))
-    return C * N / tau, torch.sqrt(var_plus / W)
 
 
 # ---- diagnostics that call the hot path (device) -------------------------------------------------------------

@@ -482,4 +482,16 @@ void oracle_unit_da_adapt(int det, double delta, double gamma, double kappa, int
     st[0] = A.mu; st[1] = (double)A.m; st[2] = A.Hbar; st[3] = A.logeps; st[4] = A.logeps_bar;
 }
 
+// Post-hoc tree-statistics diagnostics (src/diagnostics.jl:29-106) in the ABI's summation orders: out = {N, a_mean,
+// a_quantiles[5], max_depth, divergence, turning, depth_counts[33]} as doubles / int64 in the dhmc_tree_statistics_summary layout
+int oracle_summarize_tree_statistics(const double* pi, const double* acc, const int64_t* tl, const int64_t* tr, const int32_t* depth,
+                                     int64_t chains, int64_t n, void* summary, double* ebfmi_out) {
+    if (!pi || !acc || !tl || !tr || !depth || !summary || chains < 1 || n < 1) return DHMC_ERR_INVALID_ARGUMENT;
+    const TreeStatisticsSummary S = summarize_tree_statistics(acc, tl, tr, depth, chains, n);
+    std::memcpy(summary, &S, sizeof(S));
+    if (ebfmi_out)
+        for (int64_t c = 0; c < chains; ++c) ebfmi_out[c] = ebfmi(pi + c * n, n);
+    return 0;
+}
+
 }  // extern "C"

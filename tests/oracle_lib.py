@@ -387,3 +387,22 @@ def rand_p_dense(minv, n, seed=1):
     if rc:
         raise ValueError("not positive definite")
     return out, W
+
+
+def summarize_tree_statistics(pi, acceptance_rate, term_left, term_right, depth):
+    """Oracle flavour of dhmc_summarize_tree_statistics (oracle/diagnostics.hpp): returns (summary dict, ebfmi [C])."""
+    class S(C.Structure):
+        _fields_ = [("n", C.c_int64), ("a_mean", C.c_double), ("a_quantiles", C.c_double * 5), ("max_depth", C.c_int64),
+                    ("divergence", C.c_int64), ("turning", C.c_int64), ("depth_counts", C.c_int64 * 33)]
+    a = [np.ascontiguousarray(x, t) for x, t in zip((pi, acceptance_rate, term_left, term_right, depth),
+                                                     (np.float64, np.float64, np.int64, np.int64, np.int32))]
+    Cn, N = a[0].shape
+    out = S(); eb = np.zeros(Cn)
+    rc = lib().oracle_summarize_tree_statistics(*[C.c_void_p(x.ctypes.data) for x in a], C.c_int64(Cn), C.c_int64(N),
+                                                C.byref(out), C.c_void_p(eb.ctypes.data))
+    assert rc == 0
+    dc = list(out.depth_counts)
+    last = max((i for i, v in enumerate(dc) if v), default=-1)
+    return dict(N=int(out.n), a_mean=float(out.a_mean), a_quantiles=list(out.a_quantiles),
+                termination_counts=dict(max_depth=int(out.max_depth), divergence=int(out.divergence), turning=int(out.turning)),
+                depth_counts=dc[:last + 1]), eb

@@ -2,6 +2,8 @@
 Where the oracle cannot cover the full size in seconds, a slice of the chains is compared bit for bit
 (chains are independent and partition independent) and the rest is checked through properties."""
 import numpy as np
+
+import ess_reference
 import pytest
 
 import oracle_lib as ol
@@ -41,7 +43,7 @@ def test_config1_reference_path(pkg):
     assert np.array_equal(r["term_left"], inf["tree_statistics"].termination_left)
     pm = inf["posterior_matrix"]
     assert abs(pm.mean()) < 0.01 and abs(pm.var() - 1) < 0.02
-    ess = min(pkg.diagnostics.ess_rhat(pm[:, :, k])[0] for k in range(0, D, 10))
+    ess = min(ess_reference.ess_rhat(pm[:, :, k])[0] for k in range(0, D, 10))
     assert ess / (C * N) >= 0.5                      # τ = ESS/N ≥ 0.5 (sample-correctness_utilities.jl:67)
 
 
@@ -140,3 +142,80 @@ def test_config5_logistic_p256_slice(pkg):
     assert np.allclose(lq, ref_lq, rtol=1e-11)
     assert np.allclose(g, ref_g, rtol=1e-9, atol=1e-9)
     assert (r["steps"] >= 1).all()
+
+
+def _config3_problem(D=1000, rho=0.5):
+    sig = np.logspace(-1, 1, D)
+    Pc = np.zeros(D) + (1 + rho ** 2) / (1 - rho ** 2); Pc[0] = Pc[-1] = 1 / (1 - rho ** 2)
+    diag = Pc / sig ** 2
+    off = np.zeros(D); off[:D - 1] = -rho / (1 - rho ** 2) / (sig[:-1] * sig[1:])
+    idx = np.arange(D)
+    return np.concatenate([diag, off]), np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
+
+
+def test_config3_two_stream_engine_at_production_width(pkg):
+    """configs[2] through the PRODUCTION branch of the dense round engine: 256 chains at D = 1000 run as two
+    half-batches on two streams (dhmc_capi.hip `nh = 2`); chains from both halves (0..3 and 128..131, reproduced by
+    oracles at those chain offsets) must match bit for bit through an adaptive stage and a fixed one."""
+    D, C = 1000, 256
+    params, Sigma = _config3_problem(D)
+    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=31)
+    q0 = np.random.default_rng(5).normal(size=(C, D)) * np.sqrt(np.diag(Sigma))
+    dev.set_metric_dense(Sigma); dev.init(q0); dev.find_initial_stepsize()
+    eps0 = dev.stepsize()
+    a1 = dev.run(3, da={}); a2 = dev.run(2)
+    assert dev.last_run_rounds() > 0 and (a2["steps"] >= 3).all()
+    for off in (0, 128):
+        ora = ol.Oracle(D, 4, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=31, chain_offset=off, threads=4)
+        ora.set_metric_dense(Sigma); ora.init(q0[off:off + 4]); ora.find_initial_stepsize()
+        assert np.array_equal(eps0[off:off + 4], ora.stepsize())
+        b1 = ora.run(3, da={}); b2 = ora.run(2)
+        for k in b1:
+            assert np.array_equal(a1[k][off:off + 4], b1[k]), (off, k)
+            assert np.array_equal(a2[k][off:off + 4], b2[k]), (off, k)
+
+
+def test_logistic_skinny_gemm_engine_against_oracle(pkg):
+    """The GEMM-gradient round engine with N >= 4096 observations, where G = R·X runs through
+    gemm_skinny_pc_f64_kernel (producer/consumer MFMA waves): 128 chains on the device, chains 0..2 and 125..127 against
+    the oracle (every output of an adaptive stage with a metric update, and of a fixed one)."""
+    rng = np.random.default_rng(12)
+    N, D, C = 4500, 64, 128
+    X = rng.normal(size=(N, D)) / 8
+    y = (rng.random(N) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+    params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_LOGISTIC, target_params=params, seed=14)
+    dev.init(); dev.find_initial_stepsize()
+    a1 = dev.run(8, da={}); dev.update_metric_diag(a1["draws"]); a2 = dev.run(5)
+    assert dev.last_run_rounds() > 0
+    for off in (0, 125):
+        ora = ol.Oracle(D, 3, target=ol.TARGET_LOGISTIC, params=params, seed=14, chain_offset=off, threads=3)
+        ora.init(); ora.find_initial_stepsize()
+        b1 = ora.run(8, da={}); ora.update_metric_diag(b1["draws"]); b2 = ora.run(5)
+        for k in b1:
+            assert np.array_equal(a1[k][off:off + 3], b1[k]), (off, k)
+            assert np.array_equal(a2[k][off:off + 3], b2[k]), (off, k)
+
+
+def test_config5_full_size_bit_exact_against_oracle(pkg):
+    """configs[4] at its full N = 10⁵ observations, p = 256, through the GEMM-gradient round engine (128 chains): ℓ, ∇ℓ
+    and every output of two transitions of chains 0 and 127 are BIT-EQUAL to the oracle's (one k-ascending fma chain
+    of 10⁵ terms per gradient coordinate), not merely close."""
+    rng = np.random.default_rng(7)
+    N, D, C = 100000, 256, 128
+    X = rng.normal(size=(N, D)) / 16
+    y = (rng.random(N) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+    params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_LOGISTIC, target_params=params, seed=9)
+    dev.init(); dev.set_stepsize(0.02)
+    a = dev.run(2)
+    assert dev.last_run_rounds() > 0
+    q, lq, g = dev.position()
+    for off in (0, 127):
+        ora = ol.Oracle(D, 1, target=ol.TARGET_LOGISTIC, params=params, seed=9, chain_offset=off, threads=1)
+        ora.init(); ora.set_stepsize(0.02)
+        b = ora.run(2)
+        for k in b:
+            assert np.array_equal(a[k][off:off + 1], b[k]), (off, k)
+        qo, lqo, go = ora.position()
+        assert np.array_equal(q[off:off + 1], qo) and np.array_equal(lq[off:off + 1], lqo) and np.array_equal(g[off:off + 1], go)

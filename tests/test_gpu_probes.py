@@ -2,6 +2,8 @@
 explore_log_acceptance_ratios (src/diagnostics.jl:144-152, 214-227) — through the C ABI, bit for bit against
 the oracle, plus the reference's own tests for them (test/test_diagnostics.jl:42-76) through the host API."""
 import numpy as np
+
+import ess_reference
 import pytest
 
 import oracle_lib as ol
@@ -145,9 +147,9 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
         coords = np.arange(D, dtype=np.int32)[:: max(1, D // 7)]
         t = torch.from_numpy(x).cuda()
         ess, rhat = pkg.diagnostics.ess_bulk_device(t, coords, kind="plain")
-        e2, r2 = pkg.diagnostics.ess_bulk_torch(t, torch.from_numpy(coords).long().cuda())
+        e2, r2 = ess_reference.ess_bulk_torch(t, torch.from_numpy(coords).long().cuda())
         for k, j in enumerate(coords):
-            eh, rh = pkg.diagnostics.ess_rhat(x[:, :, j])
+            eh, rh = ess_reference.ess_rhat(x[:, :, j])
             assert np.isclose(ess[k], eh, rtol=1e-9), (C, N, j, ess[k], eh)
             assert np.isclose(rhat[k], rh, rtol=1e-12)
         assert np.allclose(ess, e2.cpu().numpy(), rtol=1e-9) and np.allclose(rhat, r2.cpu().numpy(), rtol=1e-12)
@@ -156,7 +158,7 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
         tt = torch.from_numpy(xt).cuda()
         eb, rb = pkg.diagnostics.ess_bulk_device(tt, coords)
         for k, j in enumerate(coords):
-            eh, rh = pkg.diagnostics.ess_bulk(xt[:, :, j])
+            eh, rh = ess_reference.ess_bulk(xt[:, :, j])
             assert np.isclose(eb[k], eh, rtol=1e-7), (C, N, j, eb[k], eh)
             assert np.isclose(rb[k], rh, rtol=1e-9)
     with pytest.raises(RuntimeError):
@@ -171,3 +173,30 @@ def test_ess_rhat_longest_series(pkg):
     assert (ess > 0.5 * 2 * 7680).all() and (np.abs(rhat - 1) < 0.01).all()
     with pytest.raises(RuntimeError):
         pkg.diagnostics.ess_bulk_device(torch.zeros((1, 7681, 1), dtype=torch.float64, device="cuda"), kind="plain")
+
+
+def test_tree_statistics_summary_on_device(pkg):
+    """dhmc_summarize_tree_statistics (HIP: EBFMI per chain, count_terminations, count_depths, mean and quantiles of the
+    acceptance rates, src/diagnostics.jl:29-106) bit for bit against the oracle's restatement — on the statistics of a
+    real funnel run (divergences, several depths), from device tensors where dhmc_run left them and from host arrays."""
+    import torch
+    C, N, D = 96, 120, 30
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=6, max_depth=6)
+    dev.init(); dev.find_initial_stepsize()
+    dev.run(40, da={}, fields=[])
+    out = {"pi": torch.empty((C, N), dtype=torch.float64, device="cuda"), "acceptance_rate": torch.empty((C, N), dtype=torch.float64, device="cuda"),
+           "term_left": torch.empty((C, N), dtype=torch.int64, device="cuda"), "term_right": torch.empty((C, N), dtype=torch.int64, device="cuda"),
+           "depth": torch.empty((C, N), dtype=torch.int32, device="cuda")}
+    dev.run_into(N, out)
+    S, eb = pkg.diagnostics.summarize_tree_statistics_device(out["pi"], out["acceptance_rate"], out["term_left"], out["term_right"], out["depth"])
+    host = {k: v.cpu().numpy() for k, v in out.items()}
+    So, ebo = ol.summarize_tree_statistics(host["pi"], host["acceptance_rate"], host["term_left"], host["term_right"], host["depth"])
+    assert dict(S) == So                                    # counts and floating point alike: same summation orders
+    assert np.array_equal(eb, ebo)
+    S2, eb2 = pkg.diagnostics.summarize_tree_statistics_device(host["pi"], host["acceptance_rate"], host["term_left"], host["term_right"], host["depth"])
+    assert dict(S2) == So and np.array_equal(eb2, ebo)      # host arrays staged by the library
+    assert So["termination_counts"]["divergence"] + So["termination_counts"]["max_depth"] > 0 and len(So["depth_counts"]) >= 4
+    ts = type("TS", (), dict(pi=host["pi"], acceptance_rate=host["acceptance_rate"], termination_left=host["term_left"],
+                             termination_right=host["term_right"], depth=host["depth"]))
+    assert np.allclose(eb, pkg.diagnostics.EBFMI(ts), rtol=1e-10)                       # the host numpy flavour agrees
+    assert pkg.diagnostics.count_terminations(ts) == So["termination_counts"]

@@ -8,6 +8,8 @@ cases — three isolated ill-conditioned MVNs, 1-D huge/tiny variance, scaled di
 import warnings
 
 import numpy as np
+
+import ess_reference
 import pytest
 from scipy import stats
 
@@ -27,7 +29,7 @@ def nuts_tests(pkg, l, exact_sampler, N, K=5, seed=1, R_fail=1.02, tau_fail=0.5,
     r = pkg.mcmc_with_warmup(seed, l, N, chains=K, reporter=pkg.NoProgressReport(), **mcmc_args)
     pm = r["posterior_matrix"]                                   # [K][N][d]
     d = pm.shape[2]
-    stat = [pkg.diagnostics.ess_bulk(pm[:, :, k]) for k in range(d)]     # MCMCDiagnosticTools.ess_rhat default: bulk, split chains
+    stat = [ess_reference.ess_bulk(pm[:, :, k]) for k in range(d)]     # MCMCDiagnosticTools.ess_rhat default: bulk, split chains
     rhat = max(s[1] for s in stat); tau = min(s[0] for s in stat) / N
     assert rhat <= R_fail, f"R̂ = {rhat}"
     assert tau >= tau_fail, f"τ = {tau}"

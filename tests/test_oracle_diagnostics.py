@@ -71,3 +71,24 @@ def test_positions_must_contain_zero():   # diagnostics.jl:218
         o.leapfrog_trajectory(0.1, 1, 3)
     with pytest.raises(ol.OracleError):
         o.leapfrog_trajectory(0.1, -3, -1)
+
+
+def test_tree_statistics_summary_against_numpy():
+    """oracle/diagnostics.hpp summarize_tree_statistics + ebfmi (src/diagnostics.jl:29-106 in the ABI's summation orders)
+    against the plain numpy formulas: counts exact, floating point to rounding."""
+    rng = np.random.default_rng(5)
+    C, N = 7, 333
+    pi = rng.normal(size=(C, N)).cumsum(axis=1) * 0.3 - 500
+    acc = rng.beta(5, 1.2, size=(C, N))
+    depth = rng.integers(0, 7, size=(C, N)).astype(np.int32)
+    kind = rng.integers(0, 3, size=(C, N))
+    tl = np.where(kind == 0, 1, np.where(kind == 1, 5, -3)).astype(np.int64)
+    tr = np.where(kind == 0, 0, np.where(kind == 1, 5, 4)).astype(np.int64)
+    S, eb = ol.summarize_tree_statistics(pi, acc, tl, tr, depth)
+    assert S["N"] == C * N
+    assert S["termination_counts"] == dict(max_depth=int((kind == 0).sum()), divergence=int((kind == 1).sum()), turning=int((kind == 2).sum()))
+    assert S["depth_counts"] == np.bincount(depth.ravel()).tolist()
+    assert np.isclose(S["a_mean"], acc.mean(), rtol=1e-13)
+    assert np.allclose(S["a_quantiles"], np.quantile(acc, [0.05, 0.25, 0.5, 0.75, 0.95]), rtol=1e-12)   # Julia's default = numpy's "linear"
+    ref = (np.diff(pi, axis=1) ** 2).mean(axis=1) / pi.var(axis=1, ddof=1)                              # diagnostics.jl:29-32
+    assert np.allclose(eb, ref, rtol=1e-11)
