@@ -245,12 +245,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    local_rank %= max(1, torch.cuda.device_count())     # a launcher that hides all but one GPU per rank leaves one device
+    ndev = max(1, torch.cuda.device_count())
+    shared_device = world > ndev and "ROCR_VISIBLE_DEVICES" not in os.environ and "HIP_VISIBLE_DEVICES" not in os.environ
+    local_rank %= ndev                                   # a launcher that hides all but one GPU per rank leaves one device
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_dev = "cuda"
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_device:
+            # several ranks on ONE GPU (a readiness run of the multi-process path on a 1-GPU box): RCCL refuses two ranks
+            # on the same device, so the three small collectives go over gloo with host tensors; the per-rank HIP path,
+            # the sharding and the reductions are the ones of the 8-GPU run
+            backend, coll_dev = "gloo", "cpu"
+            dist.init_process_group("gloo")
+        else:
+            backend = "nccl"
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -301,16 +313,17 @@ def main():
 
     t_max, total_leapfrogs, ess_rate = dt, leapfrogs, ess / ess_dt
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ll = torch.tensor([leapfrogs, ess / ess_dt], device="cuda", dtype=torch.float64)
+        ll = torch.tensor([leapfrogs, ess / ess_dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(ll, op=dist.ReduceOp.SUM)
         t_max, total_leapfrogs, ess_rate = float(tt[0]), float(ll[0]), float(ll[1])
         # the one collective of the path: gather the last draw of every chain over RCCL/xGMI
-        last = out["draws"][:, -1, :].contiguous()
-        gathered = torch.empty((world * C, D), dtype=torch.float64, device="cuda")
+        last = out["draws"][:, -1, :].contiguous().to(coll_dev)
+        gathered = torch.empty((world * C, D), dtype=torch.float64, device=coll_dev)
         dist.all_gather_into_tensor(gathered, last)
         torch.cuda.synchronize()
+        assert bool(torch.equal(gathered[rank * C:(rank + 1) * C], last))
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
@@ -331,7 +344,8 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "dim": D, "chains_per_gpu": C, "transitions_per_step": T,
                        "phase": "sampling (fixed adapted eps and M^-1 per chain)", "max_depth": 10,
-                       "parallelism": f"chains sharded x{world}, no data-path collective"},
+                       "parallelism": f"chains sharded x{world}, no data-path collective",
+                       "collective_backend": backend},
             "ess_per_sec": ess_rate,
             "ess_note": f"min rank-normalised split-chain bulk ESS (Vehtari et al. 2021; dhmc_ess_bulk) over 16 coordinates, "
                         f"the last {ess_T} draws x all chains of the last timed step, over that share of the step's time",

@@ -63,7 +63,7 @@ OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np
 
 # every symbol include/dhmc.h declares
 SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", "dhmc_version",
-           "dhmc_init", "dhmc_get_position", "dhmc_set_metric_diag", "dhmc_get_metric_diag",
+           "dhmc_init", "dhmc_set_position", "dhmc_get_position", "dhmc_set_metric_diag", "dhmc_get_metric_diag",
            "dhmc_set_metric_dense", "dhmc_get_metric_dense", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_update_metric_dense", "dhmc_state_bytes",
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",

@@ -542,13 +542,30 @@ class MCMCSteps:
 
 
 def mcmc_steps(sampling_logdensity, warmup_state=None):
-    """mcmc.jl:335-340 (constructor 2: from `mcmc_keep_warmup` results)."""
+    """mcmc.jl:335-340 (constructor 2: from `mcmc_keep_warmup` results): steps with the κ and ϵ of `warmup_state`, from its
+    Q — pushed into the context when they are not what it already holds."""
+    ctx = sampling_logdensity.ctx
+    if warmup_state is not None:
+        _argcheck(warmup_state.eps is not None, "warmup_state.ϵ ≢ nothing")         # mcmc.jl:336
+        k = warmup_state.kappa
+        if k.dense:
+            if not np.array_equal(ctx.metric_dense()[0], k.Minv):
+                ctx.set_metric_dense(k.Minv)
+        elif not np.array_equal(ctx.metric_diag(), np.broadcast_to(k.Minv, (ctx.C, ctx.D))):
+            ctx.set_metric_diag(k.Minv)
+        if not np.array_equal(ctx.stepsize(), np.broadcast_to(warmup_state.eps, (ctx.C,))):
+            ctx.set_stepsize(warmup_state.eps)
+        if not np.array_equal(ctx.position()[0], warmup_state.Q.q):
+            ctx.set_position(warmup_state.Q.q)
     return MCMCSteps(sampling_logdensity)
 
 
 def mcmc_next_step(steps, Q=None):
-    """mcmc.jl:348-351: one transition of every chain; returns (Q′, tree statistics of that transition)."""
+    """mcmc.jl:348-351: one transition of every chain from Q (default: where the chains are); returns (Q′, tree statistics
+    of that transition)."""
     ctx = steps.slogd.ctx
+    if Q is not None and not np.array_equal(ctx.position()[0], np.asarray(Q.q)):
+        ctx.set_position(Q.q)                                   # a Q of the caller's own: evaluate it, keep κ, ϵ and the streams
     draws, ts, lds, _ = _collect(ctx.run(1))
     q, lq, g = ctx.position()
     return EvaluatedLogDensity(q, lq, g), ts

@@ -110,6 +110,12 @@ class DeviceContext:
             q0 = np.ascontiguousarray(np.broadcast_to(q0, (self.C, self.D)), np.float64)
         return self._chk(abi.lib().dhmc_init(self.h, _ptr(q0), int(q0 is not None and _is_device(q0))), "dhmc_init", allow_failure)
 
+    def set_position(self, q, allow_failure=False):
+        """Q := evaluate_ℓ(ℓ, q) at the caller's positions; κ, ϵ, adaptation state and random streams are kept."""
+        if isinstance(q, np.ndarray) or not _is_device(q):
+            q = np.ascontiguousarray(np.broadcast_to(np.asarray(q, np.float64), (self.C, self.D)), np.float64)
+        return self._chk(abi.lib().dhmc_set_position(self.h, _ptr(q), int(_is_device(q))), "dhmc_set_position", allow_failure)
+
     def position(self):
         q = np.zeros((self.C, self.D)); lq = np.zeros(self.C); g = np.zeros((self.C, self.D))
         self._chk(abi.lib().dhmc_get_position(self.h, _ptr(q), _ptr(lq), _ptr(g), 0), "dhmc_get_position")
@@ -136,6 +142,8 @@ class DeviceContext:
 
     def set_stepsize(self, eps):
         eps = np.ascontiguousarray(np.atleast_1d(eps), np.float64)
+        if eps.size not in (1, self.C):
+            raise ValueError(f"ArgumentError: ϵ must be a scalar or one value per chain ({self.C}), got {eps.size}")
         self._chk(abi.lib().dhmc_set_stepsize(self.h, _ptr(eps), int(eps.size == self.C), 0), "dhmc_set_stepsize")
 
     def stepsize(self):

@@ -58,6 +58,7 @@ struct dhmc_ctx {
     uint32_t* d_sflags = nullptr;   // [C][4]: ℓ(q′) (a double) and the position flag between two search kernels (dense)
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
+    bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state
     std::string err;
     std::vector<void*> allocs;
 };
@@ -71,6 +72,14 @@ namespace {
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
             return DHMC_ERR_HIP;                                                            \
         }                                                                                   \
+    } while (0)
+
+#define DHMC_CHECK_USABLE(ctx)                                                                                     \
+    do {                                                                                                          \
+        if ((ctx)->poisoned) {                                                                                    \
+            (ctx)->err = "the context's chain state is inconsistent after a failed log-density callback: call dhmc_init or dhmc_import_state"; \
+            return DHMC_ERR_CALLBACK;                                                                             \
+        }                                                                                                         \
     } while (0)
 
 template <class Tp>
@@ -161,10 +170,20 @@ void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
     }
 }
 
+// a device temporary that is released on every return path
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 // Stage a host array onto the device (returns a temp the caller frees), or pass through.
 struct Staged {
     const void* dev = nullptr;
     void* temp = nullptr;
+    ~Staged() { if (temp) { (void)hipDeviceSynchronize(); (void)hipFree(temp); } }   // error paths; stage_free is the normal one
 };
 int stage_in(dhmc_ctx* c, const void* p, size_t bytes, int on_device, Staged* s) {
     if (on_device) { s->dev = p; return DHMC_OK; }
@@ -196,17 +215,16 @@ int copy_out_padded(dhmc_ctx* c, const double* padded, double* dst, int on_devic
     int D = c->cfg.dim, C = c->cfg.chains;
     size_t n = (size_t)C * D;
     double* d = dst;
-    void* temp = nullptr;
+    DevBuf temp;
     if (!on_device) {
-        HIP_TRY(c, hipMalloc(&temp, n * sizeof(double)));
-        d = (double*)temp;
+        HIP_TRY(c, hipMalloc(&temp.p, n * sizeof(double)));
+        d = (double*)temp.p;
     }
     hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, D, c->Dpad, C, padded, d);
     HIP_TRY(c, hipGetLastError());
     if (!on_device) {
         HIP_TRY(c, hipMemcpyAsync(dst, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(temp);
     }
     return DHMC_OK;
 }
@@ -454,6 +472,14 @@ int dhmc_set_stream(dhmc_ctx* c, void* s) {
 int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    c->poisoned = false;
+    if (c->cfg.metric == DHMC_METRIC_DENSE) {   // κ = GaussianKineticEnergy(N) (mcmc.jl:130): the dense identity again
+        const int D = c->cfg.dim;
+        std::vector<double> I((size_t)D * D, 0.0);
+        for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
+        int rc0 = upload_dense_metric(c, I, I);
+        if (rc0) return rc0;
+    }
     Staged s;
     if (q0) {
         int rc = stage_in(c, q0, sizeof(double) * (size_t)c->cfg.chains * c->cfg.dim, q0_on_device, &s);
@@ -474,8 +500,33 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     return status_code(c);
 }
 
+int dhmc_set_position(dhmc_ctx* c, const double* q, int on_device) {
+    if (!c || !q) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // dhmc_init does the evaluation (and resets κ, ϵ, counters): keep those aside and put them back
+    const size_t C = c->cfg.chains, Dp = c->Dpad;
+    const bool dense = c->cfg.metric == DHMC_METRIC_DENSE;
+    struct Keep { void* live; size_t bytes; DevBuf copy; };
+    Keep keep[7] = {{c->st.minv, C * Dp * sizeof(double), {}}, {c->st.W, C * Dp * sizeof(double), {}}, {c->st.eps, C * sizeof(double), {}},
+                    {c->st.da, C * sizeof(DAState), {}}, {c->st.transition, C * sizeof(uint32_t), {}},
+                    {dense ? (void*)c->d_Minv : nullptr, Dp * Dp * sizeof(double), {}}, {dense ? (void*)c->d_WT : nullptr, Dp * Dp * sizeof(double), {}}};
+    for (auto& k : keep) {
+        if (!k.live) continue;
+        HIP_TRY(c, hipMalloc(&k.copy.p, k.bytes));
+        HIP_TRY(c, hipMemcpyAsync(k.copy.p, k.live, k.bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const bool was_poisoned = c->poisoned;
+    const int rc = dhmc_init(c, q, on_device);
+    for (auto& k : keep)
+        if (k.live) HIP_TRY(c, hipMemcpyAsync(k.live, k.copy.p, k.bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)was_poisoned;
+    return rc;
+}
+
 int dhmc_get_position(dhmc_ctx* c, double* q, double* lq, double* grad, int on_device) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc;
     if (q && (rc = copy_out_padded(c, c->st.q, q, on_device))) return rc;
@@ -492,6 +543,15 @@ int dhmc_set_metric_diag(dhmc_ctx* c, const double* minv, int per_chain, int on_
     if (!on_device) {
         for (size_t i = 0; i < n; ++i)
             if (!(minv[i] > 0) || !std::isfinite(minv[i])) return DHMC_ERR_INVALID_ARGUMENT;
+    } else {                                   // the same @argcheck (hamiltonian.jl:63) for a device array
+        DevBuf flag;
+        int bad = 0;
+        HIP_TRY(c, hipMalloc(&flag.p, sizeof(int)));
+        HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(check_positive_finite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, minv, n, (int*)flag.p);
+        HIP_TRY(c, hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (bad) return DHMC_ERR_INVALID_ARGUMENT;
     }
     Staged s;
     int rc = stage_in(c, minv, n * sizeof(double), on_device, &s);
@@ -578,6 +638,7 @@ int dhmc_get_status(dhmc_ctx* c, uint32_t* status) {
 
 int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     dhmc_stepsize_search d{0.1, std::log(0.8), 400, 0};
     if (p) d = *p;
@@ -650,6 +711,7 @@ int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
 
 int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {
     if (!c || N < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (da) {
         if (!(0 < da->delta && da->delta < 1)) return DHMC_ERR_INVALID_ARGUMENT;  // stepsize.jl:108
@@ -723,15 +785,15 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
                 launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, C, R.list, R.list_count, c->stream);       // p₀ = z·Wᵀ
                 launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, C, R.list, R.list_count, c->stream);    // p♯₀
-                dispatch(c, Op::RoundK0, &ra);
+                if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(R.list_count, 0, sizeof(int), c->stream);
                 launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, C, nullptr, nullptr, c->stream);         // M⁻¹pₘ
                 DHMC_EXT_NPL(rounds_k2a_dense_external_kernel, dim3(C), ra.P, ra.R)                    // q′
                 rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
-                if (rc) { cleanup(); return rc; }
+                if (rc) { c->poisoned = true; cleanup(); return rc; }   // st.q holds trial positions: see DHMC_CHECK_USABLE
                 DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′
                 launch_gemm_rows(R.cp, c->d_Minv, R.cps, ld, C, nullptr, nullptr, c->stream);          // p♯
-                dispatch(c, Op::RoundK3, &ra);
+                if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&done, R.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -748,13 +810,13 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         while (e == hipSuccess && done < C) {
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
                 launch_logistic_op(0, c->NPL, ra, c->lr, c->stream);                                   // p = W∘z, p♯
-                dispatch(c, Op::RoundK0, &ra);
+                if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
                 launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
                 rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
-                if (rc) { cleanup(); return rc; }
+                if (rc) { c->poisoned = true; cleanup(); return rc; }   // st.q holds trial positions: see DHMC_CHECK_USABLE
                 DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′, p♯
-                dispatch(c, Op::RoundK3, &ra);
+                if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -773,14 +835,14 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         while (e == hipSuccess && done < C) {
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
                 launch_logistic_op(0, c->NPL, ra, c->lr, c->stream);                                   // p = W∘z, p♯
-                dispatch(c, Op::RoundK0, &ra);
+                if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
                 launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
                 launch_gemm(c->st.q, ld, c->tp.b, npad, c->lr.H, npad, C, ld, npad, c->stream);        // η = Q′·Xᵀ
                 launch_logistic_op(2, c->NPL, ra, c->lr, c->stream);                                   // r, S₁
                 launch_gemm(c->lr.H, npad, c->tp.a, ld, c->rb.tbuf, ld, C, npad, ld, c->stream);       // Xᵀr = R·X
                 launch_logistic_op(3, c->NPL, ra, c->lr, c->stream);                                   // ∇ℓ, ℓ, p′, p♯
-                dispatch(c, Op::RoundK3, &ra);
+                if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -805,7 +867,8 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         e = hipMemsetAsync(c->rb.list_count, 0, 4 * sizeof(int), c->stream);
         if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
         if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-        for (int h = 0; h < nh && e == hipSuccess; ++h) dispatch(c, Op::RoundStart, &H[h].ra, H[h].s, true);
+        for (int h = 0; h < nh && e == hipSuccess; ++h)
+            if ((rc = dispatch(c, Op::RoundStart, &H[h].ra, H[h].s, true))) { cleanup(); return rc; }
         unsigned long long rounds = 0;
         int done[4] = {0, 0, 0, 0};
         while (e == hipSuccess && done[1] + done[3] < C) {
@@ -816,12 +879,12 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                     hipStream_t s = H[h].s;
                     launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, H[h].count, R.list, R.list_count, s);               // p₀ = z·Wᵀ
                     launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, H[h].count, R.list, R.list_count, s);            // p♯₀
-                    dispatch(c, Op::RoundK0, &H[h].ra, s, true);
+                    if ((rc = dispatch(c, Op::RoundK0, &H[h].ra, s, true))) { cleanup(); return rc; }
                     e = hipMemsetAsync(R.list_count, 0, sizeof(int), s);
                     launch_gemm_rows(R.cp + off, c->d_Minv, R.tbuf + off, ld, H[h].count, nullptr, nullptr, s);     // M⁻¹pₘ
-                    dispatch(c, Op::RoundK2, &H[h].ra, s, true);
+                    if ((rc = dispatch(c, Op::RoundK2, &H[h].ra, s, true))) { cleanup(); return rc; }
                     launch_gemm_rows(R.cp + off, c->d_Minv, R.cps + off, ld, H[h].count, nullptr, nullptr, s);      // p♯
-                    dispatch(c, Op::RoundK3, &H[h].ra, s, true);
+                    if ((rc = dispatch(c, Op::RoundK3, &H[h].ra, s, true))) { cleanup(); return rc; }
                 }
             }
             if (e == hipSuccess) e = hipGetLastError();
@@ -876,9 +939,11 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     Staged s;
     int rc = stage_in(c, draws, sizeof(double) * (size_t)J * D, on_device, &s);
     if (rc) return rc;
-    double *mean = nullptr, *S = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&mean, sizeof(double) * ld));
-    HIP_TRY(c, hipMalloc((void**)&S, sizeof(double) * (size_t)ld * ld));
+    DevBuf bmean, bS;
+    HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
+    HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
+    double* const mean = (double*)bmean.p;
+    double* const S = (double*)bS.p;
     hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean);
     hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean, S, ld);
     hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
@@ -886,7 +951,6 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), S, hp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(mean); (void)hipFree(S);
     stage_free(c, &s);
     if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
     for (int i = 0; i < D; ++i)
@@ -905,10 +969,6 @@ static const uint64_t BLOB_MAGIC = 0x31434d4844ull;  // "DHMC1"
 
 // ---- Diagnostics probes (probe_kernels.hpp) ---------------------------------------------------
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
 int probe_finish(dhmc_ctx* c, const DevBuf& dst, uint32_t* status) {
     const int C = c->cfg.chains;
     std::vector<uint32_t> st(C);
@@ -1153,6 +1213,7 @@ static int blob_io(dhmc_ctx* c, char* blob, bool exporting) {
 int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
     uint64_t need;
     if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
+    DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     BlobHeader h{BLOB_MAGIC, c->cfg.dim, c->cfg.chains, c->Dpad, 0};
@@ -1163,6 +1224,7 @@ int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
 int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
     uint64_t need;
     if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
+    c->poisoned = false;
     BlobHeader h;
     std::memcpy(&h, host_blob, sizeof(h));
     if (h.magic != BLOB_MAGIC || h.dim != c->cfg.dim || h.chains != c->cfg.chains || h.Dpad != c->Dpad) return DHMC_ERR_INVALID_ARGUMENT;

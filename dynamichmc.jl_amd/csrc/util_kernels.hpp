@@ -20,6 +20,12 @@ __global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __r
     }
 }
 
+// flag := 1 if any element is not a finite positive number (the @argcheck of GaussianKineticEnergy, hamiltonian.jl:63)
+__global__ void check_positive_finite_kernel(const double* __restrict__ v, size_t n, int* __restrict__ flag) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n && (!(v[idx] > 0) || !dm_isfinite(v[idx]))) *flag = 1;
+}
+
 // padded [C][Dpad] <-> unpadded [C][D]
 __global__ void unpad_kernel(int D, int Dpad, int C, const double* __restrict__ src, double* __restrict__ dst) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

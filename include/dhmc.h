@@ -166,6 +166,11 @@ const char* dhmc_version(void);
  * (mcmc.jl:108); evaluates l strictly (hamiltonian.jl:202-217, strict=true), sets κ to the unit
  * metric and ε to "unspecified" (NaN).  Clears status words and transition counters. */
 int dhmc_init(dhmc_ctx* ctx, const double* q0, int q0_on_device);
+/* Q := evaluate_ℓ(ℓ, q) for every chain at positions of the caller's choosing (strict, as dhmc_init: hamiltonian.jl:202-217)
+ * WITHOUT touching κ, ϵ, the adaptation state or the random-stream counters — what `mcmc_next_step(steps, Q)` (mcmc.jl:348-351)
+ * needs when it is handed a Q that is not the context's own.  q: [C][D]. */
+int dhmc_set_position(dhmc_ctx* ctx, const double* q, int on_device);
+
 /* q [C][D], lq [C], grad [C][D]; any may be NULL. */
 int dhmc_get_position(dhmc_ctx* ctx, double* q, double* lq, double* grad, int on_device);
 /* GaussianKineticEnergy(Diagonal(minv)) (hamiltonian.jl:80): minv [C][D] if per_chain else [D]. */

@@ -142,3 +142,28 @@ def test_dense_metric_for_external_models(pkg):
     assert np.abs(np.cov(x.T) - Sigma).max() < 0.25 * np.abs(Sigma).max()
     assert np.median(dense["eps"]) > 2 * np.median(diag["eps"])
     assert dense["tree_statistics"].steps.mean() < diag["tree_statistics"].steps.mean()
+
+
+def test_context_is_unusable_after_a_callback_failure_until_reinitialised(pkg):
+    """A callback that fails in the middle of dhmc_run leaves trial positions in the chain state: the context refuses to go
+    on (DHMC_ERR_CALLBACK) until dhmc_init gives it a consistent state again."""
+    calls = {"n": 0}
+
+    def lg(q):
+        calls["n"] += 1
+        if calls["n"] == 6:
+            raise KeyError("model blew up in the middle of a run")
+        return -0.5 * (q * q).sum(1), -q
+
+    ctx = pkg.DeviceContext(3, 2, target=pkg.abi.TARGET_EXTERNAL)
+    ctx.set_logdensity_callback(lg)
+    ctx.init(); ctx.set_stepsize(0.5)
+    with pytest.raises(KeyError):
+        ctx.run(20)
+    with pytest.raises(RuntimeError, match="callback"):
+        ctx.run(1)
+    with pytest.raises(RuntimeError, match="callback"):
+        ctx.position()
+    calls["n"] = 100
+    ctx.init(); ctx.set_stepsize(0.5)
+    assert ctx.run(3)["draws"].shape == (2, 3, 3)

@@ -250,3 +250,82 @@ def test_empty_and_unrecorded_runs(pkg):
         pkg.DeviceContext(1025, 1)                                 # D > 1024 is outside this build (DHMC_ERR_UNSUPPORTED)
     with pytest.raises(ValueError):
         dev.run(-1)
+
+
+def _shard_worker(rank, world, port, total, D, N, outdir):
+    import os, sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks share the box's one GPU: RCCL needs one device per rank
+    off, cnt = pkg.sharding.shard_chains(total, world, rank)
+    dev = pkg.DeviceContext(D, cnt, seed=77, chain_offset=off)
+    dev.init(); dev.find_initial_stepsize()
+    r = dev.run(N, da={})
+    draws = pkg.sharding.gather_chain_major(torch.from_numpy(r["draws"]), dist, total, world)
+    steps = pkg.sharding.gather_chain_major(torch.from_numpy(r["steps"]), dist, total, world)
+    rate = pkg.sharding.job_throughput(int(r["steps"].sum()), 2.0 + rank, dist)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "gathered.npz"), draws=draws.numpy(), steps=steps.numpy(), rate=rate)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_hip_shards_equal_single_context(pkg, tmp_path):
+    """The multi-GPU layout with the HIP path as the per-rank engine: two PROCESSES (both on this box's GPU), contiguous
+    chain blocks with the block offset as RNG chain_offset, results gathered through sharding.gather_chain_major — equal,
+    chain for chain, to one context holding all chains (the HIP counterpart of tests/test_distributed_gloo.py)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    total, D, N, world = 37, 1000, 6, 2                         # ragged blocks of 19 and 18 chains, the headline width
+    mp.spawn(_shard_worker, args=(world, port, total, D, N, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(tmp_path / "gathered.npz")
+    single = pkg.DeviceContext(D, total, seed=77)
+    single.init(); single.find_initial_stepsize()
+    r = single.run(N, da={})
+    assert np.array_equal(g["draws"], r["draws"]) and np.array_equal(g["steps"], r["steps"])
+    assert np.isclose(float(g["rate"]), r["steps"].sum() / 3.0)
+
+
+def test_set_position_keeps_metric_stepsize_and_streams(pkg):
+    """dhmc_set_position: Q := evaluate_ℓ(ℓ, q) at positions of the caller's (what mcmc_next_step(steps, Q) needs for a
+    foreign Q, mcmc.jl:348-351) without touching κ, ϵ or the random-stream counters."""
+    D, C = 70, 4
+    a = pkg.DeviceContext(D, C, seed=5); b = pkg.DeviceContext(D, C, seed=5)
+    for d in (a, b):
+        d.init(); d.find_initial_stepsize()
+        r = d.run(20, da={}); d.update_metric_diag(r["draws"]); d.run(2)
+    b.set_position(a.position()[0])                       # its own position handed back in: nothing may change
+    ra, rb = a.run(3), b.run(3)
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
+    qx = np.random.default_rng(1).normal(size=(C, D))
+    m0, e0 = a.metric_diag(), a.stepsize()
+    a.set_position(qx)
+    fresh = pkg.DeviceContext(D, C, seed=99); fresh.init(qx)
+    for x, y in zip(a.position(), fresh.position()):
+        assert np.array_equal(x, y)                       # (q, ℓq, ∇ℓq) of the new point
+    assert np.array_equal(a.metric_diag(), m0) and np.array_equal(a.stepsize(), e0)
+    with pytest.raises(ValueError):
+        a.set_stepsize(np.ones(3))                        # neither a scalar nor one value per chain
+    import torch
+    with pytest.raises(ValueError):                       # hamiltonian.jl:63 for a device array too
+        a.set_metric_diag(torch.full((C, D), -1.0, dtype=torch.float64, device="cuda"))
+    assert np.array_equal(a.metric_diag(), m0)
+
+
+def test_dense_context_reinitialises_to_the_unit_metric(pkg):
+    """initialize_warmup_state always starts from GaussianKineticEnergy(N) (mcmc.jl:130), also for a dense context that was
+    adapted before."""
+    D = 6
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(D, D)); S = A @ A.T + D * np.eye(D)
+    d = pkg.DeviceContext(D, 3, metric=ol.METRIC_DENSE, seed=1)
+    d.set_metric_dense(S); d.init()
+    Minv, W = d.metric_dense()
+    assert np.array_equal(Minv, np.eye(D)) and np.array_equal(W, np.eye(D))
