@@ -246,23 +246,28 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     ndev = max(1, torch.cuda.device_count())
-    shared_device = world > ndev and "ROCR_VISIBLE_DEVICES" not in os.environ and "HIP_VISIBLE_DEVICES" not in os.environ
     local_rank %= ndev                                   # a launcher that hides all but one GPU per rank leaves one device
     torch.cuda.set_device(local_rank)
     dist = None
+    pg = None
     coll_dev = "cuda"
     backend = None
     if world > 1:
         import torch.distributed as dist
-        if shared_device:
-            # several ranks on ONE GPU (a readiness run of the multi-process path on a 1-GPU box): RCCL refuses two ranks
-            # on the same device, so the three small collectives go over gloo with host tensors; the per-rank HIP path,
-            # the sharding and the reductions are the ones of the 8-GPU run
+        # rendezvous over gloo first: do two ranks sit on the same physical GPU (a readiness run of the multi-process path
+        # on a 1-GPU box)?  RCCL refuses that ("Duplicate GPU detected"), so then the three small collectives stay on gloo
+        # with host tensors; the per-rank HIP path, the sharding and the reductions are the ones of the 8-GPU run.
+        dist.init_process_group("gloo")
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) or f"{props.name}#{local_rank}"
+        ident += "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "") + "|" + os.environ.get("HIP_VISIBLE_DEVICES", "")
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) < world:
             backend, coll_dev = "gloo", "cpu"
-            dist.init_process_group("gloo")
         else:
             backend = "nccl"
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            pg = dist.new_group(backend="nccl")
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -286,7 +291,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=pg)
             torch.cuda.synchronize()
 
     for _ in range(Wn):
@@ -314,14 +319,17 @@ def main():
     t_max, total_leapfrogs, ess_rate = dt, leapfrogs, ess / ess_dt
     if dist is not None:
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=pg)
         ll = torch.tensor([leapfrogs, ess / ess_dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(ll, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ll, op=dist.ReduceOp.SUM, group=pg)
         t_max, total_leapfrogs, ess_rate = float(tt[0]), float(ll[0]), float(ll[1])
         # the one collective of the path: gather the last draw of every chain over RCCL/xGMI
         last = out["draws"][:, -1, :].contiguous().to(coll_dev)
         gathered = torch.empty((world * C, D), dtype=torch.float64, device=coll_dev)
-        dist.all_gather_into_tensor(gathered, last)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, last, group=pg)
+        else:
+            dist.all_gather(list(gathered.view(world, C, D).unbind(0)), last, group=pg)
         torch.cuda.synchronize()
         assert bool(torch.equal(gathered[rank * C:(rank + 1) * C], last))
 

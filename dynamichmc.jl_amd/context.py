@@ -122,6 +122,11 @@ class DeviceContext:
         return q, lq, g
 
     def set_metric_diag(self, minv):
+        """GaussianKineticEnergy(Diagonal(minv)) (hamiltonian.jl:80): [D] shared, or [C][D] per chain (numpy, or a CUDA tensor)."""
+        if _is_device(minv):
+            minv = minv.contiguous()
+            self._chk(abi.lib().dhmc_set_metric_diag(self.h, _ptr(minv), int(minv.dim() == 2), 1), "dhmc_set_metric_diag")
+            return
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(abi.lib().dhmc_set_metric_diag(self.h, _ptr(minv), int(minv.ndim == 2), 0), "dhmc_set_metric_diag")
 
