@@ -137,6 +137,10 @@ class DeviceContext:
 
     def set_metric_dense(self, minv):
         """GaussianKineticEnergy(M⁻¹) with a full matrix shared by all chains (hamiltonian.jl:73)."""
+        if _is_device(minv):
+            minv = minv.contiguous()
+            self._chk(abi.lib().dhmc_set_metric_dense(self.h, _ptr(minv), 1), "dhmc_set_metric_dense")
+            return
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(abi.lib().dhmc_set_metric_dense(self.h, _ptr(minv), 0), "dhmc_set_metric_dense")
 

@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../../include/dhmc.h"
-#include "dense_metric.hpp"
+#include "dense_factor.hpp"
 #include "external_rounds.hpp"
 #include "ess_kernels.hpp"
 #include "logistic_rounds.hpp"
@@ -44,6 +44,8 @@ struct dhmc_ctx {
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
+    double* d_fwork = nullptr;   // 4 × Dpad² doubles: work space of the device factorisation (dense_factor.hpp)
+    int* d_fflags = nullptr;     // [2]: non-finite input, not positive definite
     RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
     RoundBuffers rb2{};        // second half-batch: own list and counters, same vectors
     hipStream_t stream2 = nullptr;
@@ -157,6 +159,27 @@ int upload_dense_metric(dhmc_ctx* c, const std::vector<double>& S, const std::ve
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DHMC_OK;
 }
+// κ := GaussianKineticEnergy(Symmetric(src)) (hamiltonian.jl:73) entirely on the device (dense_factor.hpp): src is a
+// device matrix with row stride lsrc whose upper triangle is read.  The context's metric is replaced only if src is
+// finite and positive definite; otherwise DHMC_ERR_INVALID_ARGUMENT (the reference's cholesky throws).
+int device_dense_metric(dhmc_ctx* c, const double* src, int lsrc) {
+    const int D = c->cfg.dim, ld = c->Dpad;
+    const size_t n = (size_t)ld * ld;
+    double* Stmp = c->d_fwork + 3 * n;
+    double* WTtmp = c->d_fwork + n;              // the X buffer: free again once M = XᵀX exists
+    int flags[2] = {0, 0};
+    HIP_TRY(c, hipMemsetAsync(c->d_fflags, 0, 2 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(df_symmetrize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, lsrc, D, Stmp, ld, c->d_fflags);
+    df_dense_metric(Stmp, Stmp, WTtmp, D, ld, c->d_fwork, c->d_fflags, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(flags, c->d_fflags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (flags[0] || flags[1]) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipMemcpyAsync(c->d_Minv, Stmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_WT, WTtmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DHMC_OK;
+}
 void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
     int D = c->cfg.dim, Dp = c->Dpad, C = c->cfg.chains;
     switch (c->NPL) {
@@ -267,7 +290,6 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         break;
     }
     case DHMC_TARGET_EXTERNAL:
-        if (cfg->metric == DHMC_METRIC_DENSE && D > 1024) return DHMC_ERR_UNSUPPORTED;   // the host factorisation is O(D³)
         break;
     default: return DHMC_ERR_UNSUPPORTED;
     }
@@ -333,6 +355,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (cfg->metric == DHMC_METRIC_DENSE) {   // GaussianKineticEnergy(N) as a dense identity
         if ((rc = dev_alloc(c, &c->d_Minv, Dp * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_WT, Dp * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_fwork, 4 * Dp * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_fflags, 2))) return fail(rc);
         c->dm = DenseMetric{c->d_Minv, c->d_WT};
         if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
         std::vector<double> I((size_t)D * D, 0.0);
@@ -574,18 +598,12 @@ int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
     if (!c || !minv || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int D = c->cfg.dim;
-    std::vector<double> h((size_t)D * D);
-    if (on_device) {
-        HIP_TRY(c, hipMemcpyAsync(h.data(), minv, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    } else {
-        std::memcpy(h.data(), minv, h.size() * sizeof(double));
-    }
-    for (double v : h)
-        if (!std::isfinite(v)) return DHMC_ERR_INVALID_ARGUMENT;
-    std::vector<double> S, W;
-    if (!host_dense_metric(h.data(), D, S, W)) return DHMC_ERR_INVALID_ARGUMENT;   // not positive definite
-    return upload_dense_metric(c, S, W);
+    Staged s;
+    int rc = stage_in(c, minv, sizeof(double) * (size_t)D * D, on_device, &s);
+    if (rc) return rc;
+    rc = device_dense_metric(c, (const double*)s.dev, D);      // symmetrise, check, factorise: all on the device
+    stage_free(c, &s);
+    return rc;
 }
 
 int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) {
@@ -947,17 +965,11 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean);
     hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean, S, ld);
     hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
-    std::vector<double> hp((size_t)ld * ld), h((size_t)D * D);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), S, hp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { stage_free(c, &s); c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
+    rc = device_dense_metric(c, S, ld);                        // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
     stage_free(c, &s);
-    if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
-    for (int i = 0; i < D; ++i)
-        for (int k = 0; k < D; ++k) h[(size_t)i * D + k] = hp[(size_t)i * ld + k];
-    std::vector<double> Sy, W;
-    if (!host_dense_metric(h.data(), D, Sy, W)) return DHMC_ERR_INVALID_ARGUMENT;   // estimate not positive definite
-    return upload_dense_metric(c, Sy, W);
+    return rc;
 }
 
 // ---- resume blob: header + raw images of the per-chain arrays -------------------------------

@@ -140,3 +140,51 @@ def test_dense_state_export_import(pkg):
     ra, rb = a.run(6), b.run(6)
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+
+
+@pytest.mark.parametrize("K", [33, 100, 257])
+def test_device_factorisation_matches_the_oracle_at_block_boundaries(pkg, K):
+    """GaussianKineticEnergy(M⁻¹) (hamiltonian.jl:73) built on the device (blocked right-looking Cholesky / triangular
+    inverse in blocks of 32, XᵀX on fp64 MFMA, csrc/dense_factor.hpp): M⁻¹ and W bit-equal to the oracle's unblocked
+    loops, for sizes around the block width; host and device inputs; a matrix that is not positive definite is refused
+    and leaves the metric in place."""
+    import torch
+    S = rand_sigma(K)
+    dev, ora = pair(pkg, K, 2)
+    dev.set_metric_dense(S); ora.set_metric_dense(S)
+    md, Wd = dev.metric_dense(); mo, Wo = ora.metric_dense()
+    assert np.array_equal(md, mo) and np.array_equal(Wd, Wo)
+    assert np.allclose(Wd @ Wd.T, np.linalg.inv(S), rtol=1e-8, atol=1e-10)
+    dev.set_metric_dense(torch.from_numpy(2 * S).cuda()); ora.set_metric_dense(2 * S)     # a device matrix
+    md, Wd = dev.metric_dense(); mo, Wo = ora.metric_dense()
+    assert np.array_equal(md, mo) and np.array_equal(Wd, Wo)
+    bad = S.copy(); bad[K // 2, K // 2] = -1.0
+    with pytest.raises(ValueError):
+        dev.set_metric_dense(bad)
+    assert np.array_equal(dev.metric_dense()[0], mo)
+
+
+def test_dense_metric_adaptation_at_1000_dimensions(pkg):
+    """SURVEY.md §8 f-2 at BASELINE config 3's width: a TuningNUTS{Symmetric} stage on a 1000-dim correlated normal —
+    pooled covariance (MFMA), regularisation, Cholesky, triangular inverse, XᵀX and the second Cholesky all on the
+    device — gives M⁻¹ and W bit-equal to the oracle's, and the chains continue identically afterwards."""
+    D, C, n = 1000, 8, 50
+    rho = 0.5
+    sig = np.logspace(-0.2, 0.2, D)
+    Pc = np.zeros(D) + (1 + rho ** 2) / (1 - rho ** 2); Pc[0] = Pc[-1] = 1 / (1 - rho ** 2)
+    diag = Pc / sig ** 2
+    off = np.zeros(D); off[:D - 1] = -rho / (1 - rho ** 2) / (sig[:-1] * sig[1:])
+    params = np.concatenate([diag, off])
+    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=16)
+    ora = ol.Oracle(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=16, threads=8)
+    q0 = np.random.default_rng(3).normal(size=(C, D)) * sig
+    for e in (dev, ora):
+        e.init(q0); e.find_initial_stepsize()
+    a, b = dev.run(n, da={}), ora.run(n, da={})
+    same(a, b, "adaptive stage")
+    lam = 5.0 / n
+    dev.update_metric_dense(a["draws"], lam); ora.update_metric_dense(b["draws"], lam)
+    md, Wd = dev.metric_dense(); mo, Wo = ora.metric_dense()
+    assert np.array_equal(md, mo), "M⁻¹"
+    assert np.array_equal(Wd, Wo), "W"
+    same(dev.run(3, da={}), ora.run(3, da={}), "after the metric update")
