@@ -497,13 +497,6 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     c->poisoned = false;
-    if (c->cfg.metric == DHMC_METRIC_DENSE) {   // κ = GaussianKineticEnergy(N) (mcmc.jl:130): the dense identity again
-        const int D = c->cfg.dim;
-        std::vector<double> I((size_t)D * D, 0.0);
-        for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
-        int rc0 = upload_dense_metric(c, I, I);
-        if (rc0) return rc0;
-    }
     Staged s;
     if (q0) {
         int rc = stage_in(c, q0, sizeof(double) * (size_t)c->cfg.chains * c->cfg.dim, q0_on_device, &s);

@@ -163,8 +163,11 @@ const char* dhmc_version(void);
 
 /* ---- warmup state: WarmupState(Q, κ, ϵ) per chain (mcmc.jl:72-79) -------------------- */
 /* initialize_warmup_state (mcmc.jl:129-132): q0 [C][D], or NULL for random_position
- * (mcmc.jl:108); evaluates l strictly (hamiltonian.jl:202-217, strict=true), sets κ to the unit
- * metric and ε to "unspecified" (NaN).  Clears status words and transition counters. */
+ * (mcmc.jl:108); evaluates l strictly (hamiltonian.jl:202-217, strict=true), sets the per-chain diagonal κ to the
+ * unit metric and ε to "unspecified" (NaN).  Clears status words and transition counters.  A DHMC_METRIC_DENSE
+ * context KEEPS its shared M⁻¹ (the identity at dhmc_create, or what dhmc_set_metric_dense / dhmc_update_metric_dense
+ * last installed): initialize_warmup_state takes κ as a keyword (mcmc.jl:129), and one matrix serves all chains, so
+ * it is set once, before or after the chains are placed. */
 int dhmc_init(dhmc_ctx* ctx, const double* q0, int q0_on_device);
 /* Q := evaluate_ℓ(ℓ, q) for every chain at positions of the caller's choosing (strict, as dhmc_init: hamiltonian.jl:202-217)
  * WITHOUT touching κ, ϵ, the adaptation state or the random-stream counters — what `mcmc_next_step(steps, Q)` (mcmc.jl:348-351)

@@ -319,13 +319,18 @@ def test_set_position_keeps_metric_stepsize_and_streams(pkg):
     assert np.array_equal(a.metric_diag(), m0)
 
 
-def test_dense_context_reinitialises_to_the_unit_metric(pkg):
-    """initialize_warmup_state always starts from GaussianKineticEnergy(N) (mcmc.jl:130), also for a dense context that was
-    adapted before."""
+def test_dense_context_keeps_its_metric_across_init(pkg):
+    """include/dhmc.h: dhmc_init resets the per-chain diagonal metric to the unit one, a dense context keeps its shared
+    M⁻¹ (initialize_warmup_state takes κ as a keyword, mcmc.jl:129) — as the oracle's restatement does."""
     D = 6
     rng = np.random.default_rng(2)
     A = rng.normal(size=(D, D)); S = A @ A.T + D * np.eye(D)
     d = pkg.DeviceContext(D, 3, metric=ol.METRIC_DENSE, seed=1)
-    d.set_metric_dense(S); d.init()
-    Minv, W = d.metric_dense()
-    assert np.array_equal(Minv, np.eye(D)) and np.array_equal(W, np.eye(D))
+    assert np.array_equal(d.metric_dense()[0], np.eye(D))          # GaussianKineticEnergy(N) at creation
+    d.set_metric_dense(S); before = d.metric_dense()
+    d.init()
+    after = d.metric_dense()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    e = pkg.DeviceContext(D, 3, seed=1)
+    e.init(); e.set_metric_diag(np.full(D, 3.0)); e.init()
+    assert np.array_equal(e.metric_diag(), np.ones((3, D)))        # the diagonal one is reset
