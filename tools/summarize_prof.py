@@ -28,9 +28,9 @@ for f in find("*kernel_trace.csv"):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     print("  ", " ".join(f"{x:.3f}" for x in d))
-    print("   (bench.py --steps 3 --warmup 1: 7 adaptive setup launches (75/25/50/100/200/400/50 transitions), then"
-          " 1 warmup + 3 timed launches of 20 transitions — compare these four with roofline.kernel_ms in"
-          " bench_trace.json — then one 100-transition ESS launch)")
+    print("   (bench.py --steps 3 --warmup 1 --transitions T: 7 adaptive setup launches (75/25/50/100/200/400/50 transitions),"
+          " then 1 warmup + 3 timed launches of T transitions — compare the last three with roofline.kernel_ms in"
+          " bench_trace.json)")
 
 for f in find("*counter_collection.csv"):
     print("== counters", os.path.relpath(f, out))
