@@ -54,6 +54,7 @@ struct dhmc_ctx {
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     LogisticRound lr{};
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
+    int builtin_big = 0;       // a built-in normal family with more than 1024 coordinates: the same engine, density from builtin_normal_eval_kernel
     dhmc_logdensity_fn ext_fn = nullptr;
     void* ext_user = nullptr;
     ExtSearchState* d_ss = nullptr;
@@ -131,6 +132,7 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
 int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false) {
     hipStream_t cs = use_override ? stream_override : c->stream;
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
+    if (c->builtin_big) return dispatch_family<ExternalT>(c->NPL, op, P, cs, M);
     switch (c->cfg.target) {
     case DHMC_TARGET_STD_NORMAL: return dispatch_family<StdNormalT>(c->NPL, op, P, cs, M);
     case DHMC_TARGET_DIAG_NORMAL: return dispatch_family<DiagNormalT>(c->NPL, op, P, cs, M);
@@ -299,7 +301,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (!c) return DHMC_ERR_HIP;
     c->cfg = *cfg;
     c->cfg.target_params = nullptr;
-    c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL && cfg->metric == DHMC_METRIC_DIAG);
+    // beyond 1024 coordinates the streaming round-engine kernels serve external models and the built-in normal families
+    c->builtin_big = D > 1024 && (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL ||
+                                  cfg->target == DHMC_TARGET_TRIDIAG_NORMAL);
+    c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big);
     if (cfg->target == DHMC_TARGET_EXTERNAL)
         if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels
             const int f = std::atoi(e);
@@ -314,7 +319,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
         c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0;
     c->dense_rounds = many_chains;
-    c->external = cfg->target == DHMC_TARGET_EXTERNAL;
+    c->external = cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
@@ -463,6 +468,15 @@ int dhmc_destroy(dhmc_ctx* c) {
 namespace {
 // ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
 int external_eval(dhmc_ctx* c, const double* q) {
+    if (c->builtin_big) {
+        const int kind = c->cfg.target == DHMC_TARGET_STD_NORMAL ? 0 : c->cfg.target == DHMC_TARGET_DIAG_NORMAL ? 1 : 2;
+        const dim3 g(c->cfg.chains), b(WAVE);
+        if (c->NPL == 32)
+            hipLaunchKernelGGL((builtin_normal_eval_kernel<32>), g, b, 0, c->stream, kind, c->cfg.dim, c->Dpad, q, c->tp.a, c->tp.b, c->lr.S1, c->rb.tbuf);
+        else
+            hipLaunchKernelGGL((builtin_normal_eval_kernel<64>), g, b, 0, c->stream, kind, c->cfg.dim, c->Dpad, q, c->tp.a, c->tp.b, c->lr.S1, c->rb.tbuf);
+        return DHMC_OK;
+    }
     if (!c->ext_fn) { c->err = "DHMC_TARGET_EXTERNAL: no callback set (dhmc_set_logdensity_callback)"; return DHMC_ERR_CALLBACK; }
     const int rc = c->ext_fn(c->ext_user, q, c->cfg.chains, c->Dpad, c->cfg.dim, c->lr.S1, c->rb.tbuf, (void*)c->stream);
     if (rc != 0) { c->err = "DHMC_TARGET_EXTERNAL: the callback returned " + std::to_string(rc); return DHMC_ERR_CALLBACK; }
@@ -481,7 +495,7 @@ int external_eval(dhmc_ctx* c, const double* q) {
 }  // namespace
 
 int dhmc_set_logdensity_callback(dhmc_ctx* c, dhmc_logdensity_fn fn, void* user) {
-    if (!c || !c->external) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!c || !c->external || c->builtin_big) return DHMC_ERR_INVALID_ARGUMENT;
     c->ext_fn = fn;
     c->ext_user = user;
     return DHMC_OK;

@@ -39,6 +39,42 @@ __device__ __forceinline__ double external_evaluate(const double* __restrict__ q
     return valid ? lq : -dm_inf();
 }
 
+// The built-in normal families beyond the register-resident kernels' 1024 coordinates (the reference has no dimension
+// limit, src/hamiltonian.jl:56-87): ℓ and ∇ℓ of ALL chains' positions q [C][ld] in one streaming kernel that stands where
+// the host's callback stands for an external model — lq [C], grad [C][ld] — so the same round engine (init, step-size
+// search, per-draw loops) serves them up to 4096 dimensions.  One wave per chain; the arithmetic (element order, the
+// ABI's blocked dot product) is the functors' of targets.hpp / oracle/targets.hpp.
+//   kind 0: standard normal; 1: diagonal normal (a = μ, b = precision); 2: tridiagonal precision (a = diag, b = off)
+template <int NPL>
+__global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D, int ld, const double* __restrict__ q,
+                                                                const double* __restrict__ a, const double* __restrict__ b,
+                                                                double* __restrict__ lq, double* __restrict__ grad) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const double* qr = q + (size_t)chain * ld;
+    double* gr = grad + (size_t)chain * ld;
+    LaneAcc<1, NPL> acc;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double x = qr[e];
+        double u, t;                                   // the dot is Σ u·t, the gradient −t
+        if (kind == 0) {
+            u = x; t = x;
+        } else if (kind == 1) {
+            u = x - a[e]; t = b[e] * u;
+        } else {
+            t = a[e] * x;
+            if (e > 0 && e < D) t = t + b[e - 1] * qr[e - 1];
+            if (e < D - 1) t = t + b[e] * qr[e + 1];
+            u = x;
+        }
+        acc.add(0, k, u, t);
+        gr[e] = -t;
+    }
+    const double s = wave_allreduce1(acc.fold(0));
+    if (lane == 0) lq[chain] = -0.5 * s;
+}
+
 // initialize_warmup_state (mcmc.jl:129-132) without the density: positions (given, or random_position mcmc.jl:108 from
 // the chain's stream exactly as init_kernel does), unit metric, ϵ unspecified, counters cleared
 template <int NPL>

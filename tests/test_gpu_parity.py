@@ -247,7 +247,9 @@ def test_empty_and_unrecorded_runs(pkg):
     dev.run(5, fields=[]); ora.run(5, fields=[])                   # nothing recorded: state still advances identically
     assert np.array_equal(dev.position()[0], ora.position()[0])
     with pytest.raises(RuntimeError, match="unsupported"):
-        pkg.DeviceContext(1025, 1)                                 # D > 1024 is outside this build (DHMC_ERR_UNSUPPORTED)
+        pkg.DeviceContext(4097, 1)                                 # D > 4096 is outside this build (DHMC_ERR_UNSUPPORTED)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        pkg.DeviceContext(1025, 1, target=ol.TARGET_FUNNEL)        # beyond 1024 only the normal families and external models
     with pytest.raises(ValueError):
         dev.run(-1)
 
@@ -334,3 +336,38 @@ def test_dense_context_keeps_its_metric_across_init(pkg):
     e = pkg.DeviceContext(D, 3, seed=1)
     e.init(); e.set_metric_diag(np.full(D, 3.0)); e.init()
     assert np.array_equal(e.metric_diag(), np.ones((3, D)))        # the diagonal one is reset
+
+
+@pytest.mark.parametrize("family,D,metric", [("std", 1500, "diag"), ("diag", 2500, "diag"), ("tridiag", 1100, "diag"), ("tridiag", 1100, "dense")])
+def test_builtin_normal_families_beyond_1024_dimensions(pkg, family, D, metric):
+    """The reference has no dimension limit (hamiltonian.jl:56-87).  Beyond the register-resident kernels' 1024 coordinates
+    the built-in normal families run through the streaming round engine (32 / 64 slots per lane, K3 as 8 / 16 waves per
+    chain) with their density evaluated by builtin_normal_eval_kernel: init, step-size search, adaptive stage with a
+    metric update and a fixed stage, bit for bit against the oracle."""
+    rng = np.random.default_rng(D)
+    C = 3
+    if family == "std":
+        tgt, params = ol.TARGET_STD_NORMAL, None
+    elif family == "diag":
+        tgt = ol.TARGET_DIAG_NORMAL
+        params = ol.target_params_blob(tgt, D, mu=rng.normal(size=D), prec=1 / (rng.normal(size=D) ** 2 + 0.1))
+    else:
+        tgt = ol.TARGET_TRIDIAG_NORMAL
+        params = ol.target_params_blob(tgt, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
+    m = ol.METRIC_DENSE if metric == "dense" else ol.METRIC_DIAG
+    dev, ora = make_pair(pkg, D, C, target=tgt, params=params, seed=4, metric=m)
+    if metric == "dense":
+        idx = np.arange(D)
+        S = 0.5 ** np.abs(idx[:, None] - idx[None, :]) + 0.5 * np.eye(D)
+        dev.set_metric_dense(S); ora.set_metric_dense(S)
+    dev.init(); ora.init()
+    for x, y in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, y)
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora.stepsize())
+    a, b = dev.run(8, da={}), ora.run(8, da={})
+    assert_same(a, b, f"{family} D={D} {metric} adaptive")
+    if metric == "diag":
+        dev.update_metric_diag(a["draws"]); ora.update_metric_diag(b["draws"])
+        assert np.array_equal(dev.metric_diag(), ora.metric_diag())
+    assert_same(dev.run(5), ora.run(5), f"{family} D={D} {metric} fixed")

@@ -48,6 +48,7 @@ while time.time() - t0 < budget:
         for k_ in env: os.environ.pop(k_, None)
     ora = ol.Oracle(D, C, params=params, threads=4, **kw)
     desc = f"{kind} D={D} C={C} max_depth={md} seed={seed} offset={off} env={env}"
+    if os.environ.get("FUZZ_VERBOSE") == "1": print("case", desc, file=sys.stderr, flush=True)
     try:
         q0 = None if rng.random() < 0.5 or kind == "divergent" else rng.normal(size=(C, D))
         if kind == "divergent": q0 = np.zeros((C, D))
