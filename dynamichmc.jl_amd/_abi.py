@@ -26,7 +26,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("dim", C.c_int32), ("chains", C.c_int32),
                 ("chain_offset", C.c_int32), ("metric", C.c_int32), ("target", C.c_int32),
                 ("target_params", C.c_void_p), ("target_params_bytes", C.c_uint64),
-                ("max_depth", C.c_int32), ("reserved", C.c_int32), ("min_delta", C.c_double),
+                ("max_depth", C.c_int32), ("dense_per_chain", C.c_int32), ("min_delta", C.c_double),
                 ("seed", C.c_uint64)]
 
 
@@ -64,7 +64,7 @@ OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np
 # every symbol include/dhmc.h declares
 SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", "dhmc_version",
            "dhmc_init", "dhmc_set_position", "dhmc_get_position", "dhmc_set_metric_diag", "dhmc_get_metric_diag",
-           "dhmc_set_metric_dense", "dhmc_get_metric_dense", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
+           "dhmc_set_metric_dense", "dhmc_get_metric_dense", "dhmc_get_metric_dense_chain", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_update_metric_dense", "dhmc_state_bytes",
            "dhmc_export_state", "dhmc_import_state", "dhmc_last_run_kernel_ms",
            "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes",

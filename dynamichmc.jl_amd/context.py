@@ -50,11 +50,12 @@ def _is_device(a):
 class DeviceContext:
     def __init__(self, dim, chains, target=abi.TARGET_STD_NORMAL, target_params=None, seed=0x23EF614D,
                  max_depth=10, min_delta=-1000.0, chain_offset=0, metric=abi.METRIC_DIAG, device=0,
-                 stream=None):
+                 stream=None, dense_per_chain=False):
         self.D, self.C = int(dim), int(chains)
         cfg = abi.Config()
         cfg.device, cfg.dim, cfg.chains, cfg.chain_offset = device, self.D, self.C, chain_offset
         cfg.metric, cfg.target, cfg.max_depth, cfg.min_delta, cfg.seed = metric, target, max_depth, min_delta, seed
+        cfg.dense_per_chain = int(bool(dense_per_chain))   # one dense M⁻¹ per chain, each adapted from its own draws (the reference's semantics)
         if target_params is not None:
             target_params = np.ascontiguousarray(target_params)
             cfg.target_params = target_params.ctypes.data
@@ -144,9 +145,10 @@ class DeviceContext:
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(abi.lib().dhmc_set_metric_dense(self.h, _ptr(minv), 0), "dhmc_set_metric_dense")
 
-    def metric_dense(self):
+    def metric_dense(self, chain=0):
+        """(M⁻¹, W) of the shared dense metric, or of `chain` in a dense_per_chain context."""
         m = np.zeros((self.D, self.D)); W = np.zeros((self.D, self.D))
-        self._chk(abi.lib().dhmc_get_metric_dense(self.h, _ptr(m), _ptr(W)), "dhmc_get_metric_dense")
+        self._chk(abi.lib().dhmc_get_metric_dense_chain(self.h, C.c_int32(chain), _ptr(m), _ptr(W)), "dhmc_get_metric_dense_chain")
         return m, W
 
     def set_stepsize(self, eps):

@@ -51,6 +51,7 @@ struct dhmc_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int dense_rounds = 1;
+    int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     LogisticRound lr{};
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
@@ -156,15 +157,18 @@ int upload_dense_metric(dhmc_ctx* c, const std::vector<double>& S, const std::ve
             a[(size_t)i * Dp + j] = S[(size_t)i * D + j];
             b[(size_t)j * Dp + i] = W[(size_t)i * D + j];   // transpose: WT[k][i] = W[i][k]
         }
-    HIP_TRY(c, hipMemcpyAsync(c->d_Minv, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_WT, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const size_t nmat = c->per_chain_dense ? (size_t)c->cfg.chains : 1;
+    for (size_t m = 0; m < nmat; ++m) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_Minv + m * Dp * Dp, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_WT + m * Dp * Dp, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DHMC_OK;
 }
 // κ := GaussianKineticEnergy(Symmetric(src)) (hamiltonian.jl:73) entirely on the device (dense_factor.hpp): src is a
 // device matrix with row stride lsrc whose upper triangle is read.  The context's metric is replaced only if src is
 // finite and positive definite; otherwise DHMC_ERR_INVALID_ARGUMENT (the reference's cholesky throws).
-int device_dense_metric(dhmc_ctx* c, const double* src, int lsrc) {
+int device_dense_metric(dhmc_ctx* c, const double* src, int lsrc, int slot = -1) {   // slot: a chain of a per-chain dense context, -1: all
     const int D = c->cfg.dim, ld = c->Dpad;
     const size_t n = (size_t)ld * ld;
     double* Stmp = c->d_fwork + 3 * n;
@@ -177,8 +181,12 @@ int device_dense_metric(dhmc_ctx* c, const double* src, int lsrc) {
     HIP_TRY(c, hipMemcpyAsync(flags, c->d_fflags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (flags[0] || flags[1]) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipMemcpyAsync(c->d_Minv, Stmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_WT, WTtmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const size_t nmat = c->per_chain_dense ? (size_t)c->cfg.chains : 1;
+    for (size_t m = 0; m < nmat; ++m) {
+        if (slot >= 0 && (size_t)slot != m) continue;
+        HIP_TRY(c, hipMemcpyAsync(c->d_Minv + m * n, Stmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_WT + m * n, WTtmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DHMC_OK;
 }
@@ -358,12 +366,16 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         c->tp.b = db;
     }
     if (cfg->metric == DHMC_METRIC_DENSE) {   // GaussianKineticEnergy(N) as a dense identity
-        if ((rc = dev_alloc(c, &c->d_Minv, Dp * Dp))) return fail(rc);
-        if ((rc = dev_alloc(c, &c->d_WT, Dp * Dp))) return fail(rc);
+        c->per_chain_dense = cfg->dense_per_chain != 0;
+        if (c->per_chain_dense && c->external) return fail(DHMC_ERR_UNSUPPORTED);
+        const size_t nmat = c->per_chain_dense ? C : 1;
+        if ((rc = dev_alloc(c, &c->d_Minv, nmat * Dp * Dp))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->d_WT, nmat * Dp * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_fwork, 4 * Dp * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_fflags, 2))) return fail(rc);
-        c->dm = DenseMetric{c->d_Minv, c->d_WT};
+        c->dm = DenseMetric{c->d_Minv, c->d_WT, c->per_chain_dense ? Dp * Dp : (size_t)0};
         if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
+        if (c->per_chain_dense) c->dense_rounds = 0;   // the GEMM engine shares one M⁻¹ across the rows of a product
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
@@ -536,11 +548,10 @@ int dhmc_set_position(dhmc_ctx* c, const double* q, int on_device) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // dhmc_init does the evaluation (and resets κ, ϵ, counters): keep those aside and put them back
     const size_t C = c->cfg.chains, Dp = c->Dpad;
-    const bool dense = c->cfg.metric == DHMC_METRIC_DENSE;
     struct Keep { void* live; size_t bytes; DevBuf copy; };
     Keep keep[7] = {{c->st.minv, C * Dp * sizeof(double), {}}, {c->st.W, C * Dp * sizeof(double), {}}, {c->st.eps, C * sizeof(double), {}},
                     {c->st.da, C * sizeof(DAState), {}}, {c->st.transition, C * sizeof(uint32_t), {}},
-                    {dense ? (void*)c->d_Minv : nullptr, Dp * Dp * sizeof(double), {}}, {dense ? (void*)c->d_WT : nullptr, Dp * Dp * sizeof(double), {}}};
+                    {nullptr, 0, {}}, {nullptr, 0, {}}};   // (dhmc_init leaves a dense metric alone)
     for (auto& k : keep) {
         if (!k.live) continue;
         HIP_TRY(c, hipMalloc(&k.copy.p, k.bytes));
@@ -613,14 +624,15 @@ int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
     return rc;
 }
 
-int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) {
-    if (!c || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+int dhmc_get_metric_dense_chain(dhmc_ctx* c, int32_t chain, double* minv, double* W) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || chain < 0 || chain >= c->cfg.chains) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int D = c->cfg.dim;
     const size_t Dp = c->Dpad;
+    const size_t off = c->per_chain_dense ? (size_t)chain * Dp * Dp : 0;
     std::vector<double> a(Dp * Dp), b(Dp * Dp);
-    HIP_TRY(c, hipMemcpyAsync(a.data(), c->d_Minv, a.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b.data(), c->d_WT, b.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(a.data(), c->d_Minv + off, a.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b.data(), c->d_WT + off, b.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) {
@@ -629,6 +641,8 @@ int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) {
         }
     return DHMC_OK;
 }
+
+int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) { return dhmc_get_metric_dense_chain(c, 0, minv, W); }
 
 int dhmc_set_stepsize(dhmc_ctx* c, const double* eps, int per_chain, int on_device) {
     if (!c || !eps) return DHMC_ERR_INVALID_ARGUMENT;
@@ -960,21 +974,26 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int D = c->cfg.dim, ld = c->Dpad;
-    const int64_t J = (int64_t)c->cfg.chains * n;
+    // shared M⁻¹: one estimate from the pooled draws of all chains; per-chain: every chain from its own n draws (mcmc.jl:281-285)
+    const int nest = c->per_chain_dense ? c->cfg.chains : 1;
+    const int64_t J = c->per_chain_dense ? n : (int64_t)c->cfg.chains * n;
     Staged s;
-    int rc = stage_in(c, draws, sizeof(double) * (size_t)J * D, on_device, &s);
+    int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s);
     if (rc) return rc;
     DevBuf bmean, bS;
     HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
     HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
     double* const mean = (double*)bmean.p;
     double* const S = (double*)bS.p;
-    hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean);
-    hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, (const double*)s.dev, mean, S, ld);
-    hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { stage_free(c, &s); c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
-    rc = device_dense_metric(c, S, ld);                        // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
+    for (int k = 0; k < nest && rc == DHMC_OK; ++k) {
+        const double* x = (const double*)s.dev + (size_t)k * J * D;
+        hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean);
+        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld);
+        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; break; }
+        rc = device_dense_metric(c, S, ld, c->per_chain_dense ? k : -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
+    }
     stage_free(c, &s);
     return rc;
 }
@@ -1201,7 +1220,7 @@ int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {
     if (!c || !nbytes) return DHMC_ERR_INVALID_ARGUMENT;
     const uint64_t C = c->cfg.chains, Dp = c->Dpad;
     *nbytes = sizeof(BlobHeader) + 4 * C * Dp * sizeof(double) + 2 * C * sizeof(double) + C * sizeof(DAState) + 2 * C * sizeof(uint32_t);
-    if (c->cfg.metric == DHMC_METRIC_DENSE) *nbytes += 2 * Dp * Dp * sizeof(double);   // shared dense M⁻¹ and Wᵀ
+    if (c->cfg.metric == DHMC_METRIC_DENSE) *nbytes += (c->per_chain_dense ? C : 1) * 2 * Dp * Dp * sizeof(double);   // dense M⁻¹ and Wᵀ (shared, or one pair per chain)
     return DHMC_OK;
 }
 
@@ -1223,8 +1242,9 @@ static int blob_io(dhmc_ctx* c, char* blob, bool exporting) {
     HIP_TRY(c, io(c->st.transition, C * sizeof(uint32_t)));
     HIP_TRY(c, io(c->st.status, C * sizeof(uint32_t)));
     if (c->cfg.metric == DHMC_METRIC_DENSE) {
-        HIP_TRY(c, io(c->d_Minv, Dp * Dp * sizeof(double)));
-        HIP_TRY(c, io(c->d_WT, Dp * Dp * sizeof(double)));
+        const size_t nmat = c->per_chain_dense ? C : 1;
+        HIP_TRY(c, io(c->d_Minv, nmat * Dp * Dp * sizeof(double)));
+        HIP_TRY(c, io(c->d_WT, nmat * Dp * Dp * sizeof(double)));
     }
     return DHMC_OK;
 }

@@ -19,6 +19,8 @@ namespace dhmc {
 struct DenseMetric {
     const double* Minv;  // [Dpad][Dpad] symmetric, pads 0
     const double* WT;    // [Dpad][Dpad] = Wᵀ (upper triangular), W Wᵀ = M, pads 0
+    size_t stride;       // 0: one matrix shared by all chains; Dpad²: chain c's matrices start at c * stride (dense_per_chain)
+    __device__ __forceinline__ DenseMetric of_chain(int chain) const { return DenseMetric{Minv + chain * stride, WT + chain * stride, 0}; }
 };
 
 // dense workspace vector indices
@@ -122,8 +124,9 @@ __device__ __forceinline__ bool merge_core_dense(XM xm_, XMS xms_, XP xp_, XPS x
 }
 
 template <class T, int NPL>
-__global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, DenseMetric M) {
+__global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, DenseMetric Mall) {
     const int chain = blockIdx.x;
+    const DenseMetric M = Mall.of_chain(chain);
     const int lane = threadIdx.x;
     const int D = P.D, Dpad = P.Dpad;
 
@@ -432,8 +435,9 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
 
 // warmup(::InitialStepsizeSearch) with a dense metric (mcmc.jl:134-148 -> stepsize.jl:46-85)
 template <class T, int NPL>
-__global__ __launch_bounds__(64, 1) void stepsize_search_dense_kernel(SearchParams P, DenseMetric M) {
+__global__ __launch_bounds__(64, 1) void stepsize_search_dense_kernel(SearchParams P, DenseMetric Mall) {
     const int chain = blockIdx.x, lane = threadIdx.x;
+    const DenseMetric M = Mall.of_chain(chain);
     const int D = P.D, Dpad = P.Dpad;
     const T tgt(P.tp);
     const size_t row = (size_t)chain * Dpad;

@@ -55,8 +55,9 @@ __device__ __forceinline__ void store_unpadded(double* dst, int lane, int D, con
 
 // MODE 0: trajectory, MODE 1: acceptance ratios
 template <class T, int NPL, bool DENSE, int MODE>
-__global__ __launch_bounds__(64, 1) void probe_kernel(ProbeParams P, DenseMetric M) {
+__global__ __launch_bounds__(64, 1) void probe_kernel(ProbeParams P, DenseMetric Mall) {
     const int chain = blockIdx.x, lane = threadIdx.x;
+    const DenseMetric M = Mall.of_chain(chain);
     const int D = P.D, Dpad = P.Dpad;
     extern __shared__ double lds[];
     const T tgt(P.tp);

@@ -110,7 +110,10 @@ typedef struct dhmc_config {
     const void* target_params; /* host pointer, copied at create */
     uint64_t target_params_bytes;
     int32_t max_depth;     /* NUTS.max_depth, 0 < max_depth <= 32 (NUTS.jl:190); default 10 (:166) */
-    int32_t reserved;
+    int32_t dense_per_chain; /* DHMC_METRIC_DENSE only.  0: one M^-1 shared by all chains, adapted from their pooled draws (the
+                              * GEMM engines; a stated deviation).  1: one M^-1 [D][D] PER CHAIN, each adapted from that chain's own
+                              * draws — the reference's semantics (mcmc.jl:281-285); chains stream their own matrix (wave-per-chain
+                              * kernels), so this is for small D * chains (2 * chains * Dpad^2 doubles of HBM). */
     double min_delta;      /* NUTS.min_Δ < 0 (NUTS.jl:191); default -1000 */
     uint64_t seed;
 } dhmc_config;
@@ -181,11 +184,14 @@ int dhmc_set_metric_diag(dhmc_ctx* ctx, const double* minv, int per_chain, int o
 int dhmc_get_metric_diag(dhmc_ctx* ctx, double* minv, int on_device); /* [C][D] */
 /* GaussianKineticEnergy(M⁻¹) dense (hamiltonian.jl:73), contexts created with DHMC_METRIC_DENSE only:
  * minv [D][D], read as Symmetric(minv) from its upper triangle, shared by all chains;
- * W = cholesky(inv(M⁻¹)).L is built by the library (unblocked Cholesky, order fixed by the ABI).
+ * W = cholesky(inv(M⁻¹)).L is built by the library on the device (element-wise operation order fixed by the ABI,
+ * csrc/dense_factor.hpp); with dense_per_chain = 1 every chain receives a copy.
  * Returns DHMC_ERR_INVALID_ARGUMENT if the matrix is not positive definite. */
 int dhmc_set_metric_dense(dhmc_ctx* ctx, const double* minv, int on_device);
-/* host [D][D] each, either may be NULL: the symmetrised M⁻¹ and the lower-triangular W (W Wᵀ = M). */
+/* host [D][D] each, either may be NULL: the symmetrised M⁻¹ and the lower-triangular W (W Wᵀ = M); with
+ * dense_per_chain = 1 those of chain 0 — dhmc_get_metric_dense_chain returns any chain's. */
 int dhmc_get_metric_dense(dhmc_ctx* ctx, double* minv, double* W);
+int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, double* W);
 /* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */
 int dhmc_set_stepsize(dhmc_ctx* ctx, const double* eps, int per_chain, int on_device);
 int dhmc_get_stepsize(dhmc_ctx* ctx, double* eps, int on_device); /* [C] */

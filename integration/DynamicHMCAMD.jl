@@ -1,16 +1,27 @@
 # NOT EXECUTED in this repository (no Julia runtime in the build image or on the GPU box): the ccall shim of
 # INTEGRATION.md §2 as a file.  Every call it makes is exercised through the identical ctypes binding
 # (dynamichmc.jl_amd/_abi.py, context.py) by the GPU tests, and through tests/cabi/cabi_client.c from plain C.
+#
+# Two layers:
+#   1. primitives — one Julia function per C-ABI entry point (Context, init!, run!, update_metric!, ...);
+#   2. the drop-in surface — methods of DynamicHMC's OWN generic functions `warmup`, `mcmc`, `mcmc_steps`,
+#      `mcmc_next_step` for a `SamplingLogDensityAMD`, plus `mcmc_keep_warmup` / `mcmc_with_warmup` methods for a
+#      `DeviceLogDensity`, so that the reference's stage fold `_warmup` (src/mcmc.jl:450-457), its stage tuples
+#      (`default_warmup_stages`, `fixed_stepsize_warmup_stages`) and its result NamedTuples are used unchanged, with a
+#      leading chain dimension on every array.
 module DynamicHMCAMD
-using DynamicHMC: NUTS, DualAveraging, InitialStepsizeSearch, TuningNUTS, DynamicHMCError,
-                  TreeStatisticsNUTS, InvalidTree, Directions
+import DynamicHMC
+using DynamicHMC: NUTS, DualAveraging, FixedStepsize, InitialStepsizeSearch, TuningNUTS, DynamicHMCError,
+                  TreeStatisticsNUTS, InvalidTree, Directions, default_warmup_stages, default_reporter, report,
+                  REPORT_SIGDIGITS
+using LinearAlgebra: Diagonal, Symmetric
 const libdhmc = "libdhmc_amd.so"            # dynamichmc.jl_amd/lib/
 
 struct Config                              # dhmc_config, include/dhmc.h
     device::Int32; dim::Int32; chains::Int32; chain_offset::Int32
     metric::Int32; target::Int32
     target_params::Ptr{Cvoid}; target_params_bytes::UInt64
-    max_depth::Int32; reserved::Int32; min_delta::Float64; seed::UInt64
+    max_depth::Int32; dense_per_chain::Int32; min_delta::Float64; seed::UInt64
 end
 struct DualAveragingABI                    # dhmc_dual_averaging
     delta::Float64; gamma::Float64; kappa::Float64
@@ -46,17 +57,20 @@ function check(ctx, rc, what; status = nothing)                      # status: t
 end
 
 mutable struct Context
-    h::Ptr{Cvoid}; chains::Int; dim::Int
+    h::Ptr{Cvoid}; chains::Int; dim::Int; metric::Int
+    callback::Any                             # keeps the @cfunction of an external model alive
 end
 
 function Context(; dim, chains, target = 0, params = Float64[], seed = 0x23ef614d, algorithm = NUTS(),
-                 chain_offset = 0, device = 0, metric = 0)          # metric: 0 per-chain diagonal, 1 shared dense
+                 chain_offset = 0, device = 0, metric = 0, dense_per_chain = false)
+    # metric: 0 per-chain diagonal; 1 dense — one M⁻¹ shared and adapted from the pooled draws (GEMM engines), or with
+    # dense_per_chain one M⁻¹ per chain adapted from that chain's own draws, as the reference does (mcmc.jl:281-285)
     cfg = Config(device, dim, chains, chain_offset, metric, target, pointer(params), sizeof(params),
-                 algorithm.max_depth, 0, algorithm.min_Δ, seed)
+                 algorithm.max_depth, dense_per_chain, algorithm.min_Δ, seed)
     h = Ref{Ptr{Cvoid}}()
     rc = GC.@preserve params ccall((:dhmc_create, libdhmc), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || throw(ArgumentError("dhmc_create: code $rc"))
-    finalizer(c -> ccall((:dhmc_destroy, libdhmc), Cint, (Ptr{Cvoid},), c.h), Context(h[], chains, dim))
+    finalizer(c -> ccall((:dhmc_destroy, libdhmc), Cint, (Ptr{Cvoid},), c.h), Context(h[], chains, dim, metric, nothing))
 end
 
 # initialize_warmup_state (mcmc.jl:129-132); q0 is D×C (each column a chain) or nothing
@@ -132,7 +146,7 @@ function set_logdensity!(ctx, f!)
     cb = @cfunction($((user, q, C, ld, D, lq, g, stream) -> (f!(unsafe_wrap(ROCArray, Ptr{Float64}(lq), (C,)),
             unsafe_wrap(ROCArray, Ptr{Float64}(g), (ld, C)), unsafe_wrap(ROCArray, Ptr{Float64}(q), (ld, C))); Cint(0))),
         Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
-    ctx.callback = cb                         # keep it alive (add the field to Context)
+    ctx.callback = cb                         # keep it alive
     check(ctx, ccall((:dhmc_set_logdensity_callback, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, cb, C_NULL), "dhmc_set_logdensity_callback")
 end
 
@@ -142,5 +156,128 @@ function export_state(ctx)
     blob = Vector{UInt8}(undef, n[])
     check(ctx, ccall((:dhmc_export_state, libdhmc), Cint, (Ptr{Cvoid}, Ptr{UInt8}, UInt64), ctx.h, blob, n[]), "dhmc_export_state")
     blob
+end
+
+# ---- Q, κ, ϵ of all chains: the WarmupState (mcmc.jl:72-79) with a chain dimension ------------------------------
+# Q := evaluate_ℓ(ℓ, q) at positions of the caller's (D×C), keeping κ, ϵ and the random streams (dhmc_set_position)
+set_position!(ctx, q::Matrix{Float64}) = check(ctx, ccall((:dhmc_set_position, libdhmc), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx.h, q, 0), "dhmc_set_position")
+function position(ctx)
+    q = Matrix{Float64}(undef, ctx.dim, ctx.chains); ℓq = Vector{Float64}(undef, ctx.chains); ∇ℓq = similar(q)
+    check(ctx, ccall((:dhmc_get_position, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+                     ctx.h, q, ℓq, ∇ℓq, 0), "dhmc_get_position")
+    (; q, ℓq, ∇ℓq)                            # column c = EvaluatedLogDensity of chain c (hamiltonian.jl:165-186)
+end
+function stepsize(ctx)
+    ϵ = Vector{Float64}(undef, ctx.chains)
+    check(ctx, ccall((:dhmc_get_stepsize, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx.h, ϵ, 0), "dhmc_get_stepsize")
+    ϵ
+end
+set_stepsize!(ctx, ϵ::Vector{Float64}) = check(ctx, ccall((:dhmc_set_stepsize, libdhmc), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, ϵ, length(ϵ) == ctx.chains, 0), "dhmc_set_stepsize")
+function kinetic_energy(ctx)                  # κ: D×C diagonals of M⁻¹ (one per chain), or the shared Symmetric M⁻¹
+    if ctx.metric == 0
+        m = Matrix{Float64}(undef, ctx.dim, ctx.chains)
+        check(ctx, ccall((:dhmc_get_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx.h, m, 0), "dhmc_get_metric_diag")
+        return [DynamicHMC.GaussianKineticEnergy(Diagonal(m[:, c])) for c in 1:ctx.chains]
+    end
+    M = Matrix{Float64}(undef, ctx.dim, ctx.dim); W = similar(M)
+    check(ctx, ccall((:dhmc_get_metric_dense, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, M, W), "dhmc_get_metric_dense")
+    DynamicHMC.GaussianKineticEnergy(Symmetric(M), collect(W'))      # row-major [i][j] read column-major is the transpose
+end
+"The triple of mcmc.jl:72-79 for all chains; the numbers live in the context, this is their host-side view."
+current_warmup_state(ctx) = (Q = position(ctx), κ = kinetic_energy(ctx), ϵ = let e = stepsize(ctx); all(isnan, e) ? nothing : e end)
+
+# ---- the drop-in surface ------------------------------------------------------------------------------------------
+"A log density evaluated on the device: a built-in family (`target`, `params`: include/dhmc.h DHMC_TARGET_*) or the caller's
+own batched `logdensity_and_gradient!` (target 7).  `dimension`/`capabilities` are those of LogDensityProblems."
+struct DeviceLogDensity
+    dim::Int; target::Int; params::Vector{Float64}; f!::Any
+end
+DeviceLogDensity(dim; target = 0, params = Float64[], f! = nothing) = DeviceLogDensity(dim, f! === nothing ? target : 7, params, f!)
+
+"SamplingLogDensity (mcmc.jl:40-53) + the context that holds the chains.  `rng` is the seed of the ABI's counter-based streams."
+struct SamplingLogDensityAMD{L,O,S}
+    rng::UInt64; ℓ::L; algorithm::O; reporter::S; ctx::Context
+end
+
+# warmup(sampling_logdensity, stage, warmup_state) -> (results, warmup_state′): the reference's seam (iv), src/mcmc.jl:99,134,258
+DynamicHMC.warmup(sl::SamplingLogDensityAMD, ::Nothing, warmup_state) = (nothing, warmup_state)
+function DynamicHMC.warmup(sl::SamplingLogDensityAMD, s::InitialStepsizeSearch, warmup_state)
+    warmup_state.ϵ ≡ nothing || throw(ArgumentError("stepsize ϵ manually specified, won't perform initial search"))  # mcmc.jl:137
+    find_initial_stepsize!(sl.ctx, s)
+    st = current_warmup_state(sl.ctx)
+    report(sl.reporter, "found initial stepsize", ϵ = round.(st.ϵ; sigdigits = REPORT_SIGDIGITS))
+    nothing, st
+end
+function DynamicHMC.warmup(sl::SamplingLogDensityAMD, tuning::TuningNUTS{M}, warmup_state) where {M}
+    (; N, stepsize_adaptation, λ) = tuning
+    ctx = sl.ctx
+    results = run!(ctx, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing)   # mcmc.jl:271-280 for all chains
+    if M ≡ Diagonal
+        update_metric!(ctx, results.posterior_matrix, λ)                                              # mcmc.jl:209,281-284
+    elseif M ≡ Symmetric
+        update_metric_dense!(ctx, results.posterior_matrix, λ)                                        # mcmc.jl:210,218-222 (pooled)
+    end
+    M ≢ Nothing && report(sl.reporter, "adaptation finished", adapted_kinetic_energy = kinetic_energy(ctx))
+    results, current_warmup_state(ctx)
+end
+
+# mcmc(sampling_logdensity, N, warmup_state) (mcmc.jl:366-381)
+DynamicHMC.mcmc(sl::SamplingLogDensityAMD, N, warmup_state) =
+    let r = run!(sl.ctx, N); (posterior_matrix = r.posterior_matrix, tree_statistics = r.tree_statistics, logdensities = r.logdensities) end
+
+# stepwise (mcmc.jl:335-351): κ and ϵ of `warmup_state` are the context's unless the caller changed them
+struct MCMCStepsAMD; sl::SamplingLogDensityAMD; end
+function DynamicHMC.mcmc_steps(sl::SamplingLogDensityAMD, warmup_state)
+    warmup_state.ϵ ≡ nothing && throw(ArgumentError("ϵ ≢ nothing"))
+    warmup_state.ϵ == stepsize(sl.ctx) || set_stepsize!(sl.ctx, warmup_state.ϵ)
+    warmup_state.Q.q == position(sl.ctx).q || set_position!(sl.ctx, warmup_state.Q.q)
+    MCMCStepsAMD(sl)
+end
+function DynamicHMC.mcmc_next_step(steps::MCMCStepsAMD, Q)
+    ctx = steps.sl.ctx
+    Q.q == position(ctx).q || set_position!(ctx, Q.q)          # a Q that is not the context's own: evaluate it there
+    r = run!(ctx, 1)
+    position(ctx), r.tree_statistics[1, :]
+end
+
+# mcmc_keep_warmup / mcmc_with_warmup (mcmc.jl:521-532,575-584) with `chains` chains on one GPU
+function DynamicHMC.mcmc_keep_warmup(rng::Integer, ℓ::DeviceLogDensity, N::Integer; chains = 1, initialization = (),
+                                     warmup_stages = default_warmup_stages(), algorithm = NUTS(),
+                                     reporter = default_reporter(), device = 0, chain_offset = 0)
+    dense = any(s -> s isa TuningNUTS{Symmetric}, warmup_stages) || get(initialization, :κ, nothing) isa Matrix
+    ctx = Context(; dim = ℓ.dim, chains, target = ℓ.target, params = ℓ.params, seed = UInt64(rng), algorithm,
+                  chain_offset, device, metric = dense ? 1 : 0)
+    ℓ.f! === nothing || set_logdensity!(ctx, ℓ.f!)
+    sl = SamplingLogDensityAMD(UInt64(rng), ℓ, algorithm, reporter, ctx)
+    init!(ctx, get(initialization, :q, nothing))                                         # initialize_warmup_state (mcmc.jl:129-132)
+    κ = get(initialization, :κ, nothing)
+    κ isa Matrix && set_metric_dense!(ctx, κ)
+    κ isa Vector && check(ctx, ccall((:dhmc_set_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, κ, 0, 0), "dhmc_set_metric_diag")
+    haskey(initialization, :ϵ) && initialization.ϵ ≢ nothing && set_stepsize!(ctx, fill(Float64(initialization.ϵ), chains))
+    initial_warmup_state = current_warmup_state(ctx)
+    warmup, warmup_state = DynamicHMC._warmup(sl, warmup_stages, initial_warmup_state)   # the reference's own fold, unchanged
+    inference = DynamicHMC.mcmc(sl, N, warmup_state)
+    (; initial_warmup_state, warmup, final_warmup_state = warmup_state, inference, sampling_logdensity = sl)
+end
+function DynamicHMC.mcmc_with_warmup(rng::Integer, ℓ::DeviceLogDensity, N; kwargs...)
+    (; final_warmup_state, inference) = DynamicHMC.mcmc_keep_warmup(rng, ℓ, N; kwargs...)
+    (; κ, ϵ) = final_warmup_state
+    (; inference..., κ, ϵ)
+end
+
+# post-hoc diagnostics where the statistics lie (device pointers to [N×C] arrays of a run with on_device outputs)
+struct TreeStatisticsSummaryABI
+    n::Int64; a_mean::Float64; a_quantiles::NTuple{5,Float64}; max_depth::Int64; divergence::Int64; turning::Int64
+    depth_counts::NTuple{33,Int64}
+end
+function summarize_tree_statistics(π, a, tl, tr, depth, C, N; on_device = true, device = 0)
+    out = Ref{TreeStatisticsSummaryABI}(); ebfmi = Vector{Float64}(undef, C)
+    rc = ccall((:dhmc_summarize_tree_statistics, libdhmc), Cint,
+               (Int32, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Int64, Int64, Cint, Ref{TreeStatisticsSummaryABI}, Ptr{Float64}),
+               device, C_NULL, π, a, tl, tr, depth, C, N, on_device, out, ebfmi)
+    rc == 0 || error("dhmc_summarize_tree_statistics: code $rc")
+    (summary = out[], EBFMI = ebfmi)
 end
 end

@@ -127,10 +127,27 @@ int oracle_set_metric_dense(oracle_ctx* c, const double* minv) {
 }
 int oracle_update_metric_dense(oracle_ctx* c, const double* draws, int64_t N, double lambda) {
     if (c->cfg.metric != DHMC_METRIC_DENSE || N < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;
+    if (c->cfg.dense_per_chain) {   // the reference's own semantics: every chain from its own draws (src/mcmc.jl:281-285)
+        for (int i = 0; i < c->cfg.chains; ++i) {
+            std::vector<double> Si = pooled_regularized_cov(draws + (size_t)i * N * c->cfg.dim, N, c->cfg.dim, lambda);
+            GaussianKineticEnergy ki = GaussianKineticEnergy::dense_from(Si.data(), c->cfg.dim);
+            if (ki.D != c->cfg.dim) return DHMC_ERR_INVALID_ARGUMENT;
+            c->chains[i].kappa = ki;
+        }
+        return DHMC_OK;
+    }
     std::vector<double> S = pooled_regularized_cov(draws, (int64_t)c->cfg.chains * N, c->cfg.dim, lambda);
     GaussianKineticEnergy k = GaussianKineticEnergy::dense_from(S.data(), c->cfg.dim);
     if (k.D != c->cfg.dim) return DHMC_ERR_INVALID_ARGUMENT;
     for (auto& ch : c->chains) ch.kappa = k;
+    return DHMC_OK;
+}
+int oracle_get_metric_dense_chain(oracle_ctx* c, int32_t chain, double* M, double* W) {
+    if (chain < 0 || chain >= c->cfg.chains) return DHMC_ERR_INVALID_ARGUMENT;
+    const auto& k = c->chains[chain].kappa;
+    if (!k.dense) return DHMC_ERR_INVALID_ARGUMENT;
+    if (M) std::memcpy(M, k.Minv.data(), sizeof(double) * k.Minv.size());
+    if (W) std::memcpy(W, k.W.data(), sizeof(double) * k.W.size());
     return DHMC_OK;
 }
 int oracle_get_metric_dense_Minv(oracle_ctx* c, double* M) {

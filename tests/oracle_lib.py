@@ -24,7 +24,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("dim", C.c_int32), ("chains", C.c_int32),
                 ("chain_offset", C.c_int32), ("metric", C.c_int32), ("target", C.c_int32),
                 ("target_params", C.c_void_p), ("target_params_bytes", C.c_uint64),
-                ("max_depth", C.c_int32), ("reserved", C.c_int32), ("min_delta", C.c_double),
+                ("max_depth", C.c_int32), ("dense_per_chain", C.c_int32), ("min_delta", C.c_double),
                 ("seed", C.c_uint64)]
 
 
@@ -112,10 +112,11 @@ def target_params_blob(target, D, **kw):
 
 
 def make_config(D, chains, target=TARGET_STD_NORMAL, seed=0x23EF614D, max_depth=10,
-                min_delta=-1000.0, chain_offset=0, metric=METRIC_DIAG, device=0, params=None):
+                min_delta=-1000.0, chain_offset=0, metric=METRIC_DIAG, device=0, params=None, dense_per_chain=False):
     cfg = Config()
     cfg.device, cfg.dim, cfg.chains, cfg.chain_offset = device, D, chains, chain_offset
     cfg.metric, cfg.target, cfg.max_depth, cfg.min_delta, cfg.seed = metric, target, max_depth, min_delta, seed
+    cfg.dense_per_chain = int(bool(dense_per_chain))
     if params is not None:
         params = np.ascontiguousarray(params)
         cfg.target_params = params.ctypes.data
@@ -196,15 +197,13 @@ class Oracle:
         draws = np.ascontiguousarray(draws, np.float64)
         self._chk(lib().oracle_update_metric_dense(self.h, _p(draws), C.c_int64(draws.shape[1]), C.c_double(lam)))
 
-    def metric_dense(self):
-        M = np.zeros((self.D, self.D))
-        self._chk(lib().oracle_get_metric_dense_Minv(self.h, _p(M)))
-        return M, self.metric_dense_W()
+    def metric_dense(self, chain=0):
+        M = np.zeros((self.D, self.D)); W = np.zeros((self.D, self.D))
+        self._chk(lib().oracle_get_metric_dense_chain(self.h, C.c_int32(chain), _p(M), _p(W)))
+        return M, W
 
     def metric_dense_W(self):
-        W = np.zeros((self.D, self.D))
-        self._chk(lib().oracle_get_metric_dense_W(self.h, _p(W)))
-        return W
+        return self.metric_dense()[1]
 
     def metric_diag(self):
         m = np.zeros((self.C, self.D))

@@ -188,3 +188,36 @@ def test_dense_metric_adaptation_at_1000_dimensions(pkg):
     assert np.array_equal(md, mo), "M⁻¹"
     assert np.array_equal(Wd, Wo), "W"
     same(dev.run(3, da={}), ora.run(3, da={}), "after the metric update")
+
+
+def test_per_chain_dense_metric_is_the_references_semantics(pkg):
+    """dense_per_chain = 1: every chain has its own M⁻¹ and adapts it from its OWN draws (mcmc.jl:281-285, what C independent
+    reference runs do), instead of one shared matrix from the pooled draws.  Per-chain M⁻¹ / W and the chains' continuation
+    bit-equal to the oracle; the chains' matrices differ from each other; the resume blob carries all of them."""
+    K, C = 9, 5
+    rho = 0.6
+    diag = np.full(K, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
+    off = np.full(K, -rho / (1 - rho ** 2))
+    params = np.concatenate([diag, off])
+    kw = dict(metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, seed=21, dense_per_chain=True)
+    dev = pkg.DeviceContext(K, C, target_params=params, **kw)
+    ora = ol.Oracle(K, C, params=params, threads=4, **kw)
+    for e in (dev, ora):
+        e.init(); e.find_initial_stepsize()
+    for n in (60, 120):
+        a, b = dev.run(n, da={}), ora.run(n, da={})
+        same(a, b, f"stage {n}")
+        lam = 5.0 / n
+        dev.update_metric_dense(a["draws"], lam); ora.update_metric_dense(b["draws"], lam)
+        for c in range(C):
+            md, Wd = dev.metric_dense(c); mo, Wo = ora.metric_dense(c)
+            assert np.array_equal(md, mo) and np.array_equal(Wd, Wo), c
+    assert not np.array_equal(dev.metric_dense(0)[0], dev.metric_dense(1)[0])
+    same(dev.run(25), ora.run(25), "after adaptation")
+    twin = pkg.DeviceContext(K, C, target_params=params, **kw)
+    twin.import_state(dev.export_state())
+    same(dev.run(5), twin.run(5), "resumed")
+    S = rand_sigma(K)
+    dev.set_metric_dense(S); ora.set_metric_dense(S)              # one matrix for every chain
+    for c in (0, C - 1):
+        assert np.array_equal(dev.metric_dense(c)[0], ora.metric_dense(c)[0])
