@@ -284,6 +284,20 @@ __device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t pu
     }
 }
 
+// Phase timing for tools/experiments/phase_timing.py (compiled in with -DDHMC_PHASE_TIMING only): every wave
+// accumulates the s_memtime clocks it spends in each region of the per-draw loop; lane 0 adds them to g_phase.
+// (Indicative only: the clock reads serialise the wave's outstanding LDS/scalar-memory operations.)
+#ifdef DHMC_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define PH_DECL unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t0 = __builtin_readcyclecounter(); int ph_cur = 0;
+#define PH(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[ph_cur] += t_ - ph_t0; ph_t0 = t_; ph_cur = (i); }
+#define PH_FLUSH { PH(0); if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); atomicAdd(&g_phase[15], 1ull); } }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH
+#endif
+
 // ------------------------------------------------------------------------------------------
 // The per-draw loop kernel.  L1LDS: keep the level-1 suspended summary in LDS as well (needs
 // 4 Dpad-rows of LDS per wave, i.e. one wave per SIMD at Dpad = 1024).
@@ -375,7 +389,9 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         return s;
     };
 
+    PH_DECL
     for (int64_t n = 0; n < P.N; ++n) {
+        PH(1)   // momentum refresh + transition setup
         const uint32_t tr = tr0 + (uint32_t)n;
         const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
 
@@ -445,6 +461,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             const bool fwd = (dirs & 1u) != 0;  // next_direction (trees.jl:31-34)
             dirs >>= 1;
             const int dir = fwd ? 1 : 0;
+            PH(2)   // edge switch
             if (reg_edge != 2 && reg_edge != dir) {
                 // park the edge we leave ...
                 stv<NPL>(wsv(ws_edge(reg_edge, 0)), lane, q);
@@ -479,7 +496,9 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
+                PH(3)   // leaf
                 leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite);
+                PH(4)   // leaf scalars
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
                 total_steps += 1;
@@ -502,6 +521,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         auto a_p = [&](int k) { return p[k]; };
                         auto a_cr = [&](int k) { return cr[k]; };
                         bool turning;
+                        PH(5)   // merge, vector part
                         if (sub) {
                             if (level == 0) {
                                 turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p);
@@ -531,6 +551,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                               : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
                             }
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
+                            PH(6)   // merge, scalar part
                             const double wl = lv_omega.get(level);
                             double w;
                             logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
@@ -565,6 +586,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                               : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr);
                             }
                             double w;
+                            PH(6)
                             logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
                             vtop_steps += v_steps;
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
@@ -601,6 +623,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             break;
                         }
                     }
+                    PH(7)   // suspend
                     if (level >= 0 && !invalid) {
                         // suspend the running subtree at `level` until its right sibling is built
                         if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
@@ -642,6 +665,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         }
 
         // ---- TreeStatisticsNUTS and the new position (NUTS.jl:238-240) -----------------
+        PH(8)   // end of transition
         const double acc_rate = [&]() {
             double a = det_exp(vtop_lsa) / (double)vtop_steps;             // NUTS.jl:87
             return uni_f64(a < 1.0 ? a : 1.0);
@@ -683,6 +707,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     }
 
     // ---- write the chain back (WarmupState + adaptation state) --------------------------
+    PH_FLUSH
     stv<NPL>(P.st.q + row, lane, q);
     if constexpr (T::kPointwiseGrad) (void)tgt.eval(q, g, lane, D);
     stv<NPL>(P.st.g + row, lane, g);

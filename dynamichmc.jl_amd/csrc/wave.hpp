@@ -23,20 +23,22 @@ __device__ __forceinline__ double uni_f64(double x) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-// One DPP-moved copy of a double (two 32-bit DPP movs).
+// One DPP-moved copy of a double (two 32-bit DPP movs).  The permutations used are total (every lane reads a valid
+// lane), so the destination needs no initial value: mov_dpp, not update_dpp with a zeroed `old` (two v_mov per copy).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
     uint64_t b = (uint64_t)__double_as_longlong(x);
-    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
-// DPP move restricted to the rows of ROWMASK; the other rows receive +0.0.
+// DPP move restricted to the rows of ROWMASK; the other rows are left UNDEFINED (wave_allreduce reads lane 63 only,
+// and no value of a masked-out row reaches it).
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_rows_f64(double x) {
     uint64_t b = (uint64_t)__double_as_longlong(x);
-    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -52,7 +54,8 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 // DPP (quad_perm, row_half_mirror, row_mirror: equal to xor 1,2,4,8 because the lanes of
 // each already-reduced group hold identical values); 16 and 32 are row_bcast15 / row_bcast31,
 // which leave (r3 + r2) + (r1 + r0) in lane 63 — the same bits as (r0 + r1) + (r2 + r3) since
-// IEEE addition commutes — read back as a scalar.
+// IEEE addition commutes — read back as a scalar.  (After row_bcast15 only rows 1 and 3 are meaningful, after
+// row_bcast31 only row 3: lane 63 = (v₃ + v₂) + lane 31, lane 31 = v₁ + v₀.)
 template <int N>
 __device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
 #pragma unroll

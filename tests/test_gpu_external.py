@@ -113,8 +113,8 @@ def test_model_with_more_than_1024_dimensions(pkg):
     assert np.abs(x.mean(0) / sd.cpu().numpy()).max() < 0.25
     assert np.abs(x.std(0) / sd.cpu().numpy() - 1).max() < 0.2
     assert 0.6 < r["tree_statistics"].acceptance_rate.mean() < 0.95
-    with pytest.raises(RuntimeError):
-        pkg.mcmc_with_warmup(3, pkg.StandardNormal(3000), 5, chains=2, reporter=pkg.NoProgressReport())   # built-in families: D <= 1024
+    with pytest.raises((ValueError, RuntimeError)):
+        pkg.mcmc_with_warmup(3, pkg.StandardNormal(4097), 5, chains=2, reporter=pkg.NoProgressReport())   # every family: D <= 4096
     with pytest.raises((ValueError, RuntimeError)):
         pkg.mcmc_with_warmup(3, pkg.TorchLogDensity(4097, logdensity=lambda q: -0.5 * (q * q).sum(1)), 5, chains=2, reporter=pkg.NoProgressReport())
 
