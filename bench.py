@@ -113,6 +113,19 @@ def cpu_baseline(transitions, threads):
                       f"{nsteps} leapfrog steps in {dt:.1f} s (C++ oracle, -O3, one chain per thread)"}
 
 
+_WORK_STREAMS = []
+
+
+def _work_stream(torch):
+    """A non-default stream for a library context (kept alive here).  The round engines capture their rounds into a
+    hipGraph, which the legacy default stream does not allow; dhmc_run synchronises its stream before it returns, and the
+    timed regions are bracketed by device-wide synchronisation, so torch's own stream needs no extra ordering."""
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    _WORK_STREAMS.append(s)
+    return s.cuda_stream
+
+
 def bench_config3(args, pkg, torch):
     """BASELINE.json configs[2]: 1000-dim correlated MVN (tridiagonal precision), dense M⁻¹ = Σ shared by all
     chains, 4096 chains, sampling at a fixed per-chain ϵ found by dual averaging.  Not the driver's line (that is
@@ -127,7 +140,7 @@ def bench_config3(args, pkg, torch):
     Sigma = np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
     ctx = pkg.DeviceContext(Dd, C, metric=pkg.abi.METRIC_DENSE, target=pkg.abi.TARGET_TRIDIAG_NORMAL,
                             target_params=np.concatenate([diag, off]), seed=args.seed,
-                            stream=torch.cuda.current_stream().cuda_stream)
+                            stream=_work_stream(torch))
     ctx.set_metric_dense(Sigma)
     ctx.init(np.random.default_rng(5).normal(size=(C, Dd)) * sig)
     ctx.find_initial_stepsize()
@@ -172,7 +185,7 @@ def bench_config45(args, pkg, torch):
     T, K = args.transitions, args.steps
     if args.config == 4:
         D, C = 30, 4096 if args.chains == CHAINS_PER_GPU else args.chains
-        ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_FUNNEL, seed=args.seed, stream=torch.cuda.current_stream().cuda_stream)
+        ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_FUNNEL, seed=args.seed, stream=_work_stream(torch))
         ctx.init(); ctx.find_initial_stepsize()
         for n, metric in ((75, False), (25, True), (50, True), (100, True), (200, True), (50, False)):
             d = torch.empty((C, n, D), dtype=torch.float64, device="cuda")
@@ -187,7 +200,7 @@ def bench_config45(args, pkg, torch):
         X = rng.normal(size=(N, D)) / 16
         y = (rng.random(N) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
         ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_LOGISTIC, target_params=pkg.LogisticRegression(X, y).params(),
-                                seed=args.seed, stream=torch.cuda.current_stream().cuda_stream)
+                                seed=args.seed, stream=_work_stream(torch))
         ctx.init(); ctx.set_stepsize(0.02)
         d = torch.empty((C, 20, D), dtype=torch.float64, device="cuda")
         ctx.run_into(20, {"draws": d}, da={}); ctx.update_metric_diag(d); ctx.run_into(15, {}, da={})
