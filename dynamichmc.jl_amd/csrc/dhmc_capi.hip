@@ -126,6 +126,10 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
         hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)((a.P.tp.npad + 255) / 256), a.P.C), dim3(256), 0, s, a.P, a.R, L);
         hipLaunchKernelGGL(logistic_sum_kernel, g, b, 0, s, a.P, a.R, L);
         break;
+    case 4:
+        (void)hipMemsetAsync(L.act_count, 0, sizeof(int), s);
+        hipLaunchKernelGGL(rounds_active_list_kernel, dim3((a.P.C + 255) / 256), dim3(256), 0, s, a.P, a.R, L);
+        break;
     default: DHMC_NPL_SWITCH(rounds_k2_logistic_kernel, a.P, a.R, L) break;
     }
 #undef DHMC_NPL_SWITCH
@@ -443,6 +447,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.T, C * npad))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
+            c->lr.nz = (int)((npad + DHMC_LOGISTIC_BLOCK - 1) / DHMC_LOGISTIC_BLOCK);
+            if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
+            if ((rc = dev_alloc(c, &c->lr.act, C + 1))) return fail(rc);
+            c->lr.act_count = c->lr.act + C;
         }
     }
     if (c->external) {
@@ -879,9 +887,11 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
                 launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
-                launch_gemm(c->st.q, ld, c->tp.b, npad, c->lr.H, npad, C, ld, npad, c->stream);        // η = Q′·Xᵀ
+                launch_logistic_op(4, c->NPL, ra, c->lr, c->stream);                                   // the rows of this round
+                launch_gemm_list(c->st.q, ld, c->tp.b, npad, c->lr.H, npad, C, ld, npad, c->lr.act, c->lr.act_count, c->stream);   // η = Q′·Xᵀ
                 launch_logistic_op(2, c->NPL, ra, c->lr, c->stream);                                   // r, S₁
-                launch_gemm(c->lr.H, npad, c->tp.a, ld, c->rb.tbuf, ld, C, npad, ld, c->stream);       // Xᵀr = R·X
+                launch_gemm_splitk(c->lr.H, npad, c->tp.a, ld, c->lr.P, ld, (size_t)C * ld, C, npad, ld, DHMC_LOGISTIC_BLOCK,
+                                   c->lr.act, c->lr.act_count, c->stream);                             // Xᵀr = R·X, block by block
                 launch_logistic_op(3, c->NPL, ra, c->lr, c->stream);                                   // ∇ℓ, ℓ, p′, p♯
                 if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }

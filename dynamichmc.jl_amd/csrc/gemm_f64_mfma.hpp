@@ -45,7 +45,8 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
                                                                    const double* __restrict__ B, int ldb,
                                                                    double* __restrict__ OUT, int ldo, int K, int nrows,
                                                                    const int* __restrict__ row_list,
-                                                                   const int* __restrict__ row_count) {
+                                                                   const int* __restrict__ row_count,
+                                                                   int kblk = 0, size_t zstride = 0) {
     constexpr int WS = 16 * FR;                       // rows/cols per wave
     constexpr int TM = WS * WT, TN = WS * WT, NT = 64 * WT * WT;
     constexpr int LS = TN + 16;                       // LDS row stride: the 4 k-rows of a fragment land on disjoint bank halves
@@ -66,10 +67,17 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     int a_grow = row0 + a_row;
     a_grow = a_grow < count ? a_grow : count - 1;       // clamp (clamped rows are not stored)
     if (row_list) a_grow = row_list[a_grow];
-    const double* a_src = A + (size_t)a_grow * lda + a_k;
+    // split-K (kblk > 0): workgroup z owns k in [z kblk, min(K, (z+1) kblk)) and writes its partial products to
+    // OUT + z zstride; the caller adds the partial results in ascending z (an ABI order: include/dhmc.h, logistic Σ_n)
+    const int kbeg = kblk > 0 ? (int)blockIdx.z * kblk : 0;
+    if (kblk > 0) {
+        K = (K - kbeg) < kblk ? (K - kbeg) : kblk;
+        OUT += (size_t)blockIdx.z * zstride;
+    }
+    const double* a_src = A + (size_t)a_grow * lda + kbeg + a_k;
     constexpr int B_TPR = TN / PER;                     // threads per B row (one k)
     const int b_k = t / B_TPR, b_c = (t % B_TPR) * PER;
-    const double* b_src = B + (size_t)b_k * ldb + col0 + b_c;
+    const double* b_src = B + (size_t)(kbeg + b_k) * ldb + col0 + b_c;
 
     // BLK: every 16×16×4 step is issued as four v_mfma_f64_4x4x4_f64 on four accumulators (operand pairing described at
     // gemm_skinny_f64_kernel below) — same bits, higher issue rate than v_mfma_f64_16x16x4_f64 on gfx950.
@@ -463,6 +471,22 @@ inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int 
                              const int* row_count, hipStream_t s) {
     dim3 grid(ld / 64, (nrows + 63) / 64);
     hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+}
+// Split-K product over gathered rows: P[z][r][0..N) = Σ_{k in block z} A[r][k] · B[k][0..N) for the rows r of row_list
+// (all rows 0..M-1 when row_list is null), z = 0 .. ceil(K / kblk) - 1; P is [nz][zstride] with rows of ldo doubles.
+inline void launch_gemm_splitk(const double* A, int lda, const double* B, int ldb, double* P, int ldo, size_t zstride, int M,
+                               int K, int N, int kblk, const int* row_list, const int* row_count, hipStream_t s) {
+    const int nz = (K + kblk - 1) / kblk;
+    dim3 grid(N / 64, (M + 63) / 64, nz);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, P, ldo, K, M, row_list,
+                       row_count, kblk, zstride);
+}
+// OUT[r][0..N) = A[r][0..K) · B for the rows r of row_list (64×64 tiles)
+inline void launch_gemm_list(const double* A, int lda, const double* B, int ldb, double* OUT, int ldo, int M, int K, int N,
+                             const int* row_list, const int* row_count, hipStream_t s) {
+    dim3 grid(N / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, row_list,
+                       row_count, 0, (size_t)0);
 }
 // General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16).  64×64 tiles (4 waves × 32×32)
 // when that grid fills the chip; otherwise 32×32 tiles worked by 4 waves of one 16×16 MFMA tile each, so a

@@ -23,6 +23,7 @@
 //                                (src/hamiltonian.jl:205) cannot change the outcome and is skipped.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/dhmc.h"
 #include "../../include/dhmc_detmath.h"
 #include "wave.hpp"
 
@@ -210,10 +211,18 @@ struct LogisticT {
     __device__ explicit LogisticT(const TargetParams& p) : X(p.a), XT(p.b), y(p.c), N(p.n), Npad(p.npad), Dpad(p.Dpad) {}
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        double gb[NPL];                                  // the running block's chains; g: the blocks folded so far
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) g[k] = 0.0;
+        for (int k = 0; k < NPL; ++k) { g[k] = 0.0; gb[k] = 0.0; }
         double lpart = 0.0;
         for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) {
+            if (n0 != 0 && n0 % DHMC_LOGISTIC_BLOCK == 0) {      // block complete (include/dhmc.h: blocks added in ascending order)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    g[k] = (n0 == DHMC_LOGISTIC_BLOCK) ? gb[k] : g[k] + gb[k];
+                    gb[k] = 0.0;
+                }
+            }
             const int64_t n = n0 + lane;
             double eta = 0.0;
 #pragma unroll
@@ -236,14 +245,16 @@ struct LogisticT {
                 const double rn = readlane_f64(r, l2);
                 const double* __restrict__ xrow = X + (size_t)(n0 + l2) * Dpad;
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) g[k] = __builtin_fma(xrow[lane + WAVE * k], rn, g[k]);
+                for (int k = 0; k < NPL; ++k) gb[k] = __builtin_fma(xrow[lane + WAVE * k], rn, gb[k]);
             }
         }
+        const bool one_block = Npad <= DHMC_LOGISTIC_BLOCK;
         LaneAcc<1, NPL> qq;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             qq.add(0, k, q[k], q[k]);
-            g[k] = g[k] - q[k];
+            const double tot = one_block ? gb[k] : g[k] + gb[k];
+            g[k] = tot - q[k];
         }
         double red[2] = {lpart, qq.fold(0)};
         wave_allreduce<2>(red);

@@ -88,6 +88,14 @@ extern "C" {
 #define DHMC_TARGET_TRIDIAG_NORMAL 2 /* l = -1/2 q'Pq, P symmetric tridiagonal.  params: double diag[D], off[D] (off[D-1] ignored) */
 #define DHMC_TARGET_FUNNEL 3      /* Neal's funnel: v=q_0~N(0,3^2), q_i|v~N(0,e^v). params: none */
 #define DHMC_TARGET_LOGISTIC 4    /* Bernoulli-logit regression, N(0,I) prior.  params: int64 n; double X[n][D]; double y[n] */
+/* Order of the logistic gradient's sum over the observations, (Xᵀr)_d = Σ_n X[n][d] r_n: the observations are cut into
+ * BLOCKS of DHMC_LOGISTIC_BLOCK; inside a block one fma chain over n ascending from +0; the blocks' partial sums are added
+ * in ascending order, ((B0 + B1) + B2) + ...  (For n <= DHMC_LOGISTIC_BLOCK: one chain.)  A block is the K-range one
+ * workgroup of the split-K product R·X owns; without the blocks every output element is ONE dependent chain of n fma's,
+ * whose length — not the number of chains still running — sets the time of a leapfrog round. */
+#ifndef DHMC_LOGISTIC_BLOCK
+#define DHMC_LOGISTIC_BLOCK 2048
+#endif
 #define DHMC_TARGET_DENSE_NORMAL 6 /* l = -1/2 (q-mu)'P(q-mu), P full symmetric (read from its upper triangle). params: double mu[D], P[D][D] */
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
                                     * (dhmc_set_logdensity_callback); dim <= 4096 with the diagonal metric, <= 1024 with

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <memory>
 #include <vector>
+#include "../include/dhmc.h"
 #include "mathops.hpp"
 
 namespace oracle {
@@ -109,7 +110,8 @@ struct Funnel : Target {
 //   η_n = x_n·β,  ℓ = Σ_n [y_n η_n - log(1 + e^{η_n})] - 1/2 β·β,  ∇ℓ = Xᵀ(y - σ(η)) - β
 // Order: η_n is one fma chain over d ascending; with t = exp(-|η|): σ = η >= 0 ? 1/(1+t) : t/(1+t),
 // log1pexp(η) = max(η, 0) + log1p(t); the sum over observations is in wave order (64 interleaved
-// partial sums of plain adds + butterfly); (Xᵀr)_d is one fma chain over n ascending.
+// partial sums of plain adds + butterfly); (Xᵀr)_d is, per block of DHMC_LOGISTIC_BLOCK observations, one fma chain
+// over n ascending, the blocks' partial sums added in ascending order (include/dhmc.h).
 struct Logistic : Target {
     int64_t N;
     std::vector<double> X, y;   // X row-major [N][D]
@@ -132,9 +134,14 @@ struct Logistic : Target {
         double S2 = wave_dot(q, q, D);
         lq = S1 - 0.5 * S2;
         for (int d = 0; d < D; ++d) {
-            double acc = 0.0;
-            for (int64_t n = 0; n < N; ++n) acc = __builtin_fma(X[(size_t)n * D + d], r[n], acc);
-            g[d] = acc - q[d];
+            double tot = 0.0;
+            for (int64_t n0 = 0; n0 < N; n0 += DHMC_LOGISTIC_BLOCK) {
+                const int64_t n1 = n0 + DHMC_LOGISTIC_BLOCK < N ? n0 + DHMC_LOGISTIC_BLOCK : N;
+                double acc = 0.0;
+                for (int64_t n = n0; n < n1; ++n) acc = __builtin_fma(X[(size_t)n * D + d], r[n], acc);
+                tot = n0 == 0 ? acc : tot + acc;
+            }
+            g[d] = tot - q[d];
         }
     }
 };

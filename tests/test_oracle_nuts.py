@@ -169,3 +169,24 @@ def test_gaussian_ke_full_and_diagonal():  # test_hamiltonian.jl:20-47
     o = ol.Oracle(K, 1)
     o.set_metric_diag(1 / d)
     assert np.allclose(o.metric_diag()[0] * d, 1)
+
+
+def test_logistic_gradient_in_blocks_of_observations():
+    """include/dhmc.h: (Xᵀr)_d is summed block by block (DHMC_LOGISTIC_BLOCK observations, blocks added in ascending order).
+    With more than two blocks the oracle's ℓ and ∇ℓ are still those of the model: ℓ from the probe, ∇ℓ recovered from one
+    leapfrog step with p₀ = 0 and unit metric (q₁ - q₀ = ϵ²/2 ∇ℓ(q₀)), against numpy."""
+    rng = np.random.default_rng(11)
+    N, D = 5003, 5                                   # 3 blocks of 2048, the last one ragged
+    X = rng.normal(size=(N, D)) / 4
+    y = (rng.random(N) < 0.4).astype(float)
+    q0 = rng.normal(size=D) / 3
+    o = ol.Oracle(D, 1, target=ol.TARGET_LOGISTIC, params=ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y))
+    o.init(q0[None, :])
+    eps = 2.0 ** -6
+    tr = o.leapfrog_trajectory(eps, 0, 1, p=np.zeros(D))
+    eta = X @ q0
+    lq = np.sum(y * eta - np.logaddexp(0.0, eta)) - 0.5 * q0 @ q0
+    grad = X.T @ (y - 1 / (1 + np.exp(-eta))) - q0
+    assert abs(tr["logdensity"][0, 0] - lq) < 1e-9 * abs(lq)
+    got = (tr["q"][0, 1] - q0) * 2 / eps ** 2
+    assert np.allclose(got, grad, rtol=0, atol=1e-7 * np.abs(grad).max())
