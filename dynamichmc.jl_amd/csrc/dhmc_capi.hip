@@ -123,8 +123,7 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
     case 0: DHMC_NPL_SWITCH(rounds_momentum_diag_kernel, a.P, a.R) break;
     case 1: DHMC_NPL_SWITCH(rounds_k1_diag_kernel, a.P, a.R) break;
     case 2:
-        hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)((a.P.tp.npad + 255) / 256), a.P.C), dim3(256), 0, s, a.P, a.R, L);
-        hipLaunchKernelGGL(logistic_sum_kernel, g, b, 0, s, a.P, a.R, L);
+        hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)L.nz, a.P.C), b, 0, s, a.P, a.R, L);
         break;
     case 4:
         (void)hipMemsetAsync(L.act_count, 0, sizeof(int), s);
@@ -445,10 +444,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         c->tp.a = dx; c->tp.b = dxt; c->tp.c = dy; c->tp.n = n; c->tp.npad = (int64_t)npad; c->tp.Dpad = (int32_t)Dp;
         if (c->logistic_rounds) {
             if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
-            if ((rc = dev_alloc(c, &c->lr.T, C * npad))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
             c->lr.nz = (int)((npad + DHMC_LOGISTIC_BLOCK - 1) / DHMC_LOGISTIC_BLOCK);
             if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
+            if ((rc = dev_alloc(c, &c->lr.S1P, (size_t)c->lr.nz * C))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.act, C + 1))) return fail(rc);
             c->lr.act_count = c->lr.act + C;
         }

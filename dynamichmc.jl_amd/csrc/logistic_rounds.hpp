@@ -6,7 +6,7 @@
 //      K1         q′ = q + ϵ·(M⁻¹∘pₘ)                                            (hamiltonian.jl:278)
 //      K_act      the list of the chains that take a leapfrog this round (the rest have finished their transitions)
 //      G_eta      H  = Q′ · Xᵀ     [A×Dpad]·[Dpad×Npad]   fp64 MFMA GEMM over the A listed rows  (η_n = x_n·β, one chain over d)
-//      K_r        r_n = y_n − σ(η_n),  Σ_n [y_n η_n − log(1+e^{η_n})] in wave order;  H ← R
+//      K_r        r_n = y_n − σ(η_n),  Σ_n [y_n η_n − log(1+e^{η_n})] per block of observations in wave order;  H ← R
 //      G_g        P_z = R · X over the observations of block z   [A×Npad]·[Npad×Dpad], split-K fp64 MFMA GEMM: (Xᵀr)_d is,
 //                 per DHMC_LOGISTIC_BLOCK observations, one chain over n ascending (include/dhmc.h)
 //      K2         G = ((P₀ + P₁) + P₂) + …,  ∇ℓ = G − q′,  ℓ = S₁ − ½ q′·q′,  p′ = pₘ + ϵ/2 ∇ℓ,  p♯ = M⁻¹∘p′  (:279-280)
@@ -26,8 +26,8 @@ namespace dhmc {
 
 struct LogisticRound {
     double* H;    // [C][Npad]  η, then r
-    double* T;    // [C][Npad]  per-observation log-likelihood terms
-    double* S1;   // [C]        Σ_n [y_n η_n − log1pexp(η_n)]
+    double* S1P;  // [nz][C]    Σ [y_n η_n − log1pexp(η_n)] over the observations of block z
+    double* S1;   // [C]        ℓ's data term, the blocks added in ascending order (external models: ℓ from the callback)
     double* P;    // [nz][C][Dpad]  R·X over the observations of block z (split-K partial products)
     int nz;       // ceil(Npad / DHMC_LOGISTIC_BLOCK)
     int* act;     // [C]  chains that take a leapfrog this round
@@ -73,46 +73,39 @@ __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBu
     }
 }
 
-// K_r, part 1: per-observation link, residual and log-likelihood term — elementwise over [C][Npad], any order:
-// H <- r, T <- y η − log(1+e^η)  (0 for the padding observations).
-__global__ __launch_bounds__(256) void logistic_link_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+// K_r: link, residual and the block's share of the log-likelihood — one wave per (block of observations, listed chain).
+// H <- r (0 for the padding observations); S1P[z][chain] <- the block's Σ [y η − log(1+e^η)] in wave order (lane l adds
+// its observations n = l mod 64 in ascending order, then the butterfly: include/dhmc.h).
+__global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
     if ((int)blockIdx.y >= *L.act_count) return;
-    const int chain = L.act[blockIdx.y];
+    const int chain = L.act[blockIdx.y], lane = threadIdx.x, z = blockIdx.x;
     const int64_t N = P.tp.n, Npad = P.tp.npad;
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Npad) return;
     double* h = L.H + (size_t)chain * Npad;
-    double* tt = L.T + (size_t)chain * Npad;
-    const double eta = h[n];
-    const double t = det_exp(-__builtin_fabs(eta));
-    const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-    const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
-    const bool valid = n < N;
-    const double yn = P.tp.c[n];
-    h[n] = valid ? yn - sig : 0.0;
-    tt[n] = valid ? yn * eta - l1pe : 0.0;
-}
-
-// K_r, part 2: S₁ = Σ_n T[n] in the ABI's wave order (lane l accumulates n = l, l+64, … ascending; butterfly).
-__global__ __launch_bounds__(64) void logistic_sum_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
-    if ((int)blockIdx.x >= *L.act_count) return;
-    const int chain = L.act[blockIdx.x], lane = threadIdx.x;
-    const int64_t Npad = P.tp.npad;
-    const double* tt = L.T + (size_t)chain * Npad;
-    // the adds are one ordered chain per lane; the loads are not: 16 of them (8 KB per wave) in flight at a time
+    const int64_t nb = (int64_t)z * DHMC_LOGISTIC_BLOCK;
+    const int64_t ne = nb + DHMC_LOGISTIC_BLOCK < Npad ? nb + DHMC_LOGISTIC_BLOCK : Npad;
     double lpart = 0.0;
-    constexpr int U = 16;
-    int64_t n0 = 0;
-    for (; n0 + U * WAVE <= Npad; n0 += U * WAVE) {
-        double v[U];
+    constexpr int U = 8;                                  // loads in flight per lane
+    for (int64_t n0 = nb; n0 < ne; n0 += U * WAVE) {
+        double eta[U], y[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = tt[n0 + u * WAVE + lane];
+        for (int u = 0; u < U; ++u) {
+            const int64_t n = n0 + u * WAVE + lane;
+            eta[u] = n < ne ? h[n] : 0.0;
+            y[u] = n < ne ? P.tp.c[n] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) lpart = lpart + v[u];
+        for (int u = 0; u < U; ++u) {
+            const int64_t n = n0 + u * WAVE + lane;
+            const double t = det_exp(-__builtin_fabs(eta[u]));
+            const double sig = eta[u] >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+            const double l1pe = (eta[u] > 0 ? eta[u] : 0.0) + det_log1p_nonneg(t);
+            const bool valid = n < N;
+            if (n < ne) h[n] = valid ? y[u] - sig : 0.0;
+            if (valid) lpart = lpart + (y[u] * eta[u] - l1pe);
+        }
     }
-    for (; n0 < Npad; n0 += WAVE) lpart = lpart + tt[n0 + lane];
-    const double s1 = wave_allreduce1(lpart);
-    if (lane == 0) L.S1[chain] = s1;
+    const double bs = wave_allreduce1(lpart);
+    if (lane == 0) L.S1P[(size_t)z * P.C + (chain - P.chain_base)] = bs;
 }
 
 // K2: gradient, log density, second half step, p♯
@@ -138,7 +131,9 @@ __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, Rou
         qq.add(0, k, q[k], q[k]);
         g[k] = g[k] - q[k];
     }
-    double lq = uni_f64(L.S1[chain] - 0.5 * wave_allreduce1(qq.fold(0)));
+    double s1 = L.S1P[chain - P.chain_base];             // the blocks' sums, added in ascending order
+    for (int z = 1; z < L.nz; ++z) s1 = s1 + L.S1P[(size_t)z * P.C + (chain - P.chain_base)];
+    double lq = uni_f64(s1 - 0.5 * wave_allreduce1(qq.fold(0)));
     bool pos_finite = true;
     if (!dm_isfinite(lq)) pos_finite = all_finite<LogisticT, NPL>(q);
     lq = demote_lq(lq, pos_finite, true);

@@ -214,7 +214,7 @@ struct LogisticT {
         double gb[NPL];                                  // the running block's chains; g: the blocks folded so far
 #pragma unroll
         for (int k = 0; k < NPL; ++k) { g[k] = 0.0; gb[k] = 0.0; }
-        double lpart = 0.0;
+        double lpart = 0.0, S1 = 0.0;
         for (int64_t n0 = 0; n0 < Npad; n0 += WAVE) {
             if (n0 != 0 && n0 % DHMC_LOGISTIC_BLOCK == 0) {      // block complete (include/dhmc.h: blocks added in ascending order)
 #pragma unroll
@@ -222,6 +222,9 @@ struct LogisticT {
                     g[k] = (n0 == DHMC_LOGISTIC_BLOCK) ? gb[k] : g[k] + gb[k];
                     gb[k] = 0.0;
                 }
+                const double bs = wave_allreduce1(lpart);
+                S1 = (n0 == DHMC_LOGISTIC_BLOCK) ? bs : S1 + bs;
+                lpart = 0.0;
             }
             const int64_t n = n0 + lane;
             double eta = 0.0;
@@ -258,7 +261,8 @@ struct LogisticT {
         }
         double red[2] = {lpart, qq.fold(0)};
         wave_allreduce<2>(red);
-        return red[0] - 0.5 * red[1];
+        S1 = one_block ? red[0] : S1 + red[0];
+        return S1 - 0.5 * red[1];
     }
     __device__ __forceinline__ double finish(double s) const { return s; }
 };

@@ -92,7 +92,10 @@ extern "C" {
  * BLOCKS of DHMC_LOGISTIC_BLOCK; inside a block one fma chain over n ascending from +0; the blocks' partial sums are added
  * in ascending order, ((B0 + B1) + B2) + ...  (For n <= DHMC_LOGISTIC_BLOCK: one chain.)  A block is the K-range one
  * workgroup of the split-K product R·X owns; without the blocks every output element is ONE dependent chain of n fma's,
- * whose length — not the number of chains still running — sets the time of a leapfrog round. */
+ * whose length — not the number of chains still running — sets the time of a leapfrog round.
+ * The log-likelihood Σ_n [y_n η_n − log(1 + e^{η_n})] is summed over the same blocks: inside a block in wave order (the
+ * terms of the observations n = l mod 64 added in ascending order from +0 for l = 0..63, then the xor butterfly), the
+ * blocks' sums added in ascending order. */
 #ifndef DHMC_LOGISTIC_BLOCK
 #define DHMC_LOGISTIC_BLOCK 2048
 #endif

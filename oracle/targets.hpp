@@ -109,8 +109,8 @@ struct Funnel : Target {
 // DHMC_TARGET_LOGISTIC: Bernoulli-logit regression with a N(0, I) prior on β = q
 //   η_n = x_n·β,  ℓ = Σ_n [y_n η_n - log(1 + e^{η_n})] - 1/2 β·β,  ∇ℓ = Xᵀ(y - σ(η)) - β
 // Order: η_n is one fma chain over d ascending; with t = exp(-|η|): σ = η >= 0 ? 1/(1+t) : t/(1+t),
-// log1pexp(η) = max(η, 0) + log1p(t); the sum over observations is in wave order (64 interleaved
-// partial sums of plain adds + butterfly); (Xᵀr)_d is, per block of DHMC_LOGISTIC_BLOCK observations, one fma chain
+// log1pexp(η) = max(η, 0) + log1p(t); the sum over observations is, per block of DHMC_LOGISTIC_BLOCK observations, in
+// wave order (64 interleaved partial sums of plain adds + butterfly), the blocks' sums added in ascending order; (Xᵀr)_d is, per block of DHMC_LOGISTIC_BLOCK observations, one fma chain
 // over n ascending, the blocks' partial sums added in ascending order (include/dhmc.h).
 struct Logistic : Target {
     int64_t N;
@@ -119,8 +119,14 @@ struct Logistic : Target {
     void eval(const MathOps& M, const double* q, double& lq, double* g) const override {
         std::vector<double> r(N);
         double partial[64];
+        double S1 = 0.0;
         for (int l = 0; l < 64; ++l) partial[l] = 0.0;
         for (int64_t n = 0; n < N; ++n) {
+            if (n != 0 && n % DHMC_LOGISTIC_BLOCK == 0) {       // a block of observations is complete (include/dhmc.h)
+                const double bs = wave_tree(partial);
+                S1 = n == DHMC_LOGISTIC_BLOCK ? bs : S1 + bs;
+                for (int l = 0; l < 64; ++l) partial[l] = 0.0;
+            }
             const double* xn = &X[(size_t)n * D];
             double eta = 0.0;
             for (int d = 0; d < D; ++d) eta = __builtin_fma(xn[d], q[d], eta);
@@ -130,7 +136,10 @@ struct Logistic : Target {
             r[n] = y[n] - sig;
             partial[n % 64] = partial[n % 64] + (y[n] * eta - l1pe);
         }
-        double S1 = wave_tree(partial);
+        {
+            const double bs = wave_tree(partial);
+            S1 = N <= DHMC_LOGISTIC_BLOCK ? bs : S1 + bs;
+        }
         double S2 = wave_dot(q, q, D);
         lq = S1 - 0.5 * S2;
         for (int d = 0; d < D; ++d) {
