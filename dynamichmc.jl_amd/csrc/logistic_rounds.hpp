@@ -119,8 +119,20 @@ __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, Rou
     double q[NPL], g[NPL], p[NPL];
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(L.P + row, lane, g);        // (Xᵀ r): the blocks' partial products, added in ascending order
-    for (int z = 1; z < L.nz; ++z) {
-        const double* pz = L.P + (size_t)z * P.C * P.Dpad + row;
+    const size_t zs = (size_t)P.C * P.Dpad;
+    constexpr int ZU = 8;                // blocks fetched together (the adds stay in order)
+    int z = 1;
+    for (; z + ZU <= L.nz; z += ZU) {
+        double t[ZU][NPL];
+#pragma unroll
+        for (int u = 0; u < ZU; ++u) ldv<NPL>(L.P + (size_t)(z + u) * zs + row, lane, t[u]);
+#pragma unroll
+        for (int u = 0; u < ZU; ++u)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) g[k] = g[k] + t[u][k];
+    }
+    for (; z < L.nz; ++z) {
+        const double* pz = L.P + (size_t)z * zs + row;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) g[k] = g[k] + pz[lane + WAVE * k];
     }
@@ -131,8 +143,16 @@ __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, Rou
         qq.add(0, k, q[k], q[k]);
         g[k] = g[k] - q[k];
     }
-    double s1 = L.S1P[chain - P.chain_base];             // the blocks' sums, added in ascending order
-    for (int z = 1; z < L.nz; ++z) s1 = s1 + L.S1P[(size_t)z * P.C + (chain - P.chain_base)];
+    double s1 = 0.0;                                      // the blocks' sums, added in ascending order: lane z fetches block z's
+    for (int z0 = 0; z0 < L.nz; z0 += WAVE) {
+        const int zl = z0 + lane;
+        const double v = zl < L.nz ? L.S1P[(size_t)zl * P.C + (chain - P.chain_base)] : 0.0;
+        const int cnt = (L.nz - z0) < WAVE ? (L.nz - z0) : WAVE;
+        for (int i = 0; i < cnt; ++i) {
+            const double b = readlane_f64(v, i);
+            s1 = (z0 + i == 0) ? b : s1 + b;
+        }
+    }
     double lq = uni_f64(s1 - 0.5 * wave_allreduce1(qq.fold(0)));
     bool pos_finite = true;
     if (!dm_isfinite(lq)) pos_finite = all_finite<LogisticT, NPL>(q);
