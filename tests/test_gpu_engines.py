@@ -60,10 +60,13 @@ def test_dense_round_engine_equals_wave_kernel(pkg):
     _same(_run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "0"}, make, steps))
 
 
-@pytest.mark.parametrize("N,D,C", [(777, 70, 40), (6000, 70, 40), (4100, 200, 70)],
-                         ids=["short-K", "long-K skinny GEMM", "long-K skinny GEMM, 3 row blocks"])
+@pytest.mark.parametrize("N,D,C", [(777, 70, 40), (6000, 70, 40), (4100, 200, 70), (2048, 64, 33), (2049, 64, 130)],
+                         ids=["one block of observations", "three blocks", "three blocks, two row tiles", "exactly one block",
+                              "one block and one observation, three row tiles"])
 def test_logistic_round_engine_equals_functor_kernel(pkg, N, D, C):
-    """N >= 4096 observations sends G = R·X through gemm_skinny_f64_kernel (deep-pipelined, XCD-aware)."""
+    """The round engine (Q′·Xᵀ and the split-K R·X over the rows of the chains still running, link and block sums, the
+    blocks folded in order by K2) against the wave-per-chain functor, which walks the same blocks of DHMC_LOGISTIC_BLOCK
+    observations one chain at a time.  Chains finish their transitions at different rounds, so the row list shrinks."""
     rng = np.random.default_rng(4)
     X = rng.normal(size=(N, D)) / 8; y = (rng.random(N) < 0.5).astype(float)
     params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)

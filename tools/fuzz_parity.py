@@ -30,7 +30,7 @@ while time.time() - t0 < budget:
     elif kind == "divergent":
         target = ol.TARGET_ALWAYS_DIVERGENT
     elif kind == "logistic":
-        target = ol.TARGET_LOGISTIC; N = int(rng.choice([10, 64, 150, 333]))
+        target = ol.TARGET_LOGISTIC; N = int(rng.choice([10, 64, 150, 333, 2048, 2049, 4500]))   # 2049+: more than one block of observations
         X = rng.normal(size=(N, D)) / 2; y = (rng.random(N) < 0.5).astype(float)
         params = ol.target_params_blob(target, D, X=X, y=y)
     elif kind == "densenormal":
