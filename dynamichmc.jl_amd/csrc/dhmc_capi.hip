@@ -47,9 +47,13 @@ struct dhmc_ctx {
     double* d_fwork = nullptr;   // 4 × Dpad² doubles: work space of the device factorisation (dense_factor.hpp)
     int* d_fflags = nullptr;     // [2]: non-finite input, not positive definite
     RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
-    RoundBuffers rb2{};        // second half-batch: own list and counters, same vectors
+    RoundBuffers rbp[4]{};     // dense round engine: the batch is run as up to 4 parts on as many streams; every part has its own
+                               // list and counters, the vectors are shared
+    hipStream_t streams[4] = {};
+    int dense_parts = 2;       // DHMC_DENSE_PARTS
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_joins[4] = {};
     int dense_rounds = 1;
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
@@ -337,6 +341,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_MW")) c->mw = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
     const size_t C = cfg->chains, Dp = c->Dpad;
@@ -391,15 +396,15 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.ts, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list, C))) return fail(rc);
-        if ((rc = dev_alloc(c, &c->rb.list_count, 4))) return fail(rc);
+        if ((rc = dev_alloc(c, &c->rb.list_count, 8))) return fail(rc);
         c->rb.done_count = c->rb.list_count + 1;
-        c->rb2 = c->rb;
-        c->rb2.list = c->rb.list + C / 2;
-        c->rb2.list_count = c->rb.list_count + 2;
-        c->rb2.done_count = c->rb.list_count + 3;
         if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return fail(DHMC_ERR_HIP);
+        for (int i = 2; i < 4; ++i)
+            if (hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(DHMC_ERR_HIP);
+        for (int i = 1; i < 4; ++i)
+            if (hipEventCreateWithFlags(&c->ev_joins[i], hipEventDisableTiming) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.ts, 0, C * sizeof(TreeState)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cp, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemset(c->rb.cps, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -477,8 +482,11 @@ int dhmc_destroy(dhmc_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    for (int i = 2; i < 4; ++i)
+        if (c->streams[i]) { (void)hipStreamSynchronize(c->streams[i]); (void)hipStreamDestroy(c->streams[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 1; i < 4; ++i) if (c->ev_joins[i]) (void)hipEventDestroy(c->ev_joins[i]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -904,23 +912,28 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         // run as two half-batches on two streams so that one half's HBM-bound tree kernel overlaps the other
         // half's MFMA-bound contractions.
         const int ld = c->Dpad;
-        const int nh = (C >= 256 && C % 2 == 0) ? 2 : 1;
-        struct Half { RoundArgs ra; hipStream_t s; int base, count; } H[2];
+        const int nh = (C >= 256 && C % c->dense_parts == 0) ? c->dense_parts : 1;
+        struct Half { RoundArgs ra; hipStream_t s; int base, count; } H[4];
+        c->streams[0] = c->stream; c->streams[1] = c->stream2;
         for (int h = 0; h < nh; ++h) {
             H[h].base = h * (C / nh);
             H[h].count = (h == nh - 1) ? C - H[h].base : C / nh;
-            H[h].ra = RoundArgs{P, h == 0 ? c->rb : c->rb2};
+            c->rbp[h] = c->rb;
+            c->rbp[h].list = c->rb.list + H[h].base;
+            c->rbp[h].list_count = c->rb.list_count + 2 * h;
+            c->rbp[h].done_count = c->rb.list_count + 2 * h + 1;
+            H[h].ra = RoundArgs{P, c->rbp[h]};
             H[h].ra.P.chain_base = H[h].base;
             H[h].ra.P.C = H[h].count;
-            H[h].s = h == 0 ? c->stream : c->stream2;
+            H[h].s = c->streams[h];
         }
-        e = hipMemsetAsync(c->rb.list_count, 0, 4 * sizeof(int), c->stream);
-        if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
-        if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+        e = hipMemsetAsync(c->rb.list_count, 0, 8 * sizeof(int), c->stream);
+        if (nh >= 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
+        for (int h = 1; h < nh && e == hipSuccess; ++h) e = hipStreamWaitEvent(c->streams[h], c->ev_fork, 0);
         for (int h = 0; h < nh && e == hipSuccess; ++h)
             if ((rc = dispatch(c, Op::RoundStart, &H[h].ra, H[h].s, true))) { cleanup(); return rc; }
         unsigned long long rounds = 0;
-        int done[4] = {0, 0, 0, 0};
+        int done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // Four rounds of both half-batches = 64 launches on two streams, the same for the whole call.  DHMC_GRAPH=1
         // captures them ONCE into a graph (fork to stream2, join back) and launches the graph until every chain is done:
         // one host call per four rounds instead of 64.  Measured on config 3: 8.05e6 leapfrog-steps/s against 8.84e6 with
@@ -950,11 +963,13 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         // (not on the legacy default stream, which cannot be captured: hosts that hand over stream 0 get plain launches)
         if (c->use_graph && c->stream != nullptr && e == hipSuccess &&
             hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
-            if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+            if (nh >= 2 && e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
+            for (int h = 1; h < nh && e == hipSuccess; ++h) e = hipStreamWaitEvent(c->streams[h], c->ev_fork, 0);
             if (e == hipSuccess) rc = enqueue_reps();
-            if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_join, c->stream2);
-            if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            for (int h = 1; h < nh && e == hipSuccess; ++h) {
+                e = hipEventRecord(c->ev_joins[h], c->streams[h]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_joins[h], 0);
+            }
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e == hipSuccess) e = e2;
             if (e == hipSuccess && !rc) e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
@@ -967,17 +982,19 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 return DHMC_ERR_HIP;
             }
         }
-        while (e == hipSuccess && done[1] + done[3] < C) {
+        while (e == hipSuccess && done[1] + done[3] + done[5] + done[7] < C) {
             if (gexec) {
                 e = hipGraphLaunch(gexec, c->stream);
             } else {
                 if ((rc = enqueue_reps())) { cleanup(); return rc; }
                 if (e == hipSuccess) e = hipGetLastError();
-                if (nh == 2 && e == hipSuccess) e = hipEventRecord(c->ev_join, c->stream2);
-                if (nh == 2 && e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+                for (int h = 1; h < nh && e == hipSuccess; ++h) {
+                    e = hipEventRecord(c->ev_joins[h], c->streams[h]);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_joins[h], 0);
+                }
             }
             rounds += REPS;
-            if (e == hipSuccess) e = hipMemcpyAsync(done, c->rb.list_count, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(done, c->rb.list_count, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
         if (gexec) (void)hipGraphExecDestroy(gexec);
