@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../dynamichmc.jl_amd/csrc/gemm_f64_mfma.hpp"
+#include "gemm_f64_pc64.hpp"
 using namespace dhmc;
 template <int WT, int FR, int TK, bool BLK>
 static void one(const char* name, int M, int K, int N, int kblk, const double* A, const double* B, double* O, const std::vector<double>& hA,
@@ -37,6 +38,30 @@ static void one(const char* name, int M, int K, int N, int kblk, const double* A
         }
     printf("  %-14s grid %5d x %3d x %2d: %7.3f ms  %5.1f TFLOP/s  mismatches %ld\n", name, grid.x, grid.y, grid.z, best, 2.0 * M * K * N / best / 1e9, bad);
 }
+static void pc64(int M, int K, int N, int kblk, const double* A, const double* B, double* O, const std::vector<double>& hA, const std::vector<double>& hB) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9;
+    (void)hipMemset(O, 0xff, (size_t)M * N * 8);
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0);
+        launch_gemm_pc64(A, K, B, N, O, N, M, K, N, nullptr, nullptr, kblk, (size_t)M * N, 0);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    hipError_t err = hipGetLastError();
+    std::vector<double> hO((size_t)M * N);
+    (void)hipMemcpy(hO.data(), O, hO.size() * 8, hipMemcpyDeviceToHost);
+    const int Ke = kblk ? kblk : K;
+    long bad = 0, n = 0;
+    for (int i = 0; i < M; i += 31)
+        for (int j = 0; j < N; j += 7) {
+            double acc = 0;
+            for (int k = 0; k < Ke; ++k) acc = fma(hA[(size_t)i * K + k], hB[(size_t)k * N + j], acc);
+            bad += acc != hO[(size_t)i * N + j]; ++n;
+        }
+    printf("  %-14s                    : %7.3f ms  %5.1f TFLOP/s  mismatches %ld of %ld  (%s)\n", "pc64 4x4x4", best, 2.0 * M * K * N / best / 1e9, bad, n, hipGetErrorString(err));
+}
 static void shape(int M, int K, int N, int kblk) {
     std::vector<double> hA((size_t)M * K), hB((size_t)K * N);
     srand(1);
@@ -55,9 +80,13 @@ static void shape(int M, int K, int N, int kblk) {
     one<4, 2, 16, false>("<4,2,16>", M, K, N, kblk, A, B, O, hA, hB);
     one<4, 2, 16, true>("<4,2,16,BLK>", M, K, N, kblk, A, B, O, hA, hB);
     one<2, 1, 64, false>("<2,1,64>", M, K, N, kblk, A, B, O, hA, hB);
+    pc64(M, K, N, kblk, A, B, O, hA, hB);
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(O);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {                                  // quick mode: the new kernel's correctness on small and ragged shapes
+        shape(64, 64, 64, 0); shape(100, 256, 128, 0); shape(200, 4096 + 32, 64, 2048);
+    }
     shape(2048, 1024, 1024, 0);
     shape(4096, 1024, 1024, 0);
     shape(512, 256, 100032, 0);
