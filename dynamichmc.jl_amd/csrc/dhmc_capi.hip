@@ -51,6 +51,7 @@ struct dhmc_ctx {
                                // list and counters, the vectors are shared
     hipStream_t streams[4] = {};
     int dense_parts = 2;       // DHMC_DENSE_PARTS
+    int dense_row_lists = 1;   // DHMC_DENSE_ROW_LISTS: products over the running chains only once some have finished
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_joins[4] = {};
@@ -341,6 +342,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_MW")) c->mw = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
@@ -397,6 +399,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->rb.ts, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list_count, 8))) return fail(rc);
+        if (cfg->metric == DHMC_METRIC_DENSE && !c->lr.act) {       // row lists of the dense round engine: [C] + a counter per part
+            if ((rc = dev_alloc(c, &c->lr.act, C + 4))) return fail(rc);
+            c->lr.act_count = c->lr.act + C;
+        }
         c->rb.done_count = c->rb.list_count + 1;
         if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return fail(DHMC_ERR_HIP);
         for (int i = 2; i < 4; ++i)
@@ -940,6 +946,11 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         // plain launches — the host was never the limit, and the graph's branches overlap less than two free-running
         // streams do — so it is off by default.
         constexpr int REPS = 4;
+        // Once the first chains have finished their transitions (the host sees the done-counters every REPS rounds), the
+        // two products of a round are taken over the rows of the chains still running only (a row list per part, rebuilt
+        // every round): a call ends when its slowest chain does, and until then every round multiplied all rows.  While
+        // every chain is running — BASELINE config 3's equal trees from start to end — nothing changes.
+        bool row_lists = false;
         auto enqueue_reps = [&]() -> int {
             for (int rep = 0; rep < REPS && e == hipSuccess; ++rep) {
                 for (int h = 0; h < nh && e == hipSuccess; ++h) {
@@ -950,9 +961,20 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                     launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, H[h].count, R.list, R.list_count, s);            // p♯₀
                     if (int r = dispatch(c, Op::RoundK0, &H[h].ra, s, true)) return r;
                     e = hipMemsetAsync(R.list_count, 0, sizeof(int), s);
-                    launch_gemm_rows(R.cp + off, c->d_Minv, R.tbuf + off, ld, H[h].count, nullptr, nullptr, s);     // M⁻¹pₘ
-                    if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;
-                    launch_gemm_rows(R.cp + off, c->d_Minv, R.cps + off, ld, H[h].count, nullptr, nullptr, s);      // p♯
+                    if (!row_lists) {
+                        launch_gemm_rows(R.cp + off, c->d_Minv, R.tbuf + off, ld, H[h].count, nullptr, nullptr, s); // M⁻¹pₘ
+                        if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;
+                        launch_gemm_rows(R.cp + off, c->d_Minv, R.cps + off, ld, H[h].count, nullptr, nullptr, s);  // p♯
+                    } else {
+                        LogisticRound L = c->lr;
+                        L.act = c->lr.act + H[h].base;
+                        L.act_count = c->lr.act + C + h;
+                        if (e == hipSuccess) e = hipMemsetAsync(L.act_count, 0, sizeof(int), s);
+                        hipLaunchKernelGGL(rounds_active_list_kernel, dim3((H[h].count + 255) / 256), dim3(256), 0, s, H[h].ra.P, R, L);
+                        launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, H[h].count, L.act, L.act_count, s);           // M⁻¹pₘ
+                        if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;
+                        launch_gemm_rows(R.cp, c->d_Minv, R.cps, ld, H[h].count, L.act, L.act_count, s);            // p♯
+                    }
                     if (int r = dispatch(c, Op::RoundK3, &H[h].ra, s, true)) return r;
                 }
             }
@@ -996,6 +1018,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             rounds += REPS;
             if (e == hipSuccess) e = hipMemcpyAsync(done, c->rb.list_count, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            row_lists = c->dense_row_lists && !gexec && done[1] + done[3] + done[5] + done[7] > 0;
         }
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (graph) (void)hipGraphDestroy(graph);
