@@ -145,3 +145,26 @@ def test_multiwave_kernel_position_overflow_matches_oracle(pkg):
     assert np.array_equal(dev.status(), ora.status()) and (dev.status() != 0).any()
     for x, y in zip(dev.position(), ora.position()):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("parts", ["1", "2", "4"])
+def test_dense_rounds_row_lists_change_nothing_but_the_rows_multiplied(pkg, parts):
+    """Dense round engine with unequal trees (a metric without the target's correlation): from the moment the first
+    chains of a call have finished, the products run over the row list of the chains still running.  Same bits as
+    multiplying every row every round (DHMC_DENSE_ROW_LISTS=0), with the batch run as 1, 2 or 4 parts."""
+    D, C = 96, 512
+    rho = 0.8
+    sig = np.logspace(-0.5, 0.5, D)
+    Pc = np.zeros(D) + (1 + rho ** 2) / (1 - rho ** 2); Pc[0] = Pc[-1] = 1 / (1 - rho ** 2)
+    params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=Pc / sig ** 2, off=-rho / (1 - rho ** 2) / (sig[:-1] * sig[1:]))
+
+    def steps(ctx):
+        ctx.set_metric_dense(np.diag(sig ** 2)); ctx.init(); ctx.find_initial_stepsize()
+        a = ctx.run(12, da={})
+        b = ctx.run(8)
+        assert b["steps"].sum(1).min() < 0.7 * b["steps"].sum(1).max()        # the chains do finish at different rounds
+        return {**{"w_" + k: v for k, v in a.items()}, **b}
+    make = lambda: pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=21)
+    env = {"DHMC_DENSE_ROUNDS": "1", "DHMC_DENSE_PARTS": parts}
+    _same(_run_with_env(pkg, {**env, "DHMC_DENSE_ROW_LISTS": "1"}, make, steps),
+          _run_with_env(pkg, {**env, "DHMC_DENSE_ROW_LISTS": "0"}, make, steps))
