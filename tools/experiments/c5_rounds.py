@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 import torch
 pkg = load_package()
-N, D, C = 100000, 256, 1024
+N, D, C = 100000, 256, int(os.environ.get("C5_C", 1024))
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(0)
 X = rng.normal(size=(N, D)) / 16
