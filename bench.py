@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0x23EF614D)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -272,8 +273,10 @@ def main():
         # with host tensors; the per-rank HIP path, the sharding and the reductions are the ones of the 8-GPU run.
         dist.init_process_group("gloo")
         props = torch.cuda.get_device_properties(local_rank)
-        ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) or f"{props.name}#{local_rank}"
-        ident += "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "") + "|" + os.environ.get("HIP_VISIBLE_DEVICES", "")
+        ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) or props.name
+        # (the device index and the visibility masks are part of the identity: eight ranks on eight indices, or on one
+        # visible device each, are eight GPUs whatever the uuid field holds)
+        ident += f"|dev{local_rank}|" + os.environ.get("ROCR_VISIBLE_DEVICES", "") + "|" + os.environ.get("HIP_VISIBLE_DEVICES", "")
         idents = [None] * world
         dist.all_gather_object(idents, ident)
         if len(set(idents)) < world:
@@ -304,7 +307,10 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(group=pg)
+            if backend == "nccl":
+                dist.barrier(group=pg, device_ids=[local_rank])
+            else:
+                dist.barrier(group=pg)
             torch.cuda.synchronize()
 
     for _ in range(Wn):
