@@ -168,7 +168,7 @@ def bench_config3(args, pkg, torch):
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "1000-dim correlated MVN (rho=0.5, sigma log-spaced 0.1..10), dense M^-1 = Sigma shared, "
-                               "4096 chains (BASELINE.json configs[2])", "transitions_per_step": T},
+                               f"{C} chains (BASELINE.json configs[2])", "transitions_per_step": T, "chains_per_gpu": C},
         "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
                  "mean_acceptance": float(out["acceptance_rate"].mean()),
                  "scaled_draw_var": float((q / torch.tensor(sig, device="cuda")).var())},
@@ -192,7 +192,7 @@ def bench_config45(args, pkg, torch):
             ctx.run_into(n, {"draws": d}, da={})
             if metric:
                 ctx.update_metric_diag(d)
-        name = "Neal's funnel D=30, diagonal metric, 4096 chains = one GPU's share of 32768 (BASELINE.json configs[3])"
+        name = f"Neal's funnel D=30, diagonal metric, {C} chains" + (" = one GPU's share of 32768" if C == 4096 else " (all of them on this GPU)" if C == 32768 else "") + " (BASELINE.json configs[3])"
         flops_per_leapfrog = None
     else:
         N, D, C = 100000, 256, 1024 if args.chains == CHAINS_PER_GPU else args.chains
@@ -204,7 +204,7 @@ def bench_config45(args, pkg, torch):
         ctx.init(); ctx.set_stepsize(0.02)
         d = torch.empty((C, 20, D), dtype=torch.float64, device="cuda")
         ctx.run_into(20, {"draws": d}, da={}); ctx.update_metric_diag(d); ctx.run_into(15, {}, da={})
-        name = "logistic regression N=1e5 p=256, diagonal metric, 1024 chains = one GPU's share of 8192 (BASELINE.json configs[4])"
+        name = f"logistic regression N=1e5 p=256, diagonal metric, {C} chains" + (" = one GPU's share of 8192" if C == 1024 else " (all of them on this GPU)" if C == 8192 else "") + " (BASELINE.json configs[4])"
         flops_per_leapfrog = 4.0 * 100032 * 256      # two GEMM passes over X per gradient
     out = {"steps": torch.empty((C, T), dtype=torch.int64, device="cuda"), "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
            "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
@@ -235,6 +235,23 @@ def bench_config45(args, pkg, torch):
         "roofline": roof}))
 
 
+def spawn_ranks(n):
+    """Re-run this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port); the ranks' stdout/stderr are inherited, the return code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (default, diagonal metric), 3 (dense metric), 4 / 5 (one GPU's share of the funnel / logistic configs)")
@@ -250,6 +267,10 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one per GPU, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` form does; rank 0 prints the one JSON line
+        return spawn_ranks(args.gpus)
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -357,7 +378,7 @@ def main():
         per_launch = leapfrogs / K
         achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
         valu_ach = per_launch * ALGO_FLOPS_PER_LEAPFROG / (k_ms * 1e-3) / 1e12
-        kernel_name = "nuts_run_mw_kernel<StdNormalT,4> (DHMC_MW=1)" if os.environ.get("DHMC_MW") == "1" else "nuts_run_kernel<StdNormalT,16,true>"
+        kernel_name = "nuts_run_kernel<StdNormalT,16,true>"
         tpl, tsrc = measured_traffic_per_leapfrog()
         line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",
@@ -367,7 +388,7 @@ def main():
             "ms_per_step": 1e3 * t_max / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "1000-dim standard MVN, per-chain diagonal mass matrix, 4096 chains per MI355X "
+            "config": {"workload": f"1000-dim standard MVN, per-chain diagonal mass matrix, {C} chains per MI355X "
                                    "(BASELINE.json configs[1])",
                        "dim": D, "chains_per_gpu": C, "transitions_per_step": T,
                        "phase": "sampling (fixed adapted eps and M^-1 per chain)", "max_depth": 10,

@@ -40,7 +40,6 @@ struct dhmc_ctx {
     unsigned long long last_leapfrogs = 0;
     int l1_in_lds = 1;
     int k3_block = 1;
-    int mw = 0;                // DHMC_MW=1: the multi-wave per-chain kernel for 512+ coordinates (nuts_mw_kernel.hpp; slower, kept as the measured alternative)
     DenseMetric dm{};          // DHMC_METRIC_DENSE only
     double* d_Minv = nullptr;
     double* d_WT = nullptr;
@@ -340,7 +339,6 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
-    if (const char* e = std::getenv("DHMC_MW")) c->mw = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
@@ -545,7 +543,8 @@ int dhmc_set_stream(dhmc_ctx* c, void* s) {
 int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     if (!c) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    c->poisoned = false;
+    // (the poisoned mark is lifted only once the new (q, ℓq, ∇ℓ) are complete; a failure after the positions were
+    // overwritten sets it)
     Staged s;
     if (q0) {
         int rc = stage_in(c, q0, sizeof(double) * (size_t)c->cfg.chains * c->cfg.dim, q0_on_device, &s);
@@ -556,6 +555,7 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     if (c->external) { DHMC_EXT_NPL(external_init_positions_kernel, dim3(c->cfg.chains), P) }
     else rc = dispatch(c, Op::Init, &P);
     if (rc) { stage_free(c, &s); return rc; }
+    c->poisoned = true;    // st.q is being overwritten: inconsistent with ℓq, ∇ℓ until the evaluation below has succeeded
     HIP_TRY(c, hipGetLastError());
     stage_free(c, &s);
     if (c->external) {     // the positions are set; ℓ and ∇ℓ come from the callback, then evaluate_ℓ(strict) (mcmc.jl:131)
@@ -563,6 +563,7 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
         DHMC_EXT_NPL(external_init_finish_kernel, dim3(c->cfg.chains), c->cfg.dim, c->Dpad, c->st, c->lr.S1, c->rb.tbuf)
         HIP_TRY(c, hipGetLastError());
     }
+    c->poisoned = false;
     return status_code(c);
 }
 
@@ -580,12 +581,10 @@ int dhmc_set_position(dhmc_ctx* c, const double* q, int on_device) {
         HIP_TRY(c, hipMalloc(&k.copy.p, k.bytes));
         HIP_TRY(c, hipMemcpyAsync(k.copy.p, k.live, k.bytes, hipMemcpyDeviceToDevice, c->stream));
     }
-    const bool was_poisoned = c->poisoned;
-    const int rc = dhmc_init(c, q, on_device);
+    const int rc = dhmc_init(c, q, on_device);    // (a failed evaluation leaves the context poisoned, as in dhmc_init)
     for (auto& k : keep)
         if (k.live) HIP_TRY(c, hipMemcpyAsync(k.live, k.copy.p, k.bytes, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    (void)was_poisoned;
     return rc;
 }
 
@@ -799,7 +798,6 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
     P.l1_in_lds = c->l1_in_lds;
     P.k3_block = c->k3_block;
-    P.mw = c->mw;
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;
@@ -1353,13 +1351,15 @@ int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
 int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
     uint64_t need;
     if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
-    c->poisoned = false;
     BlobHeader h;
     std::memcpy(&h, host_blob, sizeof(h));
     if (h.magic != BLOB_MAGIC || h.dim != c->cfg.dim || h.chains != c->cfg.chains || h.Dpad != c->Dpad) return DHMC_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return blob_io(c, const_cast<char*>((const char*)host_blob), false);
+    c->poisoned = true;    // a partially copied blob is no state
+    const int rc = blob_io(c, const_cast<char*>((const char*)host_blob), false);
+    if (rc == DHMC_OK) c->poisoned = false;
+    return rc;
 }
 
 double dhmc_last_run_kernel_ms(const dhmc_ctx* c) { return c ? c->last_ms : 0.0; }

@@ -6,7 +6,6 @@
 #include "dense_rounds.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
-#include "mw_launch.hpp"
 #include "probe_kernels.hpp"
 
 namespace dhmc {

@@ -15,13 +15,6 @@ void launch_run(const RunParams& P, hipStream_t s) {
         return true;
     }();
     (void)once;
-    // chains of 512+ coordinates of a coordinate-wise target: one wave per 256-coordinate block + a control wave
-    if constexpr (T::kElementwise && (NPL == 8 || NPL == 16)) {
-        if (P.mw) {
-            launch_run_mw<T, NPL / 4>(P, s);
-            return;
-        }
-    }
     if (P.l1_in_lds)
         hipLaunchKernelGGL((nuts_run_kernel<T, NPL, true>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, true, lds_extra_levels(NPL), T::kElementwise), s, P);
     else

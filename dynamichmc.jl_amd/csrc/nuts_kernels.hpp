@@ -70,7 +70,6 @@ struct ChainArrays {
 struct RunParams {
     int D, Dpad, C, chain_offset, max_depth, nvec;
     int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
-    int mw;                      // diagonal metric, 512+ coordinates, coordinate-wise target: a workgroup per chain (nuts_mw_kernel.hpp)
     int k3_block;                // round engines: K3 as a workgroup per chain (dense_rounds_k3b.hpp) where it applies
     double min_delta;
     uint64_t seed;
@@ -292,6 +291,10 @@ __device__ unsigned long long g_phase[16];
 #define PH_DECL unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t0 = __builtin_readcyclecounter(); int ph_cur = 0;
 #define PH(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[ph_cur] += t_ - ph_t0; ph_t0 = t_; ph_cur = (i); }
 #define PH_FLUSH { PH(0); if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); atomicAdd(&g_phase[15], 1ull); } }
+#elif defined(DHMC_PHASE_MARK)   // tools/isa_regions.py: the region boundaries as comments in the assembly (static instruction counts per region)
+#define PH_DECL
+#define PH(i) asm volatile("; DHMC_PH " #i);
+#define PH_FLUSH asm volatile("; DHMC_PH 9");
 #else
 #define PH_DECL
 #define PH(i)

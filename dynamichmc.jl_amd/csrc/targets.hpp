@@ -11,7 +11,7 @@
 //                                calls finish()), or ℓ itself (kDeferred = false).
 //   kElementwise                 element e of ∇ℓ and of the summand of ℓ depend on q_e alone (and eval takes any element base
 //                                as its `lane` argument): such targets can be cut into 256-coordinate blocks, one wave
-//                                each (nuts_mw_kernel.hpp).
+//                                each (dense_rounds_k3b.hpp; the multi-wave per-draw kernels of tools/experiments/mw and /w2).
 //   kRecomputeGrad               ∇ℓ is cheap enough that a stored proposal keeps only q and the
 //                                gradient is re-evaluated when the proposal becomes the chain's position.
 //   kPointwiseGrad               element e of ∇ℓ is a function of q_e alone at no memory cost (grad1): the kernels then

@@ -85,7 +85,7 @@ __device__ __forceinline__ bool wave_all(bool pred) { return __ballot(pred) == ~
 // 256 coordinates (4 slots per lane); inside a block lane l accumulates its slots k ascending with fma; the blocks'
 // partial sums are then combined PER LANE by an adjacent-pairs binary tree, and the 64 lane values by the xor
 // butterfly (wave_allreduce).  One block (D <= 256) is the plain fma chain.  The block structure is what lets a
-// chain of 512+ coordinates be spread over several waves (one block per wave: nuts_mw_kernel.hpp,
+// chain of 512+ coordinates be spread over several waves (one block per wave: tools/experiments/mw/nuts_mw_kernel.hpp,
 // dense_rounds_k3b.hpp) without serialising the chain across them; a single wave holding the whole row keeps one
 // accumulator per block instead (more independent fma chains, same bits).
 template <int N, int NPL>

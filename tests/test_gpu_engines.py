@@ -98,42 +98,8 @@ def test_block_per_chain_k3_equals_wave_per_chain_k3(pkg, D):
     _same(_run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "1"}, make, steps), _run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "0"}, make, steps))
 
 
-@pytest.mark.parametrize("D,target", [(512, "std"), (600, "diag"), (1000, "std"), (1000, "diag"), (1024, "std")])
-def test_multiwave_kernel_equals_one_wave_kernel(pkg, D, target):
-    """Chains of 512+ coordinates of a coordinate-wise target run as a workgroup per chain (one vector wave per
-    256-coordinate block + a control wave, nuts_mw_kernel.hpp); DHMC_MW=0 keeps the one-wave-per-chain kernel.  Same
-    bits through a warmup with adaptation and a metric update, trees cut at max_depth, and step sizes so large that
-    leaves diverge and positions overflow (evaluate_ℓ's position scan, hamiltonian.jl:203)."""
-    rng = np.random.default_rng(D)
-    if target == "diag":
-        tgt = ol.TARGET_DIAG_NORMAL
-        params = ol.target_params_blob(tgt, D, mu=rng.normal(size=D), prec=1 / (rng.normal(size=D) ** 2 + 0.1))
-    else:
-        tgt, params = ol.TARGET_STD_NORMAL, None
-
-    def steps(ctx):
-        out = {}
-        ctx.init(); ctx.find_initial_stepsize()
-        a = ctx.run(20, da={})
-        ctx.update_metric_diag(a["draws"])
-        out.update({"w_" + k: v for k, v in a.items()})
-        out.update({"i_" + k: v for k, v in ctx.run(10).items()})
-        ctx.set_stepsize(4.0)                       # most leaves diverge
-        out.update({"d_" + k: v for k, v in ctx.run(6).items()})
-        ctx.set_stepsize(1e-3)                      # every tree is cut at max_depth
-        out.update({"m_" + k: v for k, v in ctx.run(3).items()})
-        q, lq, g = ctx.position()
-        out.update(q=q, lq=lq, g=g)
-        return out
-    make = lambda: pkg.DeviceContext(D, 7, target=tgt, target_params=params, seed=21, max_depth=6)
-    a = _run_with_env(pkg, {"DHMC_MW": "1"}, make, steps)
-    b = _run_with_env(pkg, {"DHMC_MW": "0"}, make, steps)
-    _same(a, b)
-    assert (a["d_steps"] < 2 ** 6 - 1).any() and (a["m_depth"] == 6).all()
-
-
-def test_multiwave_kernel_position_overflow_matches_oracle(pkg):
-    """ϵ so large that q′ overflows: ℓq is non-finite, the vector waves scan the position (hamiltonian.jl:203), the
+def test_position_overflow_matches_oracle(pkg):
+    """ϵ so large that q′ overflows: ℓq is non-finite, the kernel scans the position (hamiltonian.jl:203), the
     chain's status word records it, the leaf is divergent — against the oracle."""
     D, C = 1000, 3
     dev = pkg.DeviceContext(D, C, seed=8); ora = ol.Oracle(D, C, seed=8, threads=4)
