@@ -158,7 +158,8 @@ def bench_config3(args, pkg, torch):
         lf += ctx.last_run_leapfrogs(); rounds += ctx.last_run_rounds(); kms.append(ctx.last_run_kernel_ms())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    flops = rounds * 2 * 2.0 * C * 1024 * 1024           # two [C×1024]·[1024×1024] contractions per round
+    nprod = ctx.dense_products()                          # 1: u′ = ∇ℓq′·M⁻¹ only (default); 2: the reference's M⁻¹pₘ and M⁻¹p′
+    flops = rounds * nprod * 2.0 * C * 1024 * 1024        # [C×1024]·[1024×1024] contractions per round
     peak = 78.6                                           # MI355X fp64 matrix peak, TFLOP/s
     ach = flops / (sum(kms) * 1e-3) / 1e12
     q = out["draws"]
@@ -168,14 +169,17 @@ def bench_config3(args, pkg, torch):
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "1000-dim correlated MVN (rho=0.5, sigma log-spaced 0.1..10), dense M^-1 = Sigma shared, "
-                               f"{C} chains (BASELINE.json configs[2])", "transitions_per_step": T, "chains_per_gpu": C},
+                               f"{C} chains (BASELINE.json configs[2])", "transitions_per_step": T, "chains_per_gpu": C,
+                   "dense_products_per_leapfrog": nprod},
         "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
                  "mean_acceptance": float(out["acceptance_rate"].mean()),
                  "scaled_draw_var": float((q / torch.tensor(sig, device="cuda")).var())},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                      "kernel": "gemm_rows_f64_kernel (v_mfma_f64_16x16x4_f64), share of whole round time",
-                     "note": "flops of the two M^-1 contractions per leapfrog round / total kernel time of the rounds "
-                             "(tree-logic kernels included); the GEMM launches alone reach ~53 TFLOP/s (profiles/)",
+                     "algorithmic_flops_per_leapfrog": nprod * 2.0 * 1024 * 1024,
+                     "note": f"flops of the {nprod} M^-1 contraction(s) per leapfrog round (2·Dpad² each; one-product recurrence: "
+                             "include/dhmc.h dhmc_set_dense_products) / total kernel time of the rounds "
+                             "(tree-logic kernels included); the GEMM launches alone reach ~50 TFLOP/s (profiles/)",
                      "rounds": rounds}}))
 
 

@@ -145,6 +145,13 @@ class DeviceContext:
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(abi.lib().dhmc_set_metric_dense(self.h, _ptr(minv), 0), "dhmc_set_metric_dense")
 
+    def set_dense_products(self, products):
+        """1: one M⁻¹ product per leapfrog (the default of a shared dense metric); 2: the reference's two (include/dhmc.h)."""
+        self._chk(abi.lib().dhmc_set_dense_products(self.h, int(products)), "dhmc_set_dense_products")
+
+    def dense_products(self):
+        return int(abi.lib().dhmc_get_dense_products(self.h))
+
     def metric_dense(self, chain=0):
         """(M⁻¹, W) of the shared dense metric, or of `chain` in a dense_per_chain context."""
         m = np.zeros((self.D, self.D)); W = np.zeros((self.D, self.D))

@@ -15,6 +15,19 @@
 //                   bookkeeping, end of transition (draw, statistics, dual averaging), and the half step
 //                   that opens the chain's next leapfrog.
 //
+// That is the reference's recurrence: two products per leapfrog (RunParams::one_product = 0).  Both are products of
+// vectors that differ by a multiple of ∇ℓ: M⁻¹pₘ = M⁻¹p + (ϵ/2)·M⁻¹∇ℓq and M⁻¹p′ = M⁻¹pₘ + (ϵ/2)·M⁻¹∇ℓq′.  With
+// one_product = 1 (the default of a shared dense metric, include/dhmc.h dhmc_set_dense_products) a chain carries
+// u = M⁻¹∇ℓq next to p♯ = M⁻¹p, and a round is
+//
+//     [G0,G0b,G0c,K0]  chains that begin a transition: p, p♯ as above and u = ∇ℓq·M⁻¹, all three fresh products
+//      K2              T = p♯ + (ϵ/2)u;  q′ = q + ϵT, ℓ(q′), ∇ℓ(q′), p′ = pₘ + ϵ/2 ∇ℓ
+//      G               U′ = ∇ℓ(Q′) · M⁻¹   for all chains — the round's ONE product (2·D² flops per leapfrog)
+//      K3              p♯′ = T + (ϵ/2)u′, then as above
+//
+// i.e. the same map with a different rounding (the oracle restates it: oracle/hamiltonian.hpp leapfrog; the deviation
+// from the two-product recurrence is bounded in tests/test_gpu_tolerance.py).
+//
 // A chain never waits for another: whatever transition and tree position it is in, its next leapfrog
 // happens in the next round.  The tree logic is the same iterative adjacent_tree as in
 // nuts_kernels.hpp, made resumable: every loop variable lives in a per-chain TreeState in HBM.
@@ -50,6 +63,7 @@ struct RoundBuffers {
     int* list;      // [C] chains that begin a transition this round
     int* list_count;
     int* done_count;
+    double* cu;     // [C][Dpad]  u = M⁻¹∇ℓq of the point being integrated (one_product: GEMM output)
 };
 // the point's q and ∇ℓ live in ChainArrays::q / ::g (the chain's position between transitions)
 
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
         wsv(wd_top(0))[e] = pk; wsv(wd_top(1))[e] = psk;              // leaf τ of z₀ (NUTS.jl:120-123)
         wsv(wd_top(2))[e] = pk; wsv(wd_top(3))[e] = psk;
         wsv(wd_top(4))[e] = pk;
+        if (P.one_product) wsv(wd_u0(P.max_depth))[e] = R.cu[row + e];   // u of the initial point: the anchor of either edge
     }
     const double lq_cur = S.lq_cur;
     const double pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
@@ -186,7 +201,14 @@ __global__ __launch_bounds__(64) void rounds_k2_kernel(RunParams P, RoundBuffers
     double q[NPL], p[NPL], g[NPL], t[NPL];
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(R.cp + row, lane, p);
-    ldv<NPL>(R.tbuf + row, lane, t);
+    if (P.one_product) {                             // M⁻¹pₘ = p♯ + (ϵ/2)·u, kept for K3 (p♯′ = M⁻¹pₘ + (ϵ/2)·u′)
+        ldv<NPL>(R.cps + row, lane, t);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) t[k] = t[k] + h * R.cu[row + lane + WAVE * k];
+        stv<NPL>(R.tbuf + row, lane, t);
+    } else {
+        ldv<NPL>(R.tbuf + row, lane, t);
+    }
 #pragma unroll
     for (int k = 0; k < NPL; ++k) q[k] = q[k] + eps_s * t[k];
     const double lres = tgt.eval(q, g, lane, P.D);
@@ -232,7 +254,14 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     // so that the kernel fits two waves per SIMD without scratch.
     double p[NPL], ps[NPL], cf[NPL], cfs[NPL], cr[NPL];
     ldv<NPL>(R.cp + row, lane, p);
-    ldv<NPL>(R.cps + row, lane, ps);
+    if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (K2 left M⁻¹pₘ in tbuf, the product left u′ in cu)
+        const double h = S.eps_s / 2;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) ps[k] = R.tbuf[row + lane + WAVE * k] + h * R.cu[row + lane + WAVE * k];
+        stv<NPL>(R.cps + row, lane, ps);
+    } else {
+        ldv<NPL>(R.cps + row, lane, ps);
+    }
     auto copy_row = [&](const double* __restrict__ src, double* __restrict__ dst) {
 #pragma unroll
         for (int k0 = 0; k0 < NPL; k0 += 4) {
@@ -475,6 +504,11 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
                     copy_row(wsv(gsrc), P.st.g + row);
                 }
                 ldv<NPL>(wsv(wd_top(nfwd ? 2 : 0)), lane, p);
+                if (P.one_product) {                 // the edge's p♯ and u travel with it
+                    copy_row(R.cu + row, wsv(wd_edge_u(max_depth, S.reg_edge)));
+                    copy_row(wsv(have ? wd_edge_u(max_depth, ndir) : wd_u0(max_depth)), R.cu + row);
+                    copy_row(wsv(wd_top(nfwd ? 3 : 1)), R.cps + row);
+                }
             }
             S.reg_edge = ndir;
             S.dir = ndir;

@@ -100,7 +100,16 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
 
     double p[NT], ps[NT], cf[NT], cfs[NT], cr[NT];
     ldv<NT>(cp_row, lane, p);
-    ldv<NT>(R.cps + row + off, lane, ps);
+    double* const cps_row = R.cps + row + off;
+    double* const cu_row = R.cu + row + off;
+    if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (dense_rounds.hpp)
+        const double h = eps_s / 2;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) ps[k] = R.tbuf[row + off + lane + WAVE * k] + h * cu_row[lane + WAVE * k];
+        stv<NT>(cps_row, lane, ps);
+    } else {
+        ldv<NT>(cps_row, lane, ps);
+    }
 
     auto randexp = [&]() -> double {   // Random.randexp at NUTS.jl:44: the nrand-th draw of this transition
         uint64_t r1, r2;
@@ -391,6 +400,11 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 copy_row(wsv(qsrc), q_row);
                 copy_row(wsv(gsrc), g_row);
                 ldv<NT>(wsv(wd_top(nfwd ? 2 : 0)), lane, p);
+                if (P.one_product) {                 // the edge's p♯ and u travel with it
+                    copy_row(cu_row, wsv(wd_edge_u(max_depth, reg_edge)));
+                    copy_row(wsv(have ? wd_edge_u(max_depth, ndir) : wd_u0(max_depth)), cu_row);
+                    copy_row(wsv(wd_top(nfwd ? 3 : 1)), cps_row);
+                }
             }
             reg_edge = ndir;
             dir = ndir;

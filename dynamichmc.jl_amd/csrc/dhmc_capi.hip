@@ -55,6 +55,7 @@ struct dhmc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_joins[4] = {};
     int dense_rounds = 1;
+    int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (round engine only)
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
@@ -386,6 +387,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         c->dm = DenseMetric{c->d_Minv, c->d_WT, c->per_chain_dense ? Dp * Dp : (size_t)0};
         if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
         if (c->per_chain_dense) c->dense_rounds = 0;   // the GEMM engine shares one M⁻¹ across the rows of a product
+        c->dense_products = (c->per_chain_dense || c->external) ? 2 : 1;
+        if (const char* e = std::getenv("DHMC_DENSE_PRODUCTS")) { const int v = std::atoi(e); if (v == 2 || (v == 1 && c->dense_products == 1)) c->dense_products = v; }
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
@@ -394,6 +397,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if ((rc = dev_alloc(c, &c->rb.cp, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.cps, C * Dp))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.tbuf, C * Dp))) return fail(rc);
+        if (cfg->metric == DHMC_METRIC_DENSE) {
+            if ((rc = dev_alloc(c, &c->rb.cu, C * Dp))) return fail(rc);
+            if (hipMemset(c->rb.cu, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
+        }
         if ((rc = dev_alloc(c, &c->rb.ts, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->rb.list_count, 8))) return fail(rc);
@@ -645,6 +652,14 @@ int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
     stage_free(c, &s);
     return rc;
 }
+
+int dhmc_set_dense_products(dhmc_ctx* c, int32_t products) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || (products != 1 && products != 2)) return DHMC_ERR_INVALID_ARGUMENT;
+    if (products == 1 && (c->per_chain_dense || c->external)) return DHMC_ERR_UNSUPPORTED;
+    c->dense_products = products;
+    return DHMC_OK;
+}
+int dhmc_get_dense_products(const dhmc_ctx* c) { return (c && c->cfg.metric == DHMC_METRIC_DENSE) ? c->dense_products : 0; }
 
 int dhmc_get_metric_dense_chain(dhmc_ctx* c, int32_t chain, double* minv, double* W) {
     if (!c || c->cfg.metric != DHMC_METRIC_DENSE || chain < 0 || chain >= c->cfg.chains) return DHMC_ERR_INVALID_ARGUMENT;
@@ -911,7 +926,10 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
         c->last_rounds = rounds;
-    } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
+    } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && (c->dense_rounds || c->dense_products == 1)) {
+        // (the one-product recurrence exists in this engine only, so it is the engine of every chain count then: results
+        // must not depend on how many chains a context holds)
+        P.one_product = c->dense_products == 1;
         // Round-based dense engine (dense_rounds.hpp): every round is one leapfrog for every chain.  The chains
         // run as two half-batches on two streams so that one half's HBM-bound tree kernel overlaps the other
         // half's MFMA-bound contractions.
@@ -957,9 +975,21 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                     hipStream_t s = H[h].s;
                     launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, H[h].count, R.list, R.list_count, s);               // p₀ = z·Wᵀ
                     launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, H[h].count, R.list, R.list_count, s);            // p♯₀
+                    if (P.one_product) launch_gemm_rows(c->st.g, c->d_Minv, R.cu, ld, H[h].count, R.list, R.list_count, s);   // u₀ = ∇ℓq₀·M⁻¹
                     if (int r = dispatch(c, Op::RoundK0, &H[h].ra, s, true)) return r;
                     e = hipMemsetAsync(R.list_count, 0, sizeof(int), s);
-                    if (!row_lists) {
+                    if (P.one_product && !row_lists) {
+                        if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;                          // M⁻¹pₘ = p♯ + (ϵ/2)u
+                        launch_gemm_rows(c->st.g + off, c->d_Minv, R.cu + off, ld, H[h].count, nullptr, nullptr, s); // u′ = ∇ℓq′·M⁻¹
+                    } else if (P.one_product) {
+                        LogisticRound L = c->lr;
+                        L.act = c->lr.act + H[h].base;
+                        L.act_count = c->lr.act + C + h;
+                        if (e == hipSuccess) e = hipMemsetAsync(L.act_count, 0, sizeof(int), s);
+                        hipLaunchKernelGGL(rounds_active_list_kernel, dim3((H[h].count + 255) / 256), dim3(256), 0, s, H[h].ra.P, R, L);
+                        if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;
+                        launch_gemm_rows(c->st.g, c->d_Minv, R.cu, ld, H[h].count, L.act, L.act_count, s);          // u′
+                    } else if (!row_lists) {
                         launch_gemm_rows(R.cp + off, c->d_Minv, R.tbuf + off, ld, H[h].count, nullptr, nullptr, s); // M⁻¹pₘ
                         if (int r = dispatch(c, Op::RoundK2, &H[h].ra, s, true)) return r;
                         launch_gemm_rows(R.cp + off, c->d_Minv, R.cps + off, ld, H[h].count, nullptr, nullptr, s);  // p♯

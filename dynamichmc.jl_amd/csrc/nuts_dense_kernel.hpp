@@ -28,7 +28,11 @@ __host__ __device__ inline int wd_top(int which) { return which; }              
 __host__ __device__ inline int wd_edge(int dir, int which) { return 5 + 2 * dir + which; }   // 0 q, 1 g
 __host__ __device__ inline int wd_stack(int level, int which) { return 9 + 5 * level + which; }  // first, first♯, last, last♯, ρ
 __host__ __device__ inline int wd_slot(int max_depth, int s, int which) { return 9 + 5 * max_depth + 2 * s + which; }
-__host__ __device__ inline int wd_nvec(int max_depth) { return 9 + 5 * max_depth + 2 * ws_nslots(max_depth); }
+__host__ __device__ inline int wd_nvec_base(int max_depth) { return 9 + 5 * max_depth + 2 * ws_nslots(max_depth); }
+// the one-product recurrence of the round engine (dense_rounds.hpp) carries u = M⁻¹∇ℓq next to q and ∇ℓq:
+__host__ __device__ inline int wd_u0(int max_depth) { return wd_nvec_base(max_depth); }                     // u of the transition's initial point
+__host__ __device__ inline int wd_edge_u(int max_depth, int dir) { return wd_nvec_base(max_depth) + 1 + dir; }   // u of a parked edge
+__host__ __device__ inline int wd_nvec(int max_depth) { return wd_nvec_base(max_depth) + 3; }
 __host__ __device__ inline size_t lds_bytes_dense() {
     return sizeof(double) * (3 * LDS_LEVELS + 2 * LDS_SLOTS) + sizeof(int) * LDS_LEVELS;
 }

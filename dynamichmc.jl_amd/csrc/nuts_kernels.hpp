@@ -71,6 +71,7 @@ struct RunParams {
     int D, Dpad, C, chain_offset, max_depth, nvec;
     int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
     int k3_block;                // round engines: K3 as a workgroup per chain (dense_rounds_k3b.hpp) where it applies
+    int one_product;             // dense round engine: one M⁻¹ product per leapfrog (dense_rounds.hpp; include/dhmc.h dhmc_set_dense_products)
     double min_delta;
     uint64_t seed;
     int64_t N;

@@ -203,6 +203,19 @@ int dhmc_set_metric_dense(dhmc_ctx* ctx, const double* minv, int on_device);
  * dense_per_chain = 1 those of chain 0 — dhmc_get_metric_dense_chain returns any chain's. */
 int dhmc_get_metric_dense(dhmc_ctx* ctx, double* minv, double* W);
 int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, double* W);
+/* How many products M⁻¹·v a leapfrog with the SHARED dense metric takes.
+ *   2: the reference's recurrence as written — ∇kinetic_energy(κ, pₘ) (hamiltonian.jl:278) and p♯ = M⁻¹p′ of the new point
+ *      (hamiltonian.jl:103, NUTS.jl:121).  4·D² flops per leapfrog.
+ *   1: the same map with one product: a chain carries u = M⁻¹∇ℓq next to p♯ = M⁻¹p; M⁻¹pₘ = p♯ + (ϵ/2)u (no product),
+ *      u′ = M⁻¹∇ℓq′ (the product), p♯′ = M⁻¹pₘ + (ϵ/2)u′.  p♯ and u of a transition's initial point are fresh products, so
+ *      rounding does not accumulate across transitions.  2·D² flops per leapfrog.  Every elementwise step is a separate
+ *      multiply and add in the order written.  The DEFAULT of a shared dense metric (a stated deviation from the
+ *      reference's operation order, like the pooled adaptation: per-step energies agree to ≈1e-12, trees are the same —
+ *      tests/test_gpu_tolerance.py); then the GEMM round engine runs whatever the number of chains.
+ * dense_per_chain contexts and DHMC_TARGET_EXTERNAL always use 2 (asking for 1 there: DHMC_ERR_UNSUPPORTED).  May be
+ * changed between dhmc_run calls.  DHMC_DENSE_PRODUCTS=2 in the environment makes 2 the default. */
+int dhmc_set_dense_products(dhmc_ctx* ctx, int32_t products);
+int dhmc_get_dense_products(const dhmc_ctx* ctx);   /* 1 or 2; 0 for a context without a dense metric */
 /* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */
 int dhmc_set_stepsize(dhmc_ctx* ctx, const double* eps, int per_chain, int on_device);
 int dhmc_get_stepsize(dhmc_ctx* ctx, double* eps, int on_device); /* [C] */

@@ -53,7 +53,8 @@ struct GaussianKineticEnergy {
             for (int i = 0; i < D; ++i) {
                 double acc = 0.0;
                 const double* row = &Minv[(size_t)i * D];
-                for (int k = 0; k < D; ++k) acc = __builtin_fma(row[k], p[k], acc);
+                if (sequential_sums()) for (int k = 0; k < D; ++k) acc = acc + row[k] * p[k];
+                else for (int k = 0; k < D; ++k) acc = __builtin_fma(row[k], p[k], acc);
                 out[i] = acc;
             }
         }
@@ -77,6 +78,7 @@ struct PhasePoint {
     VecP p;
     VecP ps;   // M⁻¹ p
     double K = 0;  // kinetic_energy(κ, p)
+    VecP u;    // M⁻¹ ∇ℓq — carried only by the one-product recurrence of the dense metric (leapfrog below)
 };
 using Z = std::shared_ptr<const PhasePoint>;
 
@@ -85,6 +87,12 @@ struct Hamiltonian {
     const Target* target;
     MathOps M;
     uint32_t* status;  // where reference `throw`s are recorded for this chain
+    // Dense metric only.  false: the reference's recurrence, two products M⁻¹·v per leapfrog (M⁻¹pₘ :278, M⁻¹p′ :103/
+    // NUTS.jl:121).  true: ONE product per leapfrog, u′ = M⁻¹∇ℓ(q′), with M⁻¹pₘ = p♯ + (ϵ/2)u and p♯′ = M⁻¹pₘ + (ϵ/2)u′
+    // propagated by linearity from the p♯ = M⁻¹p and u = M⁻¹∇ℓ computed afresh at the start of every transition
+    // (include/dhmc.h dhmc_set_dense_products; the device round engine's default).  Mathematically the same map; the
+    // rounding differs (tests/test_gpu_tolerance.py bounds it).
+    bool one_product = false;
 };
 
 inline bool all_finite(const double* x, int n) {
@@ -128,6 +136,11 @@ inline Z make_phasepoint(const Hamiltonian& H, const EvaluatedLogDensity& Q, Vec
     H.kappa->p_sharp(p->data(), ps->data());
     z->K = H.kappa->kinetic_energy(p->data(), ps->data());
     z->ps = ps;
+    if (H.one_product && H.kappa->dense) {   // the anchor of the one-product recurrence: u = M⁻¹∇ℓq, a fresh product
+        auto u = std::make_shared<Vec>(H.kappa->D);
+        H.kappa->p_sharp(Q.g->data(), u->data());
+        z->u = u;
+    }
     return z;
 }
 
@@ -148,14 +161,33 @@ inline Z leapfrog(const Hamiltonian& H, const PhasePoint& z, double eps) {
     double h = eps / 2;                                  // ϵ/2 formed first (:277)
     Vec pm(D), t(D);
     for (int i = 0; i < D; ++i) pm[i] = p[i] + h * g[i];            // :277
-    H.kappa->p_sharp(pm.data(), t.data());                           // ∇kinetic_energy(κ, pₘ)
+    const bool one = H.one_product && H.kappa->dense && z.u;
+    if (one) {
+        const Vec& ps = *z.ps;
+        const Vec& u = *z.u;
+        for (int i = 0; i < D; ++i) t[i] = ps[i] + h * u[i];        // M⁻¹pₘ = M⁻¹p + (ϵ/2) M⁻¹∇ℓq, no product
+    } else {
+        H.kappa->p_sharp(pm.data(), t.data());                       // ∇kinetic_energy(κ, pₘ)
+    }
     auto q1 = std::make_shared<Vec>(D);
     for (int i = 0; i < D; ++i) (*q1)[i] = q[i] + eps * t[i];       // :278
     EvaluatedLogDensity Q1 = evaluate_l(H, q1, false);               // :279
     auto p1 = std::make_shared<Vec>(D);
     const Vec& g1 = *Q1.g;
     for (int i = 0; i < D; ++i) (*p1)[i] = pm[i] + h * g1[i];       // :280
-    return make_phasepoint(H, Q1, p1);                               // :281
+    if (!one) return make_phasepoint(H, Q1, p1);                     // :281
+    // the leapfrog's one product, then p♯′ = M⁻¹pₘ + (ϵ/2) u′
+    auto z1 = std::make_shared<PhasePoint>();
+    auto u1 = std::make_shared<Vec>(D);
+    H.kappa->p_sharp(g1.data(), u1->data());
+    auto ps1 = std::make_shared<Vec>(D);
+    for (int i = 0; i < D; ++i) (*ps1)[i] = t[i] + h * (*u1)[i];
+    z1->Q = Q1;
+    z1->p = p1;
+    z1->ps = ps1;
+    z1->u = u1;
+    z1->K = H.kappa->kinetic_energy(p1->data(), ps1->data());
+    return z1;
 }
 
 }  // namespace oracle

@@ -52,12 +52,26 @@ struct MathOps {
 // binary tree over the power-of-two number of blocks of the padded row (missing blocks are +0.0); the 64 lane
 // values are combined by the xor-butterfly 1,2,4,8,16,32 (adjacent pairs first).  For n <= 256 this is one fma chain
 // per lane followed by the butterfly.
+// A second flavour of every sum, for tolerance tests only (tests/test_gpu_tolerance.py): plain left-to-right accumulation
+// with separately rounded products and no blocks — the textbook loop, the order closest to what a generic
+// `LinearAlgebra.dot` / `*` does on the reference's side (src/hamiltonian.jl:103,110; src/NUTS.jl:130), whose BLAS order
+// is unpinned.  Process-wide switch (oracle_set_sequential_sums); the ABI's order is the default and the only one the
+// device implements.
+inline bool& sequential_sums() {
+    static bool on = false;
+    return on;
+}
 inline double wave_tree(double* partial) {
     for (int off = 1; off < 64; off <<= 1)
         for (int l = 0; l < 64; l += 2 * off) partial[l] = partial[l] + partial[l + off];
     return partial[0];
 }
 inline double wave_dot(const double* a, const double* b, int n) {
+    if (sequential_sums()) {
+        double s = 0.0;
+        for (int e = 0; e < n; ++e) s = s + a[e] * b[e];
+        return s;
+    }
     int nblk = 1;
     while (256 * nblk < n) nblk *= 2;
     std::vector<double> blk((size_t)nblk * 64, 0.0);

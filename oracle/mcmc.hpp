@@ -22,6 +22,7 @@ struct Chain {
     uint32_t transition = 0;  // number of transitions this chain has made (RNG counter)
     uint32_t status = 0;
     ChainStream stream;
+    bool dense_one_product = false;   // Hamiltonian::one_product for this chain's transitions (not for the search / probes)
 };
 
 // src/mcmc.jl:108  random_position(rng, N) = rand(rng, N) .* 4 .- 2
@@ -92,7 +93,7 @@ inline void run_transitions(Chain& c, const Target& target, const MathOps& M, co
                             int64_t N, const DualAveraging* da, bool da_init, bool da_finalize,
                             const DrawSink& out) {
     int D = target.D;
-    Hamiltonian H{&c.kappa, &target, M, &c.status};
+    Hamiltonian H{&c.kappa, &target, M, &c.status, c.dense_one_product};
     if (da && da_init) c.da = initial_adaptation_state(M, c.eps);  // mcmc.jl:266
     for (int64_t i = 0; i < N; ++i) {
         double eps = da ? current_eps(M, c.da) : c.eps;  // :272

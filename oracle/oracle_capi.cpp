@@ -87,6 +87,14 @@ int oracle_create(const dhmc_config* cfg, int det_math, oracle_ctx** out) {
 }
 int oracle_destroy(oracle_ctx* c) { delete c; return DHMC_OK; }
 int oracle_set_threads(oracle_ctx* c, int n) { c->threads = n < 1 ? 1 : n; return DHMC_OK; }
+// every sum of the oracle left to right instead of in the ABI's order (mathops.hpp sequential_sums): process-wide
+int oracle_set_sequential_sums(int on) { sequential_sums() = on != 0; return DHMC_OK; }
+// dhmc_set_dense_products: 2 = the reference's recurrence (two M⁻¹ products per leapfrog), 1 = one product (hamiltonian.hpp)
+int oracle_set_dense_products(oracle_ctx* c, int n) {
+    if (!c || (n != 1 && n != 2) || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
+    for (auto& ch : c->chains) ch.dense_one_product = (n == 1);
+    return DHMC_OK;
+}
 
 static int any_failure(oracle_ctx* c) {
     for (auto& ch : c->chains) if (ch.status) return DHMC_ERR_CHAIN_FAILURE;

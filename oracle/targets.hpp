@@ -118,6 +118,26 @@ struct Logistic : Target {
     Logistic(int d, int64_t n, const double* x, const double* yy) : N(n), X(x, x + n * d), y(yy, yy + n) { D = d; }
     void eval(const MathOps& M, const double* q, double& lq, double* g) const override {
         std::vector<double> r(N);
+        if (sequential_sums()) {    // tolerance-test flavour (mathops.hpp): one left-to-right pass, no blocks, no fma
+            double S1 = 0.0;
+            for (int64_t n = 0; n < N; ++n) {
+                const double* xn = &X[(size_t)n * D];
+                double eta = 0.0;
+                for (int d = 0; d < D; ++d) eta = eta + xn[d] * q[d];
+                double t = M.exp(-std::fabs(eta));
+                double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+                double l1pe = (eta > 0 ? eta : 0.0) + (M.det ? dhmc::det_log1p_nonneg(t) : std::log1p(t));
+                r[n] = y[n] - sig;
+                S1 = S1 + (y[n] * eta - l1pe);
+            }
+            lq = S1 - 0.5 * wave_dot(q, q, D);
+            for (int d = 0; d < D; ++d) {
+                double acc = 0.0;
+                for (int64_t n = 0; n < N; ++n) acc = acc + X[(size_t)n * D + d] * r[n];
+                g[d] = acc - q[d];
+            }
+            return;
+        }
         double partial[64];
         double S1 = 0.0;
         for (int l = 0; l < 64; ++l) partial[l] = 0.0;

@@ -28,9 +28,12 @@ CASES = {
     "funnel_d30": (30, 6, ol.TARGET_FUNNEL, {}, 4, 10, [(40, True, False), (25, True, True), (25, False, False)]),
     "shallow_d20_maxdepth3": (20, 3, ol.TARGET_STD_NORMAL, {}, 9, 3, [(20, True, False), (10, False, False)]),
     "logistic_n150_d6": (6, 3, ol.TARGET_LOGISTIC, "logistic", 21, 10, [(25, True, True), (15, False, False)]),
-    # dense metric: correlated normal (tridiagonal precision, rho = 0.5) with the perfect metric M⁻¹ = Σ
+    # dense metric: correlated normal (tridiagonal precision, rho = 0.5) with the perfect metric M⁻¹ = Σ — the reference's
+    # recurrence (two M⁻¹ products per leapfrog; the fixture of rounds 1-2) and the one-product recurrence (round 3)
     "dense_tridiag_d12": (12, 3, ol.TARGET_TRIDIAG_NORMAL, dict(diag=np.r_[4 / 3.0, np.full(10, 5 / 3.0), 4 / 3.0], off=np.full(12, -2 / 3.0)),
-                          13, 10, [(25, True, False), (15, False, False)], "dense"),
+                          13, 10, [(25, True, False), (15, False, False)], "dense2"),
+    "dense_tridiag_d12_one_product": (12, 3, ol.TARGET_TRIDIAG_NORMAL, dict(diag=np.r_[4 / 3.0, np.full(10, 5 / 3.0), 4 / 3.0], off=np.full(12, -2 / 3.0)),
+                                      13, 10, [(25, True, False), (15, False, False)], "dense1"),
 }
 
 
@@ -51,6 +54,7 @@ def run_case(engine_factory, spec):
     out = {}
     if dense:
         P = np.diag(tkw["diag"]) + np.diag(tkw["off"][:D - 1], 1) + np.diag(tkw["off"][:D - 1], -1)
+        eng.set_dense_products(int(spec[7][-1]))
         eng.set_metric_dense(np.linalg.inv(P))
     eng.init()
     q, lq, g = eng.position()

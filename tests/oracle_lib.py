@@ -144,6 +144,12 @@ def outputs_struct(arrs, on_device=0):
     return o
 
 
+def set_sequential_sums(on):
+    """Process-wide: every sum of the oracle as a plain left-to-right loop instead of the ABI's order (oracle/mathops.hpp
+    sequential_sums) — the second flavour of the tolerance tests.  Reset it to False when done."""
+    lib().oracle_set_sequential_sums(int(bool(on)))
+
+
 class OracleError(RuntimeError):
     def __init__(self, code):
         super().__init__(f"oracle error code {code}")
@@ -162,6 +168,10 @@ class Oracle:
         if rc != OK:
             raise OracleError(rc)
         lib().oracle_set_threads(self.h, threads)
+        # a shared dense metric runs the one-product recurrence by default, as the device library does (include/dhmc.h
+        # dhmc_set_dense_products); DHMC_DENSE_PRODUCTS=2 flips both defaults
+        if self.cfg.metric == METRIC_DENSE and not self.cfg.dense_per_chain and os.environ.get("DHMC_DENSE_PRODUCTS") != "2":
+            self.set_dense_products(1)
 
     def close(self):
         if getattr(self, "h", None):
@@ -188,6 +198,9 @@ class Oracle:
     def set_metric_diag(self, minv):
         minv = np.ascontiguousarray(minv, np.float64)
         self._chk(lib().oracle_set_metric_diag(self.h, _p(minv), int(minv.ndim == 2)))
+
+    def set_dense_products(self, products):
+        self._chk(lib().oracle_set_dense_products(self.h, int(products)))
 
     def set_metric_dense(self, minv):
         minv = np.ascontiguousarray(minv, np.float64)

@@ -52,6 +52,7 @@ def test_dense_round_engine_equals_wave_kernel(pkg):
     A = rng.normal(size=(K, K)); Minv = np.linalg.inv(A.T @ A / K + 0.1 * np.eye(K))
 
     def steps(ctx):
+        ctx.set_dense_products(2)                   # the wave-per-chain kernel has the reference's two-product recurrence only
         ctx.set_metric_dense(Minv); ctx.init(); ctx.find_initial_stepsize()
         a = ctx.run(25, da={})
         b = ctx.run(15)

@@ -190,3 +190,55 @@ def test_logistic_gradient_in_blocks_of_observations():
     assert abs(tr["logdensity"][0, 0] - lq) < 1e-9 * abs(lq)
     got = (tr["q"][0, 1] - q0) * 2 / eps ** 2
     assert np.allclose(got, grad, rtol=0, atol=1e-7 * np.abs(grad).max())
+
+
+def test_dense_one_product_recurrence_stays_next_to_the_references():
+    """oracle/hamiltonian.hpp leapfrog: with `one_product` the dense leapfrog propagates p♯ = M⁻¹p and u = M⁻¹∇ℓq by
+    linearity and takes ONE product per step (u′ = M⁻¹∇ℓq′) instead of the reference's two (hamiltonian.jl:278, :103).
+    Same map, different rounding: identical trees, energies within 1e-11, positions within 1e-12 over 40 transitions of
+    ≈ 37 leapfrogs at a fixed step size.  (With dual averaging ON the two runs drift apart much faster — 1e-6 after 40
+    transitions here: the adaptation feeds last-place differences of the acceptance rate back into ϵ with a gain above one.
+    That sensitivity belongs to the algorithm, whatever the arithmetic; it is why the tolerance tests fix ϵ.)"""
+    D, C = 60, 4
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(D, D)); Minv = np.linalg.inv(A.T @ A / D + 0.2 * np.eye(D))
+    prec = 1 / (rng.normal(size=D) ** 2 + 0.3)
+    params = ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=rng.normal(size=D), prec=prec)
+    runs = {}
+    for products in (1, 2):
+        o = ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=params, metric=ol.METRIC_DENSE, seed=17, threads=4)
+        o.set_dense_products(products)
+        o.set_metric_dense(Minv)
+        o.init(); o.find_initial_stepsize()
+        eps_found = o.stepsize()
+        o.set_stepsize(0.2)
+        runs[products] = (eps_found, o.run(40))
+    assert np.array_equal(runs[1][0], runs[2][0])            # the search is the reference's single leapfrogs in both
+    a, b = runs[1][1], runs[2][1]
+    assert a["steps"].mean() > 20
+    for k in ("depth", "steps", "term_left", "term_right", "directions"):
+        assert np.array_equal(a[k], b[k]), k
+    assert not np.array_equal(a["draws"], b["draws"])        # it IS a different rounding
+    assert np.abs(a["pi"] - b["pi"]).max() < 1e-11
+    assert np.allclose(a["draws"], b["draws"], rtol=1e-12, atol=1e-12)
+
+
+def test_sequential_sums_flavour_stays_next_to_the_abi_order():
+    """oracle/mathops.hpp sequential_sums: every dot and matrix-vector product as a plain left-to-right loop with
+    separately rounded products (the flavour tests/test_gpu_tolerance.py holds the device against)."""
+    D, C = 300, 3
+    runs = {}
+    try:
+        for seq in (False, True):
+            ol.set_sequential_sums(seq)
+            o = ol.Oracle(D, C, seed=23, threads=3)
+            o.init(); o.set_stepsize(0.3)
+            runs[seq] = o.run(12)
+    finally:
+        ol.set_sequential_sums(False)
+    a, b = runs[False], runs[True]
+    for k in ("depth", "steps", "term_left", "term_right", "directions"):
+        assert np.array_equal(a[k], b[k]), k
+    assert not np.array_equal(a["pi"], b["pi"])
+    assert np.abs(a["pi"] - b["pi"]).max() < 1e-10
+    assert np.allclose(a["draws"], b["draws"], rtol=1e-11, atol=1e-12)
