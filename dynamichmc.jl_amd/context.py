@@ -47,6 +47,49 @@ def _is_device(a):
     return not isinstance(a, np.ndarray) and hasattr(a, "data_ptr") and a.is_cuda
 
 
+class _PinnedBlock:
+    """A page-locked allocation of the library (dhmc_host_alloc), returned to a small pool when the last numpy view of it
+    goes away."""
+    _pool = {}          # nbytes -> [address, ...]
+    _POOL_BYTES = 8 << 30
+    _pooled = 0
+
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+        free = _PinnedBlock._pool.get(nbytes)
+        if free:
+            self.addr = free.pop()
+            _PinnedBlock._pooled -= nbytes
+        else:
+            p = C.c_void_p()
+            rc = abi.lib().dhmc_host_alloc(C.byref(p), C.c_uint64(nbytes))
+            if rc != abi.OK or not p.value:
+                raise MemoryError(f"dhmc_host_alloc({nbytes}) failed")
+            self.addr = p.value
+
+    def __del__(self):
+        try:
+            if _PinnedBlock._pooled + self.nbytes <= _PinnedBlock._POOL_BYTES:
+                _PinnedBlock._pool.setdefault(self.nbytes, []).append(self.addr)
+                _PinnedBlock._pooled += self.nbytes
+            else:
+                abi.lib().dhmc_host_free(C.c_void_p(self.addr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array (uninitialised) in page-locked host memory — what dhmc_run's host outputs want (include/dhmc.h)."""
+    dtype = np.dtype(dtype)
+    if any(int(d) <= 0 for d in shape):
+        return np.empty(shape, dtype)            # empty, or numpy's own ValueError for a negative dimension
+    n = int(np.prod(shape)) * dtype.itemsize
+    blk = _PinnedBlock(n)
+    buf = (C.c_char * n).from_address(blk.addr)
+    buf._dhmc_block = blk                      # keeps the block alive as long as any view of the buffer is
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 class DeviceContext:
     def __init__(self, dim, chains, target=abi.TARGET_STD_NORMAL, target_params=None, seed=0x23EF614D,
                  max_depth=10, min_delta=-1000.0, chain_offset=0, metric=abi.METRIC_DIAG, device=0,
@@ -200,12 +243,15 @@ class DeviceContext:
         rc = abi.lib().dhmc_run(self.h, C.c_int64(N), C.byref(dap) if dap is not None else None, C.byref(o))
         return self._chk(rc, "dhmc_run", allow_failure)
 
-    def run(self, N, da=None, fields=None, allow_failure=False):
+    def run(self, N, da=None, fields=None, allow_failure=False, pinned=True):
+        """dhmc_run into fresh numpy arrays.  pinned: the arrays live in page-locked memory (pinned_empty), which the
+        library fills at PCIe speed and under the next chunk's kernel; they behave like any other numpy array."""
         arrs = {}
         for name, dt in abi.OUTPUT_FIELDS:
             if fields is not None and name not in fields:
                 continue
-            arrs[name] = np.zeros((self.C, N, self.D) if name == "draws" else (self.C, N), dt)
+            shape = (self.C, N, self.D) if name == "draws" else (self.C, N)
+            arrs[name] = pinned_empty(shape, dt) if pinned else np.zeros(shape, dt)
         self.run_into(N, arrs, da=da, allow_failure=allow_failure)
         return arrs
 

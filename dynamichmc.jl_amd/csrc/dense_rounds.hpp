@@ -21,7 +21,7 @@
 // u = M⁻¹∇ℓq next to p♯ = M⁻¹p, and a round is
 //
 //     [G0,G0b,G0c,K0]  chains that begin a transition: p, p♯ as above and u = ∇ℓq·M⁻¹, all three fresh products
-//      K2              T = p♯ + (ϵ/2)u;  q′ = q + ϵT, ℓ(q′), ∇ℓ(q′), p′ = pₘ + ϵ/2 ∇ℓ
+//      K2              T = p♯ + (ϵ/2)u (in p♯'s place);  q′ = q + ϵT, ℓ(q′), ∇ℓ(q′), p′ = pₘ + ϵ/2 ∇ℓ
 //      G               U′ = ∇ℓ(Q′) · M⁻¹   for all chains — the round's ONE product (2·D² flops per leapfrog)
 //      K3              p♯′ = T + (ϵ/2)u′, then as above
 //
@@ -201,11 +201,11 @@ __global__ __launch_bounds__(64) void rounds_k2_kernel(RunParams P, RoundBuffers
     double q[NPL], p[NPL], g[NPL], t[NPL];
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(R.cp + row, lane, p);
-    if (P.one_product) {                             // M⁻¹pₘ = p♯ + (ϵ/2)·u, kept for K3 (p♯′ = M⁻¹pₘ + (ϵ/2)·u′)
+    if (P.one_product) {                             // M⁻¹pₘ = p♯ + (ϵ/2)·u, kept (in p♯'s place) for K3: p♯′ = M⁻¹pₘ + (ϵ/2)·u′
         ldv<NPL>(R.cps + row, lane, t);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) t[k] = t[k] + h * R.cu[row + lane + WAVE * k];
-        stv<NPL>(R.tbuf + row, lane, t);
+        stv<NPL>(R.cps + row, lane, t);
     } else {
         ldv<NPL>(R.tbuf + row, lane, t);
     }
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     // so that the kernel fits two waves per SIMD without scratch.
     double p[NPL], ps[NPL], cf[NPL], cfs[NPL], cr[NPL];
     ldv<NPL>(R.cp + row, lane, p);
-    if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (K2 left M⁻¹pₘ in tbuf, the product left u′ in cu)
+    if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (K2 left M⁻¹pₘ in cps, the product left u′ in cu)
         const double h = S.eps_s / 2;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) ps[k] = R.tbuf[row + lane + WAVE * k] + h * R.cu[row + lane + WAVE * k];
+        for (int k = 0; k < NPL; ++k) ps[k] = R.cps[row + lane + WAVE * k] + h * R.cu[row + lane + WAVE * k];
         stv<NPL>(R.cps + row, lane, ps);
     } else {
         ldv<NPL>(R.cps + row, lane, ps);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (dense_rounds.hpp)
         const double h = eps_s / 2;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) ps[k] = R.tbuf[row + off + lane + WAVE * k] + h * cu_row[lane + WAVE * k];
+        for (int k = 0; k < NT; ++k) ps[k] = cps_row[lane + WAVE * k] + h * cu_row[lane + WAVE * k];
         stv<NT>(cps_row, lane, ps);
     } else {
         ldv<NT>(cps_row, lane, ps);

@@ -6,6 +6,7 @@
 // library: without a HIP device every entry point that computes returns DHMC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,16 @@ struct dhmc_ctx {
     uint32_t* d_sflags = nullptr;   // [C][4]: ℓ(q′) (a double) and the position flag between two search kernels (dense)
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
+    // host outputs of dhmc_run: persistent device staging (two buffers per field, grown on demand — no hipMalloc per call),
+    // a copy stream, and pinned bounce buffers for destinations that are not page-locked
+    struct StageBuf { void* p = nullptr; size_t cap = 0; };
+    StageBuf stage[2][10];
+    StageBuf bounce[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_k0[2] = {}, ev_k1[2] = {}, ev_copy[2] = {};
+    int* h_done = nullptr;     // page-locked [2][8]: the dense round engine's done-counters, read without draining the streams
+    hipEvent_t ev_done[2] = {};
+    int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
     bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state
     std::string err;
     std::vector<void*> allocs;
@@ -341,6 +352,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_HOST_CHUNK")) c->host_chunk = std::atoll(e);
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
@@ -387,7 +399,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         c->dm = DenseMetric{c->d_Minv, c->d_WT, c->per_chain_dense ? Dp * Dp : (size_t)0};
         if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
         if (c->per_chain_dense) c->dense_rounds = 0;   // the GEMM engine shares one M⁻¹ across the rows of a product
-        c->dense_products = (c->per_chain_dense || c->external) ? 2 : 1;
+        c->dense_products = c->per_chain_dense ? 2 : 1;
         if (const char* e = std::getenv("DHMC_DENSE_PRODUCTS")) { const int v = std::atoi(e); if (v == 2 || (v == 1 && c->dense_products == 1)) c->dense_products = v; }
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
@@ -487,6 +499,14 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     return DHMC_OK;
 }
 
+int dhmc_host_alloc(void** out, uint64_t nbytes) {
+    if (!out) return DHMC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (nbytes == 0) return DHMC_OK;
+    return hipHostMalloc(out, (size_t)nbytes, hipHostMallocDefault) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+}
+int dhmc_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DHMC_OK : DHMC_ERR_HIP; }
+
 int dhmc_destroy(dhmc_ctx* c) {
     if (!c) return DHMC_OK;
     (void)hipSetDevice(c->cfg.device);
@@ -500,6 +520,16 @@ int dhmc_destroy(dhmc_ctx* c) {
     for (int i = 1; i < 4; ++i) if (c->ev_joins[i]) (void)hipEventDestroy(c->ev_joins[i]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->h_done) (void)hipHostFree(c->h_done);
+    for (int b = 0; b < 2; ++b) if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
+    for (int b = 0; b < 2; ++b) {
+        for (auto& sb : c->stage[b]) if (sb.p) (void)hipFree(sb.p);
+        if (c->bounce[b].p) (void)hipHostFree(c->bounce[b].p);
+        if (c->ev_k0[b]) (void)hipEventDestroy(c->ev_k0[b]);
+        if (c->ev_k1[b]) (void)hipEventDestroy(c->ev_k1[b]);
+        if (c->ev_copy[b]) (void)hipEventDestroy(c->ev_copy[b]);
+    }
     delete c;
     return DHMC_OK;
 }
@@ -655,7 +685,7 @@ int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
 
 int dhmc_set_dense_products(dhmc_ctx* c, int32_t products) {
     if (!c || c->cfg.metric != DHMC_METRIC_DENSE || (products != 1 && products != 2)) return DHMC_ERR_INVALID_ARGUMENT;
-    if (products == 1 && (c->per_chain_dense || c->external)) return DHMC_ERR_UNSUPPORTED;
+    if (products == 1 && c->per_chain_dense) return DHMC_ERR_UNSUPPORTED;
     c->dense_products = products;
     return DHMC_OK;
 }
@@ -817,38 +847,83 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;
     }
-    // outputs: device pointers pass through; host pointers are staged through temporaries
-    struct Field { void** dev; void* host; size_t bytes; };
+    // Outputs: device pointers pass through.  Host pointers are served from the context's persistent staging buffers
+    // (grown on demand: no hipMalloc / hipFree per call).  The one-kernel engine (diagonal metric) runs a call with host
+    // outputs in CHUNKS of L transitions, two staging buffers deep: chunk k leaves over the copy stream (strided 2-D
+    // copies into the caller's [C][N][…] arrays; truly asynchronous when those are page-locked — dhmc_host_alloc) while
+    // chunk k+1 computes.  The chunks are the same transitions of the same kernel as one launch would run: same bits.
+    struct Field { void** dev; void* host; size_t elem; int idx; };   // elem: bytes of one (chain, transition) record
     std::vector<Field> staged;
-    const size_t CN = (size_t)C * N;
-    auto bind = [&](void* user, void** slot, size_t bytes) -> int {
+    const bool one_kernel = c->cfg.metric == DHMC_METRIC_DIAG && !c->logistic_rounds && !c->external;
+    const bool host_out = out && !out->on_device &&
+                          (out->draws || out->logdensities || out->eps || out->pi || out->acceptance_rate || out->steps ||
+                           out->term_left || out->term_right || out->depth || out->directions);
+    int64_t L = N;
+    if (host_out && one_kernel) {
+        const int64_t per_transition = (int64_t)C * D * (int64_t)sizeof(double);
+        // default: ≈ 1 GiB of draws per chunk, but at least four chunks per call so that most of the copy runs under a kernel
+        L = c->host_chunk > 0 ? c->host_chunk : std::min(((int64_t)1 << 30) / (per_transition > 0 ? per_transition : 1), (N + 3) / 4);
+        if (L < 1) L = 1;
+        if (L > N) L = N;
+    }
+    const int nbuf = L < N ? 2 : 1;
+    auto bind = [&](void* user, void** slot, size_t elem, int idx) -> int {
         *slot = nullptr;
         if (!user) return DHMC_OK;
         if (out->on_device) { *slot = user; return DHMC_OK; }
-        HIP_TRY(c, hipMalloc(slot, bytes));
-        staged.push_back({slot, user, bytes});
+        const size_t need = (size_t)C * (size_t)L * elem;
+        for (int b = 0; b < nbuf; ++b) {
+            auto& sb = c->stage[b][idx];
+            if (sb.cap < need) {
+                if (sb.p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(sb.p)); sb.p = nullptr; sb.cap = 0; }
+                HIP_TRY(c, hipMalloc(&sb.p, need));
+                sb.cap = need;
+            }
+        }
+        *slot = c->stage[0][idx].p;
+        staged.push_back({slot, user, elem, idx});
         return DHMC_OK;
     };
     int rc = DHMC_OK;
     if (out) {
-        if (!rc) rc = bind(out->draws, (void**)&P.out.draws, CN * D * sizeof(double));
-        if (!rc) rc = bind(out->logdensities, (void**)&P.out.logdensities, CN * sizeof(double));
-        if (!rc) rc = bind(out->eps, (void**)&P.out.eps, CN * sizeof(double));
-        if (!rc) rc = bind(out->pi, (void**)&P.out.pi, CN * sizeof(double));
-        if (!rc) rc = bind(out->acceptance_rate, (void**)&P.out.acceptance_rate, CN * sizeof(double));
-        if (!rc) rc = bind(out->steps, (void**)&P.out.steps, CN * sizeof(int64_t));
-        if (!rc) rc = bind(out->term_left, (void**)&P.out.term_left, CN * sizeof(int64_t));
-        if (!rc) rc = bind(out->term_right, (void**)&P.out.term_right, CN * sizeof(int64_t));
-        if (!rc) rc = bind(out->depth, (void**)&P.out.depth, CN * sizeof(int32_t));
-        if (!rc) rc = bind(out->directions, (void**)&P.out.directions, CN * sizeof(uint32_t));
+        if (!rc) rc = bind(out->draws, (void**)&P.out.draws, D * sizeof(double), 0);
+        if (!rc) rc = bind(out->logdensities, (void**)&P.out.logdensities, sizeof(double), 1);
+        if (!rc) rc = bind(out->eps, (void**)&P.out.eps, sizeof(double), 2);
+        if (!rc) rc = bind(out->pi, (void**)&P.out.pi, sizeof(double), 3);
+        if (!rc) rc = bind(out->acceptance_rate, (void**)&P.out.acceptance_rate, sizeof(double), 4);
+        if (!rc) rc = bind(out->steps, (void**)&P.out.steps, sizeof(int64_t), 5);
+        if (!rc) rc = bind(out->term_left, (void**)&P.out.term_left, sizeof(int64_t), 6);
+        if (!rc) rc = bind(out->term_right, (void**)&P.out.term_right, sizeof(int64_t), 7);
+        if (!rc) rc = bind(out->depth, (void**)&P.out.depth, sizeof(int32_t), 8);
+        if (!rc) rc = bind(out->directions, (void**)&P.out.directions, sizeof(uint32_t), 9);
     }
-    auto cleanup = [&]() { for (auto& f : staged) if (*f.dev) (void)hipFree(*f.dev); };
+    auto cleanup = [&]() {};   // (the staging buffers belong to the context)
     if (rc) { cleanup(); return rc; }
+    if (!staged.empty() && !c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(c, hipEventCreate(&c->ev_k0[b]));
+            HIP_TRY(c, hipEventCreate(&c->ev_k1[b]));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[b], hipEventDisableTiming));
+        }
+    }
+    // transitions [n0, n0 + len) of every staged field: staging buffer b (record stride L) -> the caller's arrays (stride N)
+    auto d2h = [&](int b, int64_t n0, int64_t len, hipStream_t s) -> hipError_t {
+        for (auto& f : staged) {
+            char* dst = (char*)f.host + (size_t)n0 * f.elem;
+            hipError_t ce = hipMemcpy2DAsync(dst, (size_t)N * f.elem, c->stage[b][f.idx].p, (size_t)L * f.elem, (size_t)len * f.elem,
+                                             (size_t)C, hipMemcpyDeviceToHost, s);
+            if (ce != hipSuccess) return ce;
+        }
+        return hipSuccess;
+    };
+    double chunk_ms = 0.0;
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
     if (e == hipSuccess && c->external && c->cfg.metric == DHMC_METRIC_DENSE) {
         // dense round engine (dense_rounds.hpp) with the host's callback as the density, one batch on one stream
+        P.one_product = c->dense_products == 1;
         RoundArgs ra{P, c->rb};
         const int ld = c->Dpad;
         const RoundBuffers& R = c->rb;
@@ -860,14 +935,16 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
                 launch_gemm_rows(R.cp, c->d_WT, R.tbuf, ld, C, R.list, R.list_count, c->stream);       // p₀ = z·Wᵀ
                 launch_gemm_rows(R.tbuf, c->d_Minv, R.cps, ld, C, R.list, R.list_count, c->stream);    // p♯₀
+                if (P.one_product) launch_gemm_rows(c->st.g, c->d_Minv, R.cu, ld, C, R.list, R.list_count, c->stream);   // u₀ = ∇ℓq₀·M⁻¹
                 if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(R.list_count, 0, sizeof(int), c->stream);
-                launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, C, nullptr, nullptr, c->stream);         // M⁻¹pₘ
-                DHMC_EXT_NPL(rounds_k2a_dense_external_kernel, dim3(C), ra.P, ra.R)                    // q′
+                if (!P.one_product) launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, C, nullptr, nullptr, c->stream);   // M⁻¹pₘ
+                DHMC_EXT_NPL(rounds_k2a_dense_external_kernel, dim3(C), ra.P, ra.R)                    // q′ (one product: M⁻¹pₘ = p♯ + (ϵ/2)u)
                 rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
                 if (rc) { c->poisoned = true; cleanup(); return rc; }   // st.q holds trial positions: see DHMC_CHECK_USABLE
                 DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′
-                launch_gemm_rows(R.cp, c->d_Minv, R.cps, ld, C, nullptr, nullptr, c->stream);          // p♯
+                if (P.one_product) launch_gemm_rows(c->st.g, c->d_Minv, R.cu, ld, C, nullptr, nullptr, c->stream);   // u′ = ∇ℓq′·M⁻¹
+                else launch_gemm_rows(R.cp, c->d_Minv, R.cps, ld, C, nullptr, nullptr, c->stream);     // p♯
                 if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }
             if (e == hipSuccess) e = hipGetLastError();
@@ -1032,6 +1109,15 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 return DHMC_ERR_HIP;
             }
         }
+        // The host never drains the streams to look at the done-counters: after every batch of REPS rounds they are copied
+        // into page-locked memory behind an event, and the host reads the PREVIOUS batch's copy once the next batch is
+        // enqueued.  So it runs one batch ahead; the (at most REPS) rounds enqueued after the last chain finished find no
+        // chain in a leaf phase and, with the row lists, no rows to multiply.
+        if (!c->h_done && e == hipSuccess) {
+            e = hipHostMalloc((void**)&c->h_done, 2 * 8 * sizeof(int), hipHostMallocDefault);
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming);
+        }
+        long long batch = 0;
         while (e == hipSuccess && done[1] + done[3] + done[5] + done[7] < C) {
             if (gexec) {
                 e = hipGraphLaunch(gexec, c->stream);
@@ -1044,30 +1130,69 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 }
             }
             rounds += REPS;
-            if (e == hipSuccess) e = hipMemcpyAsync(done, c->rb.list_count, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            int* slot = c->h_done + 8 * (batch & 1);
+            if (e == hipSuccess) e = hipMemcpyAsync(slot, c->rb.list_count, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_done[batch & 1], c->stream);
+            if (batch >= 1 && e == hipSuccess) {
+                e = hipEventSynchronize(c->ev_done[(batch - 1) & 1]);
+                std::memcpy(done, c->h_done + 8 * ((batch - 1) & 1), 8 * sizeof(int));
+            }
+            batch += 1;
             row_lists = c->dense_row_lists && !gexec && done[1] + done[3] + done[5] + done[7] > 0;
         }
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (graph) (void)hipGraphDestroy(graph);
         c->last_rounds = rounds;
+    } else if (e == hipSuccess && nbuf == 2) {
+        // the one-kernel engine, host outputs, in chunks: kernel of chunk k ‖ copy of chunk k-1
+        const int64_t nchunks = (N + L - 1) / L;
+        bool used[2] = {false, false};
+        for (int64_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+            const int b = (int)(k & 1);
+            const int64_t n0 = k * L, len = (n0 + L <= N) ? L : N - n0;
+            RunParams Q = P;
+            Q.N = len;
+            Q.out_stride = L;
+            if (da) { Q.da_init = (k == 0) ? da->init : 0; Q.da_finalize = (k == nchunks - 1) ? da->finalize : 0; }
+            for (auto& f : staged) *f.dev = c->stage[b][f.idx].p;          // (the slots are fields of P.out: copy them again)
+            Q.out = P.out;
+            if (used[b]) {                                                   // buffer b: its previous copy has left, and its kernel time is known
+                e = hipStreamWaitEvent(c->stream, c->ev_copy[b], 0);
+                if (e == hipSuccess) e = hipEventSynchronize(c->ev_k1[b]);
+                float ms = 0.f;
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_k0[b], c->ev_k1[b]);
+                chunk_ms += ms;
+            }
+            if (e == hipSuccess) e = hipEventRecord(c->ev_k0[b], c->stream);
+            if (e == hipSuccess && (rc = dispatch(c, Op::Run, &Q))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(c->ev_k1[b], c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_k1[b], 0);
+            if (e == hipSuccess) e = d2h(b, n0, len, c->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_copy[b], c->copy_stream);
+            used[b] = true;
+        }
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            if (used[b]) {
+                e = hipEventSynchronize(c->ev_k1[b]);
+                float ms = 0.f;
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_k0[b], c->ev_k1[b]);
+                chunk_ms += ms;
+            }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
     } else if (e == hipSuccess) {
         rc = dispatch(c, Op::Run, &P);
         if (rc) { cleanup(); return rc; }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
-    if (e == hipSuccess)
-        for (auto& f : staged) {
-            e = hipMemcpyAsync(f.host, *f.dev, f.bytes, hipMemcpyDeviceToHost, c->stream);
-            if (e != hipSuccess) break;
-        }
+    if (e == hipSuccess && nbuf == 1 && !staged.empty()) e = d2h(0, 0, N, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) {
         float ms = 0.f;
         e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        c->last_ms = ms;
+        c->last_ms = nbuf == 2 ? chunk_ms : ms;     // kernel time only: not the waits for copies between the chunks
     }
     cleanup();
     if (e != hipSuccess) { c->err = std::string("dhmc_run: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }

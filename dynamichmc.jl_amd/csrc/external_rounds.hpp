@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64) void rounds_k2_external_kernel(RunParams P, Rou
         gdst[e] = gv;
         const double p1 = cp[e] + h * gv;                                  // hamiltonian.jl:280
         cp[e] = p1;
-        cps[e] = minv[e] * p1;
-    });
+        if (!P.one_product) cps[e] = minv[e] * p1;                         // (dense metric: overwritten by the product; one-product
+    });                                                                    //  recurrence: cps holds M⁻¹pₘ for K3, dense_rounds.hpp)
     if (lane == 0) {
         S.lq_leaf = lq;
         if (!pos_finite) S.status |= DHMC_ST_NONFINITE_POSITION;
@@ -275,11 +275,18 @@ __global__ __launch_bounds__(64) void rounds_k2a_dense_external_kernel(RunParams
     const TreeState& S = R.ts[chain];
     if (S.phase != PH_LEAF) return;
     const size_t row = (size_t)chain * P.Dpad;
-    const double eps_s = S.eps_s;
+    const double eps_s = S.eps_s, h = eps_s / 2;
 #pragma unroll 4
     for (int k = 0; k < NPL; ++k) {
         const int e = lane + WAVE * k;
-        P.st.q[row + e] = P.st.q[row + e] + eps_s * R.tbuf[row + e];
+        double t;
+        if (P.one_product) {                                               // M⁻¹pₘ = p♯ + (ϵ/2)·u, kept in p♯'s place (dense_rounds.hpp)
+            t = R.cps[row + e] + h * R.cu[row + e];
+            R.cps[row + e] = t;
+        } else {
+            t = R.tbuf[row + e];
+        }
+        P.st.q[row + e] = P.st.q[row + e] + eps_s * t;
     }
 }
 

@@ -75,6 +75,8 @@ struct RunParams {
     double min_delta;
     uint64_t seed;
     int64_t N;
+    int64_t out_stride;          // record (chain, n) of the outputs is at chain * out_stride + n (0: out_stride = N): a call whose
+                                 // host outputs leave in chunks writes every chunk into a staging buffer of the chunk's length
     ChainArrays st;
     int adapt, da_init, da_finalize, t0;
     double delta, gamma, kappa;
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         lq_cur = sl_lq.get(init_slot);
         const double pi_stat = sl_pi.get(init_slot);
 
-        const size_t o = (size_t)chain * P.N + n;
+        const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + n;
         if (P.out.draws) {
             double* drow = P.out.draws + o * D;
 #pragma unroll

@@ -167,6 +167,14 @@ typedef struct dhmc_outputs {
     uint32_t* directions;    /* [C][N]    Directions.flags as drawn */
 } dhmc_outputs;
 
+/* ---- page-locked host memory for result buffers ---------------------------------------- */
+/* dhmc_run with host pointers copies every output field device -> host.  Into PAGE-LOCKED memory those copies run at PCIe
+ * speed and — with the diagonal metric, where a call leaves in chunks of transitions — under the next chunk's kernel; into
+ * pageable memory the runtime stages them at a fraction of that.  These two calls hand out / take back page-locked
+ * memory (hipHostMalloc) for callers that cannot allocate it themselves; any page-locked memory works the same. */
+int dhmc_host_alloc(void** out, uint64_t nbytes);
+int dhmc_host_free(void* p);
+
 /* ---- lifecycle ----------------------------------------------------------------------- */
 int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out);
 int dhmc_destroy(dhmc_ctx* ctx);
@@ -212,7 +220,7 @@ int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, doub
  *      multiply and add in the order written.  The DEFAULT of a shared dense metric (a stated deviation from the
  *      reference's operation order, like the pooled adaptation: per-step energies agree to ≈1e-12, trees are the same —
  *      tests/test_gpu_tolerance.py); then the GEMM round engine runs whatever the number of chains.
- * dense_per_chain contexts and DHMC_TARGET_EXTERNAL always use 2 (asking for 1 there: DHMC_ERR_UNSUPPORTED).  May be
+ * dense_per_chain contexts always use 2 (asking for 1 there: DHMC_ERR_UNSUPPORTED).  May be
  * changed between dhmc_run calls.  DHMC_DENSE_PRODUCTS=2 in the environment makes 2 the default. */
 int dhmc_set_dense_products(dhmc_ctx* ctx, int32_t products);
 int dhmc_get_dense_products(const dhmc_ctx* ctx);   /* 1 or 2; 0 for a context without a dense metric */

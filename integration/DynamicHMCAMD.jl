@@ -15,7 +15,18 @@ using DynamicHMC: NUTS, DualAveraging, FixedStepsize, InitialStepsizeSearch, Tun
                   TreeStatisticsNUTS, InvalidTree, Directions, default_warmup_stages, default_reporter, report,
                   REPORT_SIGDIGITS
 using LinearAlgebra: Diagonal, Symmetric
+using AMDGPU: ROCArray                      # device-resident results (run!(...; on_device = true)) and external models
 const libdhmc = "libdhmc_amd.so"            # dynamichmc.jl_amd/lib/
+
+# Page-locked host arrays (dhmc_host_alloc): dhmc_run fills them at PCIe speed, chunk k's copy under chunk k+1's kernel;
+# an ordinary Array works too, at the runtime's staged rate (DESIGN.md §6: 7.6e7 against 1.0e8 leapfrog-steps/s).
+function pinned_array(::Type{T}, dims...) where {T}
+    p = Ref{Ptr{Cvoid}}()
+    rc = ccall((:dhmc_host_alloc, libdhmc), Cint, (Ref{Ptr{Cvoid}}, UInt64), p, prod(dims) * sizeof(T))
+    rc == 0 || throw(OutOfMemoryError())
+    a = unsafe_wrap(Array, Ptr{T}(p[]), dims; own = false)
+    finalizer(_ -> ccall((:dhmc_host_free, libdhmc), Cint, (Ptr{Cvoid},), p[]), a)
+end
 
 struct Config                              # dhmc_config, include/dhmc.h
     device::Int32; dim::Int32; chains::Int32; chain_offset::Int32
@@ -83,18 +94,24 @@ find_initial_stepsize!(ctx, s::InitialStepsizeSearch) = check(ctx,
           StepsizeSearchABI(s.initial_ϵ, s.log_threshold, s.maxiter_crossing, 0)), "dhmc_find_initial_stepsize")
 
 # the per-draw loops (mcmc.jl:271-280 with `da`, :374-379 without)
-function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing)
+# on_device: the draws stay in HBM (a ROCArray, for dhmc_update_metric_* / dhmc_ess_* on device pointers); the per-draw
+# scalars always come to the host
+function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing, on_device::Bool = false)
     D, C = ctx.dim, ctx.chains
-    pm = Array{Float64}(undef, D, N, C)               # posterior_matrix[:, i] per chain (mcmc.jl:275)
-    ℓs = Matrix{Float64}(undef, N, C); ϵs = similar(ℓs); π = similar(ℓs); a = similar(ℓs)
-    steps = Matrix{Int64}(undef, N, C); tl = similar(steps); tr = similar(steps)
-    depth = Matrix{Int32}(undef, N, C); dirs = Matrix{UInt32}(undef, N, C)
-    out = Outputs(0, 0, pointer(pm), pointer(ℓs), pointer(ϵs), pointer(π), pointer(a), pointer(steps),
+    mk(T, dims...) = on_device ? ROCArray{T}(undef, dims...) : pinned_array(T, dims...)
+    pm = mk(Float64, D, N, C)                          # posterior_matrix[:, i] per chain (mcmc.jl:275)
+    ℓs = mk(Float64, N, C); ϵs = mk(Float64, N, C); π = mk(Float64, N, C); a = mk(Float64, N, C)
+    steps = mk(Int64, N, C); tl = mk(Int64, N, C); tr = mk(Int64, N, C)
+    depth = mk(Int32, N, C); dirs = mk(UInt32, N, C)
+    out = Outputs(on_device, 0, pointer(pm), pointer(ℓs), pointer(ϵs), pointer(π), pointer(a), pointer(steps),
                   pointer(tl), pointer(tr), pointer(depth), pointer(dirs))
     daref = da === nothing ? C_NULL : Ref(DualAveragingABI(da.δ, da.γ, da.κ, da.t₀, 1, 1, 0))
     rc = GC.@preserve pm ℓs ϵs π a steps tl tr depth dirs ccall((:dhmc_run, libdhmc), Cint,
             (Ptr{Cvoid}, Int64, Ptr{DualAveragingABI}, Ref{Outputs}), ctx.h, N, daref, out)
     check(ctx, rc, "dhmc_run")
+    if on_device                                       # the scalars to the host; pm stays where it is
+        ℓs, ϵs, π, a, steps, tl, tr, depth, dirs = Array.((ℓs, ϵs, π, a, steps, tl, tr, depth, dirs))
+    end
     stats = [TreeStatisticsNUTS(π[i, c], depth[i, c], InvalidTree(tl[i, c], tr[i, c]), a[i, c], steps[i, c],
                                 Directions(dirs[i, c])) for i in 1:N, c in 1:C]       # NUTS.jl:208-221
     (posterior_matrix = pm, tree_statistics = stats, ϵs = ϵs, logdensities = ℓs)
@@ -108,6 +125,10 @@ update_metric!(ctx, pm, λ) = check(ctx, ccall((:dhmc_update_metric_diag, libdhm
 # TuningNUTS{Symmetric} stage (mcmc.jl:210,218-222; pooled over the context's chains)
 set_metric_dense!(ctx, Minv::Matrix{Float64}) = check(ctx, ccall((:dhmc_set_metric_dense, libdhmc), Cint,
     (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx.h, pointer(Minv), 0), "dhmc_set_metric_dense")
+# 2: the reference's leapfrog with a dense metric (two M⁻¹ products, hamiltonian.jl:278 and :103); 1 (default of a shared
+# dense metric): the same map with one product per step (include/dhmc.h)
+set_dense_products!(ctx, n::Integer) = check(ctx, ccall((:dhmc_set_dense_products, libdhmc), Cint, (Ptr{Cvoid}, Int32), ctx.h, n),
+                                             "dhmc_set_dense_products")
 update_metric_dense!(ctx, pm, λ) = check(ctx, ccall((:dhmc_update_metric_dense, libdhmc), Cint,
     (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Cint), ctx.h, pointer(pm), size(pm, 2), λ, 0), "dhmc_update_metric_dense")
 
@@ -231,8 +252,16 @@ DynamicHMC.mcmc(sl::SamplingLogDensityAMD, N, warmup_state) =
 struct MCMCStepsAMD; sl::SamplingLogDensityAMD; end
 function DynamicHMC.mcmc_steps(sl::SamplingLogDensityAMD, warmup_state)
     warmup_state.ϵ ≡ nothing && throw(ArgumentError("ϵ ≢ nothing"))
-    warmup_state.ϵ == stepsize(sl.ctx) || set_stepsize!(sl.ctx, warmup_state.ϵ)
-    warmup_state.Q.q == position(sl.ctx).q || set_position!(sl.ctx, warmup_state.Q.q)
+    ctx = sl.ctx
+    warmup_state.ϵ == stepsize(ctx) || set_stepsize!(ctx, warmup_state.ϵ)
+    # κ of the warmup state, if it is not the context's own (mcmc.jl:337-339 builds the Hamiltonian from warmup_state.κ)
+    if warmup_state.κ isa DynamicHMC.GaussianKineticEnergy                      # one dense κ shared by the chains
+        set_metric_dense!(ctx, Matrix(warmup_state.κ.M⁻¹))
+    elseif !(warmup_state.κ ≡ kinetic_energy(ctx))
+        m = reduce(hcat, [Vector(k.M⁻¹.diag) for k in warmup_state.κ])           # D×C
+        check(ctx, ccall((:dhmc_set_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, m, 1, 0), "dhmc_set_metric_diag")
+    end
+    warmup_state.Q.q == position(ctx).q || set_position!(ctx, warmup_state.Q.q)
     MCMCStepsAMD(sl)
 end
 function DynamicHMC.mcmc_next_step(steps::MCMCStepsAMD, Q)

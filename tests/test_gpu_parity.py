@@ -371,3 +371,43 @@ def test_builtin_normal_families_beyond_1024_dimensions(pkg, family, D, metric):
         dev.update_metric_diag(a["draws"]); ora.update_metric_diag(b["draws"])
         assert np.array_equal(dev.metric_diag(), ora.metric_diag())
     assert_same(dev.run(5), ora.run(5), f"{family} D={D} {metric} fixed")
+
+
+def test_host_outputs_in_chunks_equal_device_outputs(pkg, monkeypatch):
+    """dhmc_run with host result buffers leaves in chunks of transitions over a copy stream, two staging buffers deep
+    (csrc/dhmc_capi.hip); the chunks are the same transitions of the same kernel: pageable and page-locked destinations, a
+    chunk length that does not divide N, adaptation across the chunks — all equal to one launch into device buffers."""
+    import torch
+    from dynamichmc_jl_amd.context import pinned_empty
+    D, C, N = 70, 9, 11
+    fields = pkg.abi.OUTPUT_FIELDS
+    tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32, np.uint32: torch.int32}
+
+    def run(kind, chunk):
+        if chunk:
+            monkeypatch.setenv("DHMC_HOST_CHUNK", str(chunk))
+        else:
+            monkeypatch.delenv("DHMC_HOST_CHUNK", raising=False)
+        ctx = pkg.DeviceContext(D, C, seed=12)
+        ctx.init(); ctx.find_initial_stepsize()
+        res = []
+        for da in ({}, None):
+            shape = lambda k: (C, N, D) if k == "draws" else (C, N)
+            if kind == "device":
+                arrs = {k: torch.zeros(shape(k), dtype=tdt[dt], device="cuda") for k, dt in fields}
+            elif kind == "pinned":
+                arrs = {k: pinned_empty(shape(k), dt) for k, dt in fields}
+            else:
+                arrs = {k: np.zeros(shape(k), dt) for k, dt in fields}
+            ctx.run_into(N, arrs, da=da)
+            res.append({k: (a.cpu().numpy().view(dt) if kind == "device" else np.array(a)) for (k, dt), a in zip(fields, arrs.values())})
+        res.append({"eps": ctx.stepsize(), "q": ctx.position()[0]})
+        ctx.close()
+        return res
+
+    ref = run("device", 0)
+    for kind, chunk in (("pageable", 0), ("pageable", 4), ("pinned", 4), ("pinned", 1), ("pinned", 11), ("pinned", 50)):
+        got = run(kind, chunk)
+        for a, b in zip(ref, got):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (kind, chunk, k)
