@@ -16,9 +16,9 @@ void launch_run(const RunParams& P, hipStream_t s) {
     }();
     (void)once;
     if (P.l1_in_lds)
-        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, true>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, true, lds_extra_levels(NPL), T::kElementwise), s, P);
+        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, true>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, true, lds_extra_levels(NPL)), s, P);
     else
-        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, false>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, false, 0, T::kElementwise), s, P);
+        hipLaunchKernelGGL((nuts_run_kernel<T, NPL, false>), dim3(P.C), dim3(WAVE), lds_bytes(P.Dpad, false, 0), s, P);
 }
 template <class T, int NPL>
 void launch_init(const InitParams& P, hipStream_t s) {

@@ -107,11 +107,11 @@ __host__ __device__ constexpr int lds_extra_levels(int NPL) { return NPL == 1 ? 
 // The per-level / per-slot scalars of the tree logic live in the lanes of a few registers (wave.hpp LaneArr), not in LDS.
 // Wide chains (16 slots per lane, kTrajInLds): M⁻¹ stays in registers and the rows are (level 0, level 1 first / last,
 // trajectory p₋ / p₊) — 40 KB per wave, four waves fill the CU's 160 KB exactly.
-// (Coordinate-wise targets only: the layout is what BASELINE config 2 runs; the other families keep M⁻¹ in LDS and the
-// trajectory in registers.)
-__host__ __device__ constexpr bool traj_in_lds(int NPL, bool l1_in_lds, bool elementwise) { return NPL == 16 && l1_in_lds && elementwise; }
-__host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds, int extra_levels, bool elementwise) {
-    if (traj_in_lds(Dpad / 64, l1_in_lds, elementwise)) return sizeof(double) * (size_t)Dpad * 5;
+// (Every target family since round 3: round 2 restricted it to coordinate-wise targets after a fault in a fuzz sweep that
+// no longer reproduces — DESIGN.md §10 — and a tridiagonal-precision normal at D = 1000 runs 2.9× faster with it.)
+__host__ __device__ constexpr bool traj_in_lds(int NPL, bool l1_in_lds) { return NPL == 16 && l1_in_lds; }
+__host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds, int extra_levels) {
+    if (traj_in_lds(Dpad / 64, l1_in_lds)) return sizeof(double) * (size_t)Dpad * 5;
     return sizeof(double) * ((size_t)Dpad * ((l1_in_lds ? 4 : 2) + 3 * extra_levels));
 }
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     const int D = P.D, Dpad = P.Dpad;
 
     extern __shared__ double lds[];
-    constexpr bool TPL = traj_in_lds(NPL, L1LDS, T::kElementwise);          // M⁻¹ in registers; trajectory edges p₋, p₊ in LDS
+    constexpr bool TPL = traj_in_lds(NPL, L1LDS);                           // M⁻¹ in registers; trajectory edges p₋, p₊ in LDS
     double* m_lds = lds;                                   // [Dpad]   (!TPL)
     double* l0_lds = lds + (TPL ? 0 : 1) * Dpad;           // [Dpad]   level-0 suspended momentum
     double* l1f_lds = lds + (TPL ? 1 : 2) * Dpad;          // [Dpad]   level-1 first   (L1LDS only)

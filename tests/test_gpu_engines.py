@@ -46,6 +46,39 @@ def test_diag_kernel_lds_variants_agree(pkg):
     _same(_run_with_env(pkg, {"DHMC_L1_LDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_L1_LDS": "0"}, make, steps))
 
 
+def test_lds_trajectory_layout_with_a_target_that_is_not_coordinate_wise(pkg):
+    """VERDICT r2 #5 / DESIGN.md §10: the layout of the wide per-draw kernel that keeps the trajectory's edge momenta in LDS
+    and M⁻¹ in registers was restricted to coordinate-wise targets in round 2, after a fault in a fuzz sweep with the
+    tridiagonal-precision normal at D = 1000.  The fault does not reproduce (19 000 tridiagonal cases at 700 <= D <= 1024,
+    the whole GPU suite and the fuzz sweep with the layout forced on for every family: tools/experiments/tpl_fault_repro.py,
+    profiles/r03_lds_layout_fault.txt), the restriction is gone, and this is the regression test: that family, D = 1000 and
+    1024, through adaptation, a metric update, divergent and depth-limited trees — against the oracle and against the
+    other (DHMC_L1_LDS=0) layout."""
+    for D in (1000, 1024):
+        rng = np.random.default_rng(D)
+        params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.0 + rng.random()), off=np.full(D - 1, -0.9 * rng.random()))
+
+        def steps(ctx):
+            out = {}
+            ctx.init(); ctx.find_initial_stepsize()
+            a = ctx.run(12, da={})
+            ctx.update_metric_diag(a["draws"])
+            out.update({"w_" + k: v for k, v in a.items()})
+            out.update({"i_" + k: v for k, v in ctx.run(6).items()})
+            ctx.set_stepsize(3.0)                       # most leaves diverge
+            out.update({"d_" + k: v for k, v in ctx.run(4).items()})
+            ctx.set_stepsize(2e-3)                      # every tree is cut at max_depth
+            out.update({"m_" + k: v for k, v in ctx.run(2).items()})
+            return out
+        make = lambda: pkg.DeviceContext(D, 9, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=33, max_depth=6)
+        a = _run_with_env(pkg, {"DHMC_L1_LDS": "1"}, make, steps)
+        b = _run_with_env(pkg, {"DHMC_L1_LDS": "0"}, make, steps)
+        o = steps(ol.Oracle(D, 9, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=33, max_depth=6, threads=9))
+        _same(a, b)
+        _same(a, o)
+        assert (a["m_depth"] == 6).all()
+
+
 def test_dense_round_engine_equals_wave_kernel(pkg):
     rng = np.random.default_rng(3)
     K = 96
