@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DHMC_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libd
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNSUPPORTED, ERR_CHAIN_FAILURE, ERR_NO_DEVICE, ERR_CALLBACK = range(7)
 ST_NONFINITE_POSITION, ST_INVALID_INITIAL, ST_STEPSIZE_SEARCH_FAILED, ST_NONFINITE_START_DENSITY = 1, 2, 4, 8
 TARGET_STD_NORMAL, TARGET_DIAG_NORMAL, TARGET_TRIDIAG_NORMAL, TARGET_FUNNEL, TARGET_LOGISTIC, TARGET_ALWAYS_DIVERGENT, TARGET_DENSE_NORMAL, TARGET_EXTERNAL = range(8)
+TARGET_USER_BASE = 1000     # + the handle of dhmc_register_target_source: a run-time compiled device functor
 METRIC_DIAG, METRIC_DENSE = 0, 1
 
 ERROR_NAMES = {ERR_INVALID_ARGUMENT: "invalid argument", ERR_HIP: "HIP runtime error",
@@ -70,7 +71,8 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes",
            "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
            "dhmc_set_logdensity_callback", "dhmc_ess_bulk", "dhmc_summarize_tree_statistics",
-           "dhmc_set_dense_products", "dhmc_get_dense_products", "dhmc_host_alloc", "dhmc_host_free"]
+           "dhmc_set_dense_products", "dhmc_get_dense_products", "dhmc_host_alloc", "dhmc_host_free",
+           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log"]
 
 _lib = None
 
@@ -113,12 +115,13 @@ def lib():
             getattr(L, s)
         L.dhmc_last_error.restype = C.c_char_p
         L.dhmc_version.restype = C.c_char_p
+        L.dhmc_target_source_log.restype = C.c_char_p
         L.dhmc_last_run_kernel_ms.restype = C.c_double
         L.dhmc_last_run_leapfrogs.restype = C.c_uint64
         L.dhmc_last_run_rounds.restype = C.c_uint64
         L.dhmc_workspace_bytes.restype = C.c_uint64
         for name in SYMBOLS:
-            if name.startswith("dhmc_") and name not in ("dhmc_last_error", "dhmc_version", "dhmc_last_run_kernel_ms",
+            if name.startswith("dhmc_") and name not in ("dhmc_last_error", "dhmc_version", "dhmc_target_source_log", "dhmc_last_run_kernel_ms",
                                                          "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes"):
                 getattr(L, name).restype = C.c_int
         _lib = L

@@ -25,7 +25,7 @@ __all__ = [
     "default_warmup_stages", "fixed_stepsize_warmup_stages", "GaussianKineticEnergy",
     "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
-    "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent", "TorchLogDensity",
+    "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent", "TorchLogDensity", "DeviceFunctorLogDensity",
     "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
     "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
 ]
@@ -305,6 +305,34 @@ class TorchLogDensity(_Target):
                 (g,) = torch.autograd.grad(lq.sum(), x)
             return lq.detach(), g
         return fg
+
+
+class DeviceFunctorLogDensity(_Target):
+    """The user's own model as a DEVICE FUNCTOR: HIP C++ source defining `struct <name>` in namespace dhmc with the interface
+    of the built-in families (include/dhmc.h dhmc_register_target_source), compiled at run time into the
+    library's own per-draw / initialisation / step-size-search kernels — no host round trip per leapfrog, as `north_star`
+    asks ("the user ∇log π is supplied as a device function").  `params`: doubles handed to the functor's constructor.
+    Diagonal metric, dimension <= 1024."""
+
+    def __init__(self, dimension, source, name, params=None):
+        self.D = int(dimension)
+        self._params = None if params is None else np.ascontiguousarray(params, np.float64).ravel()
+        import ctypes
+        h = ctypes.c_int32(-1)
+        rc = abi.lib().dhmc_register_target_source(source.encode(), name.encode(), ctypes.byref(h))
+        _argcheck(rc == abi.OK, "dhmc_register_target_source")
+        self.family = abi.TARGET_USER_BASE + h.value
+
+    def params(self):
+        return self._params
+
+    @staticmethod
+    def check(dimension, source, name):
+        """Compile only (no GPU needed); returns (ok, compiler log)."""
+        import ctypes
+        log = ctypes.create_string_buffer(1 << 16)
+        rc = abi.lib().dhmc_check_target_source(source.encode(), name.encode(), ctypes.c_int32(dimension), log, ctypes.c_uint64(len(log)))
+        return rc == abi.OK, log.value.decode(errors="replace")
 
 
 class AlwaysDivergent(_Target):

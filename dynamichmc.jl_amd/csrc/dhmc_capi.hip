@@ -5,12 +5,15 @@
 // stream, and maps per-chain failure words onto return codes.  There is NO CPU path in this
 // library: without a HIP device every entry point that computes returns DHMC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +29,67 @@
 #include "util_kernels.hpp"
 
 using namespace dhmc;
+
+// ---- the caller's device functor, compiled at run time (include/dhmc.h dhmc_register_target_source) -----------------------
+#include "gen/rtc_headers.inc"     // const char dhmc_rtc_headers[]: the kernel headers as one string (make_rtc_source.py)
+namespace {
+struct UserKernels {
+    hipModule_t mod = nullptr;
+    hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr;
+};
+struct UserTarget {
+    std::string source, name;
+    std::map<std::pair<int, int>, UserKernels> built;   // (device, slots per lane) -> module
+};
+std::vector<UserTarget> g_user_targets;
+std::mutex g_user_mutex;
+std::string g_rtc_log;
+
+// hiprtc has the HIP device runtime built in but no system headers: the fixed-width integer names the headers use
+const char* rtc_prelude() {
+    return "typedef unsigned char uint8_t; typedef unsigned int uint32_t; typedef int int32_t;\n"
+           "typedef unsigned long long uint64_t; typedef long long int64_t;\n";
+}
+// compile `source` (which defines dhmc::`name`) with the kernel templates for one chain width; *code receives the code object
+int rtc_compile(const std::string& source, const std::string& name, int npl, std::vector<char>* code, std::string (*lowered)[4]) {
+    std::string src = rtc_prelude();
+    src += dhmc_rtc_headers;
+    src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
+    src += source;
+    src += "\n";
+    const std::string T = "dhmc::" + name, N = std::to_string(npl);
+    const std::string exprs[4] = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
+                                  "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">"};
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
+    for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+    size_t ls = 0;
+    (void)hiprtcGetProgramLogSize(prog, &ls);
+    g_rtc_log.assign(ls, '\0');
+    if (ls) (void)hiprtcGetProgramLog(prog, &g_rtc_log[0]);
+    int rc = DHMC_OK;
+    if (r != HIPRTC_SUCCESS) {
+        rc = DHMC_ERR_INVALID_ARGUMENT;
+    } else {
+        if (lowered)
+            for (int i = 0; i < 4; ++i) {
+                const char* low = nullptr;
+                if (hiprtcGetLoweredName(prog, exprs[i].c_str(), &low) != HIPRTC_SUCCESS || !low) { rc = DHMC_ERR_HIP; break; }
+                (*lowered)[i] = low;
+            }
+        if (rc == DHMC_OK && code) {
+            size_t cs = 0;
+            if (hiprtcGetCodeSize(prog, &cs) != HIPRTC_SUCCESS) rc = DHMC_ERR_HIP;
+            else { code->resize(cs); if (hiprtcGetCode(prog, code->data()) != HIPRTC_SUCCESS) rc = DHMC_ERR_HIP; }
+        }
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    return rc;
+}
+int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : 0; }
+}  // namespace
 
 struct dhmc_ctx {
     dhmc_config cfg{};
@@ -79,6 +143,8 @@ struct dhmc_ctx {
     int* h_done = nullptr;     // page-locked [2][8]: the dense round engine's done-counters, read without draining the streams
     hipEvent_t ev_done[2] = {};
     int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
+    const UserKernels* user = nullptr;   // target >= DHMC_TARGET_USER_BASE: the run-time compiled kernels of the caller's functor
+    void* d_user_params = nullptr;
     bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state
     std::string err;
     std::vector<void*> allocs;
@@ -153,6 +219,23 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
 int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false) {
     hipStream_t cs = use_override ? stream_override : c->stream;
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
+    if (c->user) {     // the caller's functor: the same three kernels, from the run-time compiled module
+        hipFunction_t f = nullptr;
+        unsigned lds = 0;
+        switch (op) {
+        case Op::Run: {
+            const RunParams& R = *(const RunParams*)P;
+            f = R.l1_in_lds ? c->user->run_lds : c->user->run;
+            lds = (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0));
+            break;
+        }
+        case Op::Init: f = c->user->init; break;
+        case Op::Search: f = c->user->search; lds = (unsigned)(sizeof(double) * c->Dpad); break;
+        default: return DHMC_ERR_UNSUPPORTED;
+        }
+        void* args[] = {const_cast<void*>(P)};
+        return hipModuleLaunchKernel(f, (unsigned)c->cfg.chains, 1, 1, WAVE, 1, 1, lds, cs, args, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+    }
     if (c->builtin_big) return dispatch_family<ExternalT>(c->NPL, op, P, cs, M);
     switch (c->cfg.target) {
     case DHMC_TARGET_STD_NORMAL: return dispatch_family<StdNormalT>(c->NPL, op, P, cs, M);
@@ -321,7 +404,15 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     }
     case DHMC_TARGET_EXTERNAL:
         break;
-    default: return DHMC_ERR_UNSUPPORTED;
+    default:
+        if (cfg->target >= DHMC_TARGET_USER_BASE) {
+            std::lock_guard<std::mutex> lock(g_user_mutex);
+            if ((size_t)(cfg->target - DHMC_TARGET_USER_BASE) >= g_user_targets.size()) return DHMC_ERR_INVALID_ARGUMENT;
+            if (cfg->metric != DHMC_METRIC_DIAG || D > 1024) return DHMC_ERR_UNSUPPORTED;
+            if (cfg->target_params_bytes % sizeof(double) != 0 || (cfg->target_params_bytes && !cfg->target_params)) return DHMC_ERR_INVALID_ARGUMENT;
+            break;
+        }
+        return DHMC_ERR_UNSUPPORTED;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return DHMC_ERR_NO_DEVICE;
@@ -375,6 +466,33 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (hipMemset(c->st.da, 0, C * sizeof(DAState)) != hipSuccess) return fail(DHMC_ERR_HIP);
     if (hipMemset(c->st.status, 0, C * sizeof(uint32_t)) != hipSuccess) return fail(DHMC_ERR_HIP);
     if (hipMemset(c->st.transition, 0, C * sizeof(uint32_t)) != hipSuccess) return fail(DHMC_ERR_HIP);
+    if (cfg->target >= DHMC_TARGET_USER_BASE) {
+        // the caller's functor: its parameters to the device, its kernels from the cache or from hiprtc
+        const size_t nb = (size_t)cfg->target_params_bytes;
+        if (nb) {
+            if (hipMalloc(&c->d_user_params, nb) != hipSuccess) return fail(DHMC_ERR_HIP);
+            c->allocs.push_back(c->d_user_params);
+            if (hipMemcpy(c->d_user_params, cfg->target_params, nb, hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
+        }
+        c->tp.a = (const double*)c->d_user_params;
+        c->tp.n = (int64_t)(nb / sizeof(double));
+        std::lock_guard<std::mutex> lock(g_user_mutex);
+        UserTarget& U = g_user_targets[cfg->target - DHMC_TARGET_USER_BASE];
+        const auto key = std::make_pair((int)cfg->device, c->NPL);
+        auto it = U.built.find(key);
+        if (it == U.built.end()) {
+            std::vector<char> code;
+            std::string low[4];
+            if ((rc = rtc_compile(U.source, U.name, c->NPL, &code, &low))) return fail(rc);
+            UserKernels K;
+            if (hipModuleLoadData(&K.mod, code.data()) != hipSuccess) return fail(DHMC_ERR_HIP);
+            if (hipModuleGetFunction(&K.run_lds, K.mod, low[0].c_str()) != hipSuccess || hipModuleGetFunction(&K.run, K.mod, low[1].c_str()) != hipSuccess ||
+                hipModuleGetFunction(&K.init, K.mod, low[2].c_str()) != hipSuccess || hipModuleGetFunction(&K.search, K.mod, low[3].c_str()) != hipSuccess)
+                return fail(DHMC_ERR_HIP);
+            it = U.built.emplace(key, K).first;
+        }
+        c->user = &it->second;
+    }
     if (cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL) {
         std::vector<double> a(Dp, 0.0), b(Dp, 0.0);
         const double* src = (const double*)cfg->target_params;
@@ -498,6 +616,28 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     *out = c;
     return DHMC_OK;
 }
+
+int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle) {
+    if (!hip_source || !functor_name || !*functor_name || !target_handle) return DHMC_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_user_mutex);
+    g_user_targets.push_back(UserTarget{hip_source, functor_name, {}});
+    *target_handle = (int32_t)g_user_targets.size() - 1;
+    return DHMC_OK;
+}
+int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, char* log, uint64_t log_bytes) {
+    if (!hip_source || !functor_name) return DHMC_ERR_INVALID_ARGUMENT;
+    const int npl = npl_for_user_dim(dim);
+    if (npl == 0) return DHMC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_user_mutex);
+    const int rc = rtc_compile(hip_source, functor_name, npl, nullptr, nullptr);
+    if (log && log_bytes) {
+        const size_t n = std::min<size_t>(g_rtc_log.size(), (size_t)log_bytes - 1);
+        std::memcpy(log, g_rtc_log.data(), n);
+        log[n] = '\0';
+    }
+    return rc;
+}
+const char* dhmc_target_source_log(void) { return g_rtc_log.c_str(); }
 
 int dhmc_host_alloc(void** out, uint64_t nbytes) {
     if (!out) return DHMC_ERR_INVALID_ARGUMENT;

@@ -103,6 +103,10 @@ extern "C" {
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
                                     * (dhmc_set_logdensity_callback); dim <= 4096 with the diagonal metric, <= 1024 with
                                     * the dense one (the built-in families: dim <= 1024). params: none */
+#define DHMC_TARGET_USER_BASE 1000  /* + the handle dhmc_register_target_source returned: the caller's own DEVICE FUNCTOR, compiled at run
+                                    * time into the library's own per-draw, initialisation and step-size-search kernels — no host round
+                                    * trip per leapfrog, the same kernels the built-in families run.  Diagonal metric, dim <= 1024.
+                                    * params: any number of doubles, handed to the functor's constructor (TargetParams::a, n = count). */
 #define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
 
 /* ---- kinetic energy (GaussianKineticEnergy, hamiltonian.jl:56-87) -------------------- */
@@ -174,6 +178,23 @@ typedef struct dhmc_outputs {
  * memory (hipHostMalloc) for callers that cannot allocate it themselves; any page-locked memory works the same. */
 int dhmc_host_alloc(void** out, uint64_t nbytes);
 int dhmc_host_free(void* p);
+
+/* ---- the caller's log density as a device functor (LogDensityProblems.logdensity_and_gradient, hamiltonian.jl:204) ------
+ * hip_source: HIP C++ that defines, in namespace dhmc, a struct `functor_name` with the interface of the built-in families
+ * (csrc/targets.hpp; INTEGRATION.md §4 shows one in full):
+ *     static constexpr bool kDeferred, kElementwise, kPointwiseGrad, kRecomputeGrad, kBigDims (= false),
+ *                           kFiniteLqImpliesFiniteQ, kFiniteLqImpliesFiniteGrad;
+ *     __device__ explicit functor_name(const TargetParams& p);           // p.a: the context's params (doubles, device), p.n: how many
+ *     template <int NPL> __device__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const;
+ *     __device__ double finish(double s) const;                          // ℓ from the wave-reduced sum when kDeferred
+ * Lane l holds coordinates l, l+64, … (slot k <-> coordinate l + 64 k; pads are 0); eval fills g = ∇ℓ(q) and returns ℓ (or the
+ * lane's partial sum of it).  The source is compiled with hiprtc (-O3 -ffp-contract=off, as the library itself) against the
+ * library's kernel templates when a context is created with target = DHMC_TARGET_USER_BASE + *target_handle; compile errors come
+ * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().
+ * dhmc_check_target_source compiles only (no device needed) for `dim` coordinates and returns the log. */
+int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle);
+int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, char* log, uint64_t log_bytes);
+const char* dhmc_target_source_log(void);   /* the log of the last run-time compilation in this process */
 
 /* ---- lifecycle ----------------------------------------------------------------------- */
 int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out);

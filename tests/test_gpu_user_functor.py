@@ -1,0 +1,64 @@
+"""GPU: `north_star` — "the user ∇log π is supplied as a device function".  A functor a caller wrote (tests/user_functors.py) is
+compiled at run time into nuts_run_kernel / init_kernel / stepsize_search_kernel (dhmc_register_target_source) and runs with no
+host round trip per leapfrog."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import user_functors as uf
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+@pytest.mark.parametrize("D", [5, 200, 1000])
+def test_user_written_diag_normal_is_bit_equal_to_the_builtin_family_and_the_oracle(pkg, D):
+    rng = np.random.default_rng(D)
+    mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
+    user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
+    C = 6
+
+    def steps(ctx):
+        out = {}
+        ctx.init(); ctx.find_initial_stepsize()
+        out["eps0"] = ctx.stepsize()
+        a = ctx.run(25, da={})
+        ctx.update_metric_diag(a["draws"])
+        out.update({"w_" + k: v for k, v in a.items()})
+        out.update({"i_" + k: v for k, v in ctx.run(12).items()})
+        q, lq, g = ctx.position()
+        out.update(q=q, lq=lq, g=g)
+        return out
+    a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
+    b = steps(pkg.DeviceContext(D, C, target=ol.TARGET_DIAG_NORMAL, target_params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3))
+    o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3, threads=6))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], o[k]), k
+
+
+def test_a_model_of_the_callers_own_through_mcmc_with_warmup(pkg):
+    """Independent Student-t(5) coordinates with scales 0.5 … 4: no built-in family; posterior moments from the drop-in API."""
+    D, nu = 12, 5.0
+    scale = np.linspace(0.5, 4.0, D)
+    l = pkg.DeviceFunctorLogDensity(D, uf.STUDENT_T, "StudentT", params=np.concatenate([[nu], scale]))
+    r = pkg.mcmc_with_warmup(7, l, 1500, chains=64, reporter=pkg.NoProgressReport())
+    x = r["posterior_matrix"].reshape(-1, D)
+    sd = scale * np.sqrt(nu / (nu - 2))
+    assert np.abs(x.mean(0) / sd).max() < 0.06
+    assert np.abs(x.std(0) / sd - 1).max() < 0.12
+    assert 0.6 < r["tree_statistics"].acceptance_rate.mean() < 0.97
+    r2 = pkg.mcmc_with_warmup(7, l, 1500, chains=64, reporter=pkg.NoProgressReport())
+    assert np.array_equal(r["posterior_matrix"], r2["posterior_matrix"])
+
+
+def test_a_broken_functor_fails_at_create_with_the_compilers_log(pkg):
+    l = pkg.DeviceFunctorLogDensity(4, uf.BROKEN, "Broken")
+    with pytest.raises(Exception):
+        pkg.DeviceContext(4, 2, target=l.family)
+    assert b"undeclared_thing" in pkg.abi.lib().dhmc_target_source_log()

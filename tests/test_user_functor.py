@@ -1,0 +1,28 @@
+"""CPU: a caller's device functor compiles against the library's kernel templates with hiprtc (no GPU needed for the compile
+step: dhmc_check_target_source); a broken one comes back with the compiler's log.  The run itself: tests/test_gpu_user_functor.py."""
+import pytest
+
+import user_functors as uf
+from __graft_entry__ import load_package
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+@pytest.mark.parametrize("dim", [3, 100, 1000])
+def test_user_functors_compile_into_the_kernels(pkg, dim):
+    for src, name in ((uf.DIAG_NORMAL, "MyDiagNormal"), (uf.STUDENT_T, "StudentT")):
+        ok, log = pkg.DeviceFunctorLogDensity.check(dim, src, name)
+        assert ok, log
+
+
+def test_compile_errors_come_back_with_the_log(pkg):
+    ok, log = pkg.DeviceFunctorLogDensity.check(10, uf.BROKEN, "Broken")
+    assert not ok
+    assert "undeclared_thing" in log
+    ok, log = pkg.DeviceFunctorLogDensity.check(10, uf.DIAG_NORMAL, "NoSuchStruct")
+    assert not ok and "NoSuchStruct" in log
+    ok, _ = pkg.DeviceFunctorLogDensity.check(5000, uf.DIAG_NORMAL, "MyDiagNormal")      # beyond 1024 coordinates: unsupported
+    assert not ok
