@@ -592,11 +592,21 @@ def mcmc_next_step(steps, Q=None):
     """mcmc.jl:348-351: one transition of every chain from Q (default: where the chains are); returns (Q′, tree statistics
     of that transition)."""
     ctx = steps.slogd.ctx
-    if Q is not None and not np.array_equal(ctx.position()[0], np.asarray(Q.q)):
-        ctx.set_position(Q.q)                                   # a Q of the caller's own: evaluate it, keep κ, ϵ and the streams
+    # A Q that is the context's own last state (the object this function returned, or equal arrays) costs no copy; a Q of
+    # the caller's own is evaluated on the device — strictly, as dhmc_init does, where the reference would trust its ℓq and
+    # ∇ℓq (mcmc.jl:348-351): a stated deviation, the position is what defines the step.
+    last = getattr(steps, "_last_Q", None)
+    if Q is not None and Q is not last and not (last is not None and np.array_equal(last.q, np.asarray(Q.q))):
+        if last is not None or not np.array_equal(ctx.position()[0], np.asarray(Q.q)):
+            ctx.set_position(Q.q)
     draws, ts, lds, _ = _collect(ctx.run(1))
     q, lq, g = ctx.position()
-    return EvaluatedLogDensity(q, lq, g), ts
+    out = EvaluatedLogDensity(q, lq, g)
+    try:
+        steps._last_Q = out
+    except AttributeError:
+        pass
+    return out, ts
 
 
 def stack_posterior_matrices(results):

@@ -24,8 +24,9 @@ def count_terminations(tree_statistics):
 
 
 def count_depths(tree_statistics):
-    """diagnostics.jl:87-95."""
-    return dict(sorted(Counter(np.asarray(tree_statistics.depth).ravel().tolist()).items()))
+    """diagnostics.jl:87-95: element d is the number of trees of depth d (0 … the deepest seen), as the reference's Vector{Int}
+    and as the device flavour returns it."""
+    return np.bincount(np.asarray(tree_statistics.depth).ravel().astype(np.int64)).tolist()
 
 
 def summarize_tree_statistics(tree_statistics):

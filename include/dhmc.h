@@ -101,8 +101,11 @@ extern "C" {
 #endif
 #define DHMC_TARGET_DENSE_NORMAL 6 /* l = -1/2 (q-mu)'P(q-mu), P full symmetric (read from its upper triangle). params: double mu[D], P[D][D] */
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
-                                    * (dhmc_set_logdensity_callback); dim <= 4096 with the diagonal metric, <= 1024 with
-                                    * the dense one (the built-in families: dim <= 1024). params: none */
+                                    * (dhmc_set_logdensity_callback); dim <= 4096, diagonal or shared dense metric. params: none */
+/* Dimension limits.  dim <= 1024: every family, every metric (register/LDS-resident kernels, GEMM round engines).
+ * 1024 < dim <= 4096: DHMC_TARGET_EXTERNAL and the three normal families (STD / DIAG / TRIDIAG), diagonal or shared dense
+ * metric, through the streaming round engine (for the normal families the library evaluates the density itself where the
+ * callback would stand; dhmc_set_logdensity_callback is then DHMC_ERR_INVALID_ARGUMENT).  Everything else: DHMC_ERR_UNSUPPORTED. */
 #define DHMC_TARGET_USER_BASE 1000  /* + the handle dhmc_register_target_source returned: the caller's own DEVICE FUNCTOR, compiled at run
                                     * time into the library's own per-draw, initialisation and step-size-search kernels — no host round
                                     * trip per leapfrog, the same kernels the built-in families run.  Diagonal metric, dim <= 1024.

@@ -219,3 +219,23 @@ def test_config5_full_size_bit_exact_against_oracle(pkg):
             assert np.array_equal(a[k][off:off + 1], b[k]), (off, k)
         qo, lqo, go = ora.position()
         assert np.array_equal(q[off:off + 1], qo) and np.array_equal(lq[off:off + 1], lqo) and np.array_equal(g[off:off + 1], go)
+
+
+def test_bench_launches_its_own_ranks():
+    """a plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N ranks itself, one per
+    GPU (torch.distributed.run on 127.0.0.1), and rank 0 prints the one JSON line with n_gpus = N.  On this 1-GPU box the two
+    ranks share the device: the collectives then run over gloo (RCCL refuses two ranks on one GPU), everything else — chain
+    sharding by chain_offset, barrier + max-over-ranks timing, the gather of the last draws — is the 8-GPU path."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--chains", "2048", "--steps", "2", "--warmup", "1",
+                        "--transitions", "40", "--short-warmup", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["chains_per_gpu"] == 2048
+    assert d["config"]["collective_backend"] in ("gloo", "nccl")
+    assert "2048 chains" in d["config"]["workload"]
+    assert d["value"] > 1e7 and d["scaling"] == "weak"

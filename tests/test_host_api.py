@@ -106,7 +106,7 @@ def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8,
     e = pkg.diagnostics.EBFMI(ts)
     assert ((1.8 < e) & (e < 2.2)).all()
     s = pkg.diagnostics.summarize_tree_statistics(ts)
-    assert s["N"] == 20000 and sum(s["termination_counts"].values()) == 20000 and sum(s["depth_counts"].values()) == 20000
+    assert s["N"] == 20000 and sum(s["termination_counts"].values()) == 20000 and sum(s["depth_counts"]) == 20000
     x = rng.normal(size=(4, 2000))
     ess, rhat = ess_reference.ess_rhat(x)
     assert 6000 < ess < 10000 and abs(rhat - 1) < 0.01
