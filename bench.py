@@ -7,8 +7,8 @@ step size search, 900 dual-averaging transitions with per-chain diagonal metric 
 25/50/100/200/400 windows, mcmc.jl:415-425) so the timed region runs at adapted per-chain ϵ and M⁻¹.
 
 One "step" = one dhmc_run call = one pass of the per-draw loop (mcmc.jl:374-379) of
-`--transitions` NUTS transitions (default 500: ≈0.1 s of GPU work, so that K = 10..20 timed steps
-are a second or more) for every chain, draws and tree statistics written to buffers already
+`--transitions` NUTS transitions (default 1000: ≈0.2 s of GPU work, so that K = 10..20 timed steps
+are several seconds of GPU activity) for every chain, draws and tree statistics written to buffers already
 resident in HBM.  value = Σ leapfrog steps of all chains and ranks ÷ wall time of the K timed steps
 (barrier + synchronize on both sides, max over ranks).  The warmup phase (adaptation on, metric
 updates included) is timed separately during setup and reported as `warmup_phase`.
@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--transitions", type=int, default=None, help="NUTS transitions per chain per step (default 500 for config 2, 20 otherwise)")
+    ap.add_argument("--transitions", type=int, default=None, help="NUTS transitions per chain per step (default 1000 for config 2, 20 otherwise)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--short-warmup", action="store_true", help="65-transition adaptive setup instead of the reference's 900")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -313,7 +313,7 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     if args.transitions is None:
-        args.transitions = 500 if args.config == 2 else 20
+        args.transitions = 1000 if args.config == 2 else 20
     if args.config == 3:
         return bench_config3(args, pkg, torch)
     if args.config in (4, 5):

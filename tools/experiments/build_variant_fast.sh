@@ -12,6 +12,6 @@ OBJ=$ROOT/dynamichmc.jl_amd/lib/obj
 FLAGS="-O3 -std=c++17 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wno-unused-result"
 (cd $ROOT/dynamichmc.jl_amd/csrc && /opt/rocm/bin/hipcc $FLAGS -DDHMC_FAMILY=$FAM "$@" -c -o $D/family_$FAM.o family.hip)
 OTHERS=$(ls $OBJ/*.o | grep -v "family_$FAM.o")
-/opt/rocm/bin/hipcc $FLAGS -shared -o $D/libdhmc_amd.so $OTHERS $D/family_$FAM.o
+/opt/rocm/bin/hipcc $FLAGS -shared -o $D/libdhmc_amd.so $OTHERS $D/family_$FAM.o -lhiprtc
 rm -f $D/family_$FAM.o
 ls -la $D/libdhmc_amd.so
