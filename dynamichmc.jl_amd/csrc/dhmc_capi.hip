@@ -35,7 +35,7 @@ using namespace dhmc;
 namespace {
 struct UserKernels {
     hipModule_t mod = nullptr;
-    hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr;
+    hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr, probe_traj = nullptr, probe_ratio = nullptr;
 };
 struct UserTarget {
     std::string source, name;
@@ -51,15 +51,17 @@ const char* rtc_prelude() {
            "typedef unsigned long long uint64_t; typedef long long int64_t;\n";
 }
 // compile `source` (which defines dhmc::`name`) with the kernel templates for one chain width; *code receives the code object
-int rtc_compile(const std::string& source, const std::string& name, int npl, std::vector<char>* code, std::string (*lowered)[4]) {
+constexpr int kRtcKernels = 6;
+int rtc_compile(const std::string& source, const std::string& name, int npl, std::vector<char>* code, std::string (*lowered)[kRtcKernels]) {
     std::string src = rtc_prelude();
     src += dhmc_rtc_headers;
     src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
     src += source;
     src += "\n";
     const std::string T = "dhmc::" + name, N = std::to_string(npl);
-    const std::string exprs[4] = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
-                                  "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">"};
+    const std::string exprs[kRtcKernels] = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
+                                            "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
+                                            "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
     for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
@@ -74,7 +76,7 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, std
         rc = DHMC_ERR_INVALID_ARGUMENT;
     } else {
         if (lowered)
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kRtcKernels; ++i) {
                 const char* low = nullptr;
                 if (hiprtcGetLoweredName(prog, exprs[i].c_str(), &low) != HIPRTC_SUCCESS || !low) { rc = DHMC_ERR_HIP; break; }
                 (*lowered)[i] = low;
@@ -231,6 +233,12 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
         }
         case Op::Init: f = c->user->init; break;
         case Op::Search: f = c->user->search; lds = (unsigned)(sizeof(double) * c->Dpad); break;
+        case Op::ProbeTrajectory: case Op::ProbeRatios: {     // Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios
+            DenseMetric none{};
+            void* pargs[] = {const_cast<void*>(P), &none};
+            return hipModuleLaunchKernel(op == Op::ProbeTrajectory ? c->user->probe_traj : c->user->probe_ratio, (unsigned)c->cfg.chains, 1, 1,
+                                         WAVE, 1, 1, (unsigned)(sizeof(double) * c->Dpad), cs, pargs, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+        }
         default: return DHMC_ERR_UNSUPPORTED;
         }
         void* args[] = {const_cast<void*>(P)};
@@ -482,12 +490,13 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         auto it = U.built.find(key);
         if (it == U.built.end()) {
             std::vector<char> code;
-            std::string low[4];
+            std::string low[kRtcKernels];
             if ((rc = rtc_compile(U.source, U.name, c->NPL, &code, &low))) return fail(rc);
             UserKernels K;
             if (hipModuleLoadData(&K.mod, code.data()) != hipSuccess) return fail(DHMC_ERR_HIP);
             if (hipModuleGetFunction(&K.run_lds, K.mod, low[0].c_str()) != hipSuccess || hipModuleGetFunction(&K.run, K.mod, low[1].c_str()) != hipSuccess ||
-                hipModuleGetFunction(&K.init, K.mod, low[2].c_str()) != hipSuccess || hipModuleGetFunction(&K.search, K.mod, low[3].c_str()) != hipSuccess)
+                hipModuleGetFunction(&K.init, K.mod, low[2].c_str()) != hipSuccess || hipModuleGetFunction(&K.search, K.mod, low[3].c_str()) != hipSuccess ||
+                hipModuleGetFunction(&K.probe_traj, K.mod, low[4].c_str()) != hipSuccess || hipModuleGetFunction(&K.probe_ratio, K.mod, low[5].c_str()) != hipSuccess)
                 return fail(DHMC_ERR_HIP);
             it = U.built.emplace(key, K).first;
         }
@@ -1542,6 +1551,49 @@ int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t cha
         if (hipMemcpyAsync(rhat + j, dr.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
     }
     if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
+    return DHMC_OK;
+}
+
+int dhmc_ess_tail(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess) {
+    if (!draws || !coords || !ess || chains < 1 || n < 8 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
+    const int64_t half = n / 2, N2 = 2 * half, S = chains * N2, C2 = 2 * chains;
+    if (half > 7680 || S > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
+    for (int i = 0; i < ncoords; ++i)
+        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dk, dk2, di, di2, dz, da, dm, de, dr, dtmp, dc0;
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
+                                           (int32_t*)nullptr, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
+    const int32_t zero = 0;
+    if (hipMalloc(&dk.p, sizeof(double) * S) != hipSuccess || hipMalloc(&dk2.p, sizeof(double) * S) != hipSuccess ||
+        hipMalloc(&di.p, sizeof(int32_t) * S) != hipSuccess || hipMalloc(&di2.p, sizeof(int32_t) * S) != hipSuccess ||
+        hipMalloc(&dz.p, sizeof(double) * S) != hipSuccess || hipMalloc(&da.p, sizeof(double) * S) != hipSuccess ||
+        hipMalloc(&dm.p, sizeof(double) * C2) != hipSuccess || hipMalloc(&de.p, sizeof(double) * 2) != hipSuccess ||
+        hipMalloc(&dr.p, sizeof(double)) != hipSuccess || hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess ||
+        hipMalloc(&dc0.p, sizeof(int32_t)) != hipSuccess)
+        return DHMC_ERR_HIP;
+    if (hipMemcpyAsync(dc0.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    std::vector<double> both((size_t)ncoords * 2);
+    for (int j = 0; j < ncoords; ++j) {
+        hipLaunchKernelGGL(ess_gather_kernel, dim3(nb), dim3(256), 0, s, draws, n, dim, coords[j], chains, N2, (double*)dk.p, (int32_t*)di.p);
+        if (hipcub::DeviceRadixSort::SortPairs(dtmp.p, tmp_bytes, (const double*)dk.p, (double*)dk2.p, (const int32_t*)di.p,
+                                               (int32_t*)di2.p, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
+        for (int upper = 0; upper < 2; ++upper) {
+            hipLaunchKernelGGL(ess_tail_indicator_kernel, dim3(nb), dim3(256), 0, s, (const double*)dk2.p, (const int32_t*)di2.p, S, upper, (double*)dz.p);
+            hipLaunchKernelGGL(ess_acov_kernel, dim3(1, (unsigned)C2), dim3(ESS_THREADS), sizeof(double) * half, s, (const double*)dz.p, half,
+                               (int64_t)1, (const int32_t*)dc0.p, C2, (double*)da.p, (double*)dm.p);
+            hipLaunchKernelGGL(ess_finish_kernel, dim3(1), dim3(ESS_THREADS), sizeof(double) * half, s, (const double*)da.p,
+                               (const double*)dm.p, half, C2, (double*)de.p + upper, (double*)dr.p);
+        }
+        if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
+        if (hipMemcpyAsync(both.data() + 2 * j, de.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
+        if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;     // (de is reused by the next coordinate)
+    }
+    for (int j = 0; j < ncoords; ++j) ess[j] = std::min(both[2 * j], both[2 * j + 1]);
     return DHMC_OK;
 }
 

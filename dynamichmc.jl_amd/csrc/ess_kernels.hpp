@@ -128,4 +128,20 @@ __global__ void ess_rank_kernel(const double* __restrict__ skeys, const int32_t*
     z[sidx[r]] = normcdfinv((rank - 0.375) / ((double)S + 0.25));
 }
 
+// ---- tail ESS (Vehtari et al. 2021, §4.3; MCMCDiagnosticTools ess(kind = :tail)): the smaller of the ESS of the indicators
+// I(x <= q₀.₀₅) and I(x >= q₀.₉₅) over the split chains, q the 5 % / 95 % quantile of all S draws of the coordinate (type 7, as
+// Statistics.quantile) read from the sorted keys of the rank pass. ----------------------------------------------------------
+__global__ void ess_tail_indicator_kernel(const double* __restrict__ skeys, const int32_t* __restrict__ sidx, int64_t S, int upper,
+                                          double* __restrict__ z) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S) return;
+    const double h = (double)(S - 1) * (upper ? 0.95 : 0.05);
+    const int64_t lo = (int64_t)h;
+    const double frac = h - (double)lo;
+    const double a = skeys[lo], b = skeys[lo + 1 < S ? lo + 1 : lo];
+    const double q = a + frac * (b - a);
+    const double key = skeys[r];
+    z[sidx[r]] = (upper ? key >= q : key <= q) ? 1.0 : 0.0;
+}
+
 }  // namespace dhmc

@@ -82,7 +82,8 @@ def ess_bulk_device(draws, coords=None, kind="bulk"):
     """ESS and R-hat per coordinate for draws [C][N][D] held in HBM (a CUDA torch tensor), computed where they lie by
     the library's HIP kernels (csrc/ess_kernels.hpp), so ESS/s can be reported without shipping the draws to the host
     (SURVEY.md §8 f-3).  kind = "bulk": rank-normalised split-chain bulk ESS (`dhmc_ess_bulk`, the estimator of
-    tests/ess_reference.py ess_bulk); "plain": no split, no rank normalisation (`dhmc_ess_rhat`).
+    tests/ess_reference.py ess_bulk); "plain": no split, no rank normalisation (`dhmc_ess_rhat`); "tail": the smaller of the
+    ESS of the 5 % and 95 % quantile indicators over the split chains (`dhmc_ess_tail`; R-hat is NaN for this kind).
     Returns numpy arrays (ess [k], rhat [k])."""
     import ctypes as C_
     from . import _abi as abi
@@ -93,6 +94,13 @@ def ess_bulk_device(draws, coords=None, kind="bulk"):
         coords.cpu().numpy() if hasattr(coords, "cpu") else coords, np.int32)
     ess = np.zeros(idx.size); rhat = np.zeros(idx.size)
     import torch
+    if kind == "tail":
+        rc = abi.lib().dhmc_ess_tail(C_.c_int32(draws.device.index or 0), C_.c_void_p(torch.cuda.current_stream(draws.device).cuda_stream),
+                                     C_.c_void_p(draws.data_ptr()), C_.c_int64(Cn), C_.c_int64(N), C_.c_int64(D),
+                                     C_.c_void_p(idx.ctypes.data), C_.c_int32(idx.size), C_.c_void_p(ess.ctypes.data))
+        if rc != abi.OK:
+            raise RuntimeError(f"dhmc_ess_tail: {abi.ERROR_NAMES.get(rc, rc)}")
+        return ess, np.full(idx.size, np.nan)
     fn = abi.lib().dhmc_ess_bulk if kind == "bulk" else abi.lib().dhmc_ess_rhat
     rc = fn(C_.c_int32(draws.device.index or 0), C_.c_void_p(torch.cuda.current_stream(draws.device).cuda_stream),
                                  C_.c_void_p(draws.data_ptr()), C_.c_int64(Cn), C_.c_int64(N), C_.c_int64(D),

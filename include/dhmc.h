@@ -321,6 +321,10 @@ int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t cha
  * n/2 <= 7680. */
 int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
+/* Tail ESS (Vehtari et al. 2021; MCMCDiagnosticTools ess(kind = :tail)): the smaller of the ESS of I(x <= q5%) and I(x >= q95%)
+ * over the split chains, the quantiles (type 7) taken over all draws of the coordinate.  Same limits as dhmc_ess_bulk. */
+int dhmc_ess_tail(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
+                  const int32_t* coords, int32_t ncoords, double* ess);
 
 /* Post-hoc NUTS diagnostics over the SoA tree statistics of dhmc_run (DynamicHMC.Diagnostics, diagnostics.jl:29-106), all
  * [chains][n] arrays as dhmc_outputs writes them (device pointers if on_device, so 4096 x 1000 statistics need not

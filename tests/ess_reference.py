@@ -42,6 +42,18 @@ def ess_bulk(x):
 
 
 
+def ess_tail(x):
+    """Tail ESS of one scalar, x [C][N] (Vehtari et al. 2021 §4.3; MCMCDiagnosticTools ess(kind = :tail)): split every chain in
+    two, the indicators of the pooled 5 % and 95 % quantiles, the plain estimator on each, the smaller of the two.  Host
+    flavour of `dhmc_ess_tail`."""
+    x = np.asarray(x, np.float64)
+    C, N = x.shape
+    h = N // 2
+    xs = x[:, :2 * h].reshape(2 * C, h)
+    q05, q95 = np.quantile(xs.ravel(), [0.05, 0.95])
+    return min(ess_rhat((xs <= q05).astype(np.float64))[0], ess_rhat((xs >= q95).astype(np.float64))[0])
+
+
 def ess_bulk_torch(draws, coords=None):
     """The same estimator with torch FFTs — an independent cross-check of the HIP kernels (tests only)."""
     import torch

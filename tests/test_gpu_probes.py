@@ -161,6 +161,12 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
             eh, rh = ess_reference.ess_bulk(xt[:, :, j])
             assert np.isclose(eb[k], eh, rtol=1e-7), (C, N, j, eb[k], eh)
             assert np.isclose(rb[k], rh, rtol=1e-9)
+        # tail ESS: indicators of the pooled 5 % / 95 % quantiles over the split chains (dhmc_ess_tail)
+        if N >= 100:
+            et, _ = pkg.diagnostics.ess_bulk_device(tt, coords, kind="tail")
+            for k, j in enumerate(coords):
+                eh = ess_reference.ess_tail(xt[:, :, j])
+                assert np.isclose(et[k], eh, rtol=1e-7), (C, N, j, et[k], eh)
     with pytest.raises(RuntimeError):
         pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"), kind="plain")   # n < 4
 

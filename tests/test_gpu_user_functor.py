@@ -62,3 +62,21 @@ def test_a_broken_functor_fails_at_create_with_the_compilers_log(pkg):
     with pytest.raises(Exception):
         pkg.DeviceContext(4, 2, target=l.family)
     assert b"undeclared_thing" in pkg.abi.lib().dhmc_target_source_log()
+
+
+def test_diagnostics_probes_of_a_user_functor_equal_the_builtin_family(pkg):
+    """Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios (diagnostics.jl:144-227) for the caller's functor: the probe
+    kernels are compiled from its source as well."""
+    D, C = 130, 4
+    rng = np.random.default_rng(1)
+    mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
+    user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
+    a = pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=9)
+    b = pkg.DeviceContext(D, C, target=ol.TARGET_DIAG_NORMAL, target_params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=9)
+    for ctx in (a, b):
+        ctx.init(); ctx.find_initial_stepsize(); ctx.run(5, da={})
+    ta, tb = a.leapfrog_trajectory(0.1, -5, 7, momentum_index=2), b.leapfrog_trajectory(0.1, -5, 7, momentum_index=2)
+    for k in ("delta", "logdensity", "q", "p", "range"):
+        assert np.array_equal(ta[k], tb[k]), k
+    ra, rb = a.explore_log_acceptance_ratios([0.05, 0.2, 0.8], n_momenta=6), b.explore_log_acceptance_ratios([0.05, 0.2, 0.8], n_momenta=6)
+    assert np.array_equal(ra, rb)
