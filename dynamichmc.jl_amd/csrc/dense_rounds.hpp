@@ -45,6 +45,7 @@ struct TreeState {
     int32_t phase, n;
     uint32_t tr, dirs, directions0, j, nleaf, nrand, status;
     int32_t depth, dir, reg_edge, stored0, stored1, zeta_top, init_slot;
+    int32_t k2_done, pad_;       // K3b has already done K2's work for the chain's next leapfrog (RunParams::fuse_k2)
     int64_t i, i_minus, i_plus, term_left, term_right, vtop_steps;
     uint64_t free_mask;
     unsigned long long total_steps;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
         S.j = 0;
         S.nleaf = 1;
         S.eps_s = eps_s;
+        S.k2_done = 0;
         S.phase = PH_LEAF;
     }
 }
@@ -194,7 +196,7 @@ template <class T, int NPL>
 __global__ __launch_bounds__(64) void rounds_k2_kernel(RunParams P, RoundBuffers R) {
     const int chain = P.chain_base + blockIdx.x, lane = threadIdx.x;
     TreeState& S = R.ts[chain];
-    if (S.phase != PH_LEAF) return;
+    if (S.phase != PH_LEAF || S.k2_done) return;     // (k2_done: K3b did this step when it finished the previous leaf)
     const T tgt(P.tp);
     const size_t row = (size_t)chain * P.Dpad;
     const double eps_s = S.eps_s, h = eps_s / 2;

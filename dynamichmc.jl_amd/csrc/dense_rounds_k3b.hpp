@@ -56,6 +56,8 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     if (R.ts[chain].phase != PH_LEAF) return;
     __shared__ TreeState S;
     __shared__ double xch[6][K3B_WPC][WAVE];
+    __shared__ double qedge[K3B_WPC][2];         // fused K2: first / last coordinate of every wave's block of q′
+    __shared__ int fin_flag;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&R.ts[chain]);
@@ -98,15 +100,19 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     double eps_s = uni_f64(S.eps_s), omega_top = uni_f64(S.omega_top), vtop_lsa = uni_f64(S.vtop_lsa), lq_cur = uni_f64(S.lq_cur);
     DAState da = S.da;
 
-    double p[NT], ps[NT], cf[NT], cfs[NT], cr[NT];
+    double p[NT], ps[NT], cf[NT], cfs[NT], cr[NT], u[NT];
     ldv<NT>(cp_row, lane, p);
     double* const cps_row = R.cps + row + off;
     double* const cu_row = R.cu + row + off;
+    constexpr bool CAN_FUSE = BlockEval<T>::value;
+    const bool fuse = CAN_FUSE && P.fuse_k2 && P.one_product;
+    int32_t k2_done = 0;
+    double lq_next = 0.0;
     if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (dense_rounds.hpp)
         const double h = eps_s / 2;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) ps[k] = cps_row[lane + WAVE * k] + h * cu_row[lane + WAVE * k];
-        stv<NT>(cps_row, lane, ps);
+        for (int k = 0; k < NT; ++k) { u[k] = cu_row[lane + WAVE * k]; ps[k] = cps_row[lane + WAVE * k] + h * u[k]; }
+        if (!fuse) stv<NT>(cps_row, lane, ps);       // (fused: the row receives the next M⁻¹pₘ at the end instead)
     } else {
         ldv<NT>(cps_row, lane, ps);
     }
@@ -400,7 +406,11 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 copy_row(wsv(qsrc), q_row);
                 copy_row(wsv(gsrc), g_row);
                 ldv<NT>(wsv(wd_top(nfwd ? 2 : 0)), lane, p);
-                if (P.one_product) {                 // the edge's p♯ and u travel with it
+                if (fuse) {                          // the edge's p♯ and u travel with it: in registers here
+                    stv<NT>(wsv(wd_edge_u(max_depth, reg_edge)), lane, u);
+                    ldv<NT>(wsv(have ? wd_edge_u(max_depth, ndir) : wd_u0(max_depth)), lane, u);
+                    ldv<NT>(wsv(wd_top(nfwd ? 3 : 1)), lane, ps);
+                } else if (P.one_product) {
                     copy_row(cu_row, wsv(wd_edge_u(max_depth, reg_edge)));
                     copy_row(wsv(have ? wd_edge_u(max_depth, ndir) : wd_u0(max_depth)), cu_row);
                     copy_row(wsv(wd_top(nfwd ? 3 : 1)), cps_row);
@@ -419,10 +429,61 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
         const double h = eps_s / 2;
 #pragma unroll
         for (int k = 0; k < NT; ++k) p[k] = p[k] + h * g_row[lane + WAVE * k];   // pₘ of the next leapfrog (hamiltonian.jl:277)
+        if constexpr (CAN_FUSE) {
+            if (fuse) {
+                // K2 of the chain's next leapfrog, here (dense_rounds.hpp rounds_k2_kernel, one-product form): the same
+                // operations on the same operands, a wave per 256-coordinate block — the rows q, ∇ℓ, p and M⁻¹pₘ are written once
+                // instead of written by K3, read and written again by K2.
+                const T tgt(P.tp);
+                double t[NT], qv[NT], gv[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    t[k] = ps[k] + h * u[k];                                       // M⁻¹pₘ = p♯ + (ϵ/2)·u
+                    qv[k] = q_row[lane + WAVE * k] + eps_s * t[k];                 // hamiltonian.jl:278
+                }
+                stv<NT>(cps_row, lane, t);
+                double part;
+                if constexpr (T::kElementwise) {
+                    part = tgt.eval(qv, gv, off + lane, D);
+                } else {                                                           // neighbours across the blocks' borders
+                    if (lane == 0) qedge[wave][0] = qv[0];
+                    if (lane == WAVE - 1) qedge[wave][1] = qv[NT - 1];
+                    __syncthreads();
+                    const double left = wave > 0 ? qedge[wave - 1][1] : 0.0;
+                    const double right = wave + 1 < K3B_WPC ? qedge[wave + 1][0] : 0.0;
+                    part = tgt.eval_block(qv, gv, off + lane, lane, D, left, right);
+                }
+                double lsum[1];
+                block_allreduce<1, K3B_WPC>(wave, lane, xch, [&](double (&a)[1]) { a[0] = part; }, lsum);
+                double lq = uni_f64(tgt.finish(lsum[0]));
+                bool pos_finite = true;
+                if (!T::kFiniteLqImpliesFiniteQ || !dm_isfinite(lq)) {            // evaluate_ℓ's position scan (hamiltonian.jl:203)
+                    bool fin = true;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) fin = fin && dm_isfinite(qv[k]);
+                    if (tid == 0) fin_flag = 1;
+                    __syncthreads();
+                    if (!wave_all(fin) && lane == 0) fin_flag = 0;
+                    __syncthreads();
+                    pos_finite = fin_flag != 0;
+                }
+                static_assert(T::kFiniteLqImpliesFiniteGrad, "block evaluation: families whose gradient needs no scan");
+                lq = demote_lq(lq, pos_finite, true);
+                if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
+                lq_next = lq;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) p[k] = p[k] + h * gv[k];             // p′ (hamiltonian.jl:280)
+                stv<NT>(q_row, lane, qv);
+                stv<NT>(g_row, lane, gv);
+                k2_done = 1;
+            }
+        }
         stv<NT>(cp_row, lane, p);
     }
     __syncthreads();
     if (tid == 0) {
+        S.k2_done = k2_done;
+        if (k2_done) S.lq_leaf = lq_next;
         S.nrand = nrand; S.status = status; S.dirs = dirs; S.j = jleaf; S.nleaf = nleaf; S.tr = tr;
         S.depth = depth; S.dir = dir; S.reg_edge = reg_edge; S.stored0 = stored0; S.stored1 = stored1;
         S.zeta_top = zeta_top; S.init_slot = init_slot; S.n = n_done; S.phase = phase;

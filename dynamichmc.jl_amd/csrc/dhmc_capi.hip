@@ -122,6 +122,7 @@ struct dhmc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_joins[4] = {};
     int dense_rounds = 1;
+    int fuse_k2 = 1;           // DHMC_FUSE_K2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
     int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (round engine only)
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
@@ -452,6 +453,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_HOST_CHUNK")) c->host_chunk = std::atoll(e);
+    if (const char* e = std::getenv("DHMC_FUSE_K2")) c->fuse_k2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
@@ -1156,6 +1158,7 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         // (the one-product recurrence exists in this engine only, so it is the engine of every chain count then: results
         // must not depend on how many chains a context holds)
         P.one_product = c->dense_products == 1;
+        P.fuse_k2 = c->fuse_k2;
         // Round-based dense engine (dense_rounds.hpp): every round is one leapfrog for every chain.  The chains
         // run as two half-batches on two streams so that one half's HBM-bound tree kernel overlaps the other
         // half's MFMA-bound contractions.

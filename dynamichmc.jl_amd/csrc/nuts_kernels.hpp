@@ -72,6 +72,8 @@ struct RunParams {
     int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
     int k3_block;                // round engines: K3 as a workgroup per chain (dense_rounds_k3b.hpp) where it applies
     int one_product;             // dense round engine: one M⁻¹ product per leapfrog (dense_rounds.hpp; include/dhmc.h dhmc_set_dense_products)
+    int fuse_k2;                 // … and K3b also takes the chain's next position update and density evaluation (K2's work) where the
+                                 // family can be evaluated a block per wave (targets.hpp BlockEval)
     double min_delta;
     uint64_t seed;
     int64_t N;

@@ -121,6 +121,30 @@ struct TridiagNormalT {
         }
         return acc.fold(0);
     }
+    // The same density over ONE 256-coordinate block of the row, for kernels that spread a chain over a workgroup with a
+    // wave per block (dense_rounds_k3b.hpp): q, g are the block's slots of the lane, e0 the coordinate of the lane's slot 0,
+    // `left` / `right` the coordinates just outside the block (anything where the row ends).  Returns the lane's partial sum
+    // of the block — the fma chain LaneAcc runs over that block in eval() above: same bits.
+    template <int NT>
+    __device__ __forceinline__ double eval_block(const double (&q)[NT], double (&g)[NT], int e0, int lane, int D, double left, double right) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int e = e0 + WAVE * k;
+            const double left_same = __shfl_up(q[k], 1);
+            const double left_prev = (k > 0) ? __shfl(q[k > 0 ? k - 1 : 0], WAVE - 1) : left;
+            const double qm = (lane == 0) ? left_prev : left_same;
+            const double right_same = __shfl_down(q[k], 1);
+            const double right_next = (k + 1 < NT) ? __shfl(q[k + 1 < NT ? k + 1 : k], 0) : right;
+            const double qp = (lane == WAVE - 1) ? right_next : right_same;
+            double t = diag[e] * q[k];
+            if (e > 0 && e < D) t = t + off[e - 1] * qm;
+            if (e < D - 1) t = t + off[e] * qp;
+            acc = __builtin_fma(q[k], t, acc);
+            g[k] = -t;
+        }
+        return acc;
+    }
     __device__ __forceinline__ double finish(double s) const { return -0.5 * s; }
 };
 
@@ -309,6 +333,17 @@ struct ExternalT {
         return dm_nan();
     }
     __device__ __forceinline__ double finish(double s) const { return s; }
+};
+
+// Can the family be evaluated block by block (a wave per 256 coordinates)?  Coordinate-wise targets through eval() with the
+// block's first coordinate as the element base; the tridiagonal normal through eval_block().
+template <class T>
+struct BlockEval {
+    static constexpr bool value = T::kElementwise;
+};
+template <>
+struct BlockEval<TridiagNormalT> {
+    static constexpr bool value = true;
 };
 
 }  // namespace dhmc
