@@ -106,6 +106,25 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     double* const cu_row = R.cu + row + off;
     constexpr bool CAN_FUSE = BlockEval<T>::value;
     const bool fuse = CAN_FUSE && P.fuse_k2 && P.one_product;
+    // ∇ℓ of a stored point (proposal slot, parked edge) is not kept next to its q but re-evaluated from it, a block per wave
+    // (same functor, same bits), for the families where that is cheap: two row copies less per suspended leaf
+    const bool regrad = CAN_FUSE && T::kRecomputeGrad && P.fuse_k2;
+    const T tgt(P.tp);
+    auto eval_blockwise = [&](const double (&qv)[NT], double (&gv)[NT]) -> double {    // the lane's partial sum of ℓ's reduction
+        if constexpr (!CAN_FUSE) {
+            return 0.0;
+        } else if constexpr (T::kElementwise) {
+            return tgt.eval(qv, gv, off + lane, D);
+        } else {                                                                       // neighbours across the blocks' borders
+            __syncthreads();                                                           // (qedge free again)
+            if (lane == 0) qedge[wave][0] = qv[0];
+            if (lane == WAVE - 1) qedge[wave][1] = qv[NT - 1];
+            __syncthreads();
+            const double left = wave > 0 ? qedge[wave - 1][1] : 0.0;
+            const double right = wave + 1 < K3B_WPC ? qedge[wave + 1][0] : 0.0;
+            return tgt.eval_block(qv, gv, off + lane, lane, D, left, right);
+        }
+    };
     int32_t k2_done = 0;
     double lq_next = 0.0;
     if (P.one_product) {                             // p♯′ = M⁻¹pₘ + (ϵ/2)·u′ (dense_rounds.hpp)
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
         int s = __builtin_ctzll(free_mask);
         free_mask &= ~(1ull << s);
         copy_row(q_row, wsv(wd_slot(max_depth, s, 0)));
-        copy_row(g_row, wsv(wd_slot(max_depth, s, 1)));
+        if (!regrad) copy_row(g_row, wsv(wd_slot(max_depth, s, 1)));
         S.sl_lq[s] = lq_leaf;
         S.sl_pi[s] = pi_leaf;
         return s;
@@ -338,8 +357,13 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 for (int k = 0; k < NT; ++k)
                     if (off + lane + WAVE * k < D) drow[lane + WAVE * k] = qv[k];
             }
+            if (regrad) {
+                double gv[NT];
+                (void)eval_blockwise(qv, gv);
+                stv<NT>(g_row, lane, gv);
+            }
         }
-        copy_row(wsv(wd_slot(max_depth, init_slot, 1)), g_row);
+        if (!regrad) copy_row(wsv(wd_slot(max_depth, init_slot, 1)), g_row);
         if (tid == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;
             if (P.out.eps) P.out.eps[o] = eps_used;
@@ -398,13 +422,21 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
             const int ndir = nfwd ? 1 : 0;
             if (reg_edge != ndir) {
                 copy_row(q_row, wsv(wd_edge(reg_edge, 0)));
-                copy_row(g_row, wsv(wd_edge(reg_edge, 1)));
+                if (!regrad) copy_row(g_row, wsv(wd_edge(reg_edge, 1)));
                 if (reg_edge == 1) stored1 = 1; else stored0 = 1;
                 const bool have = nfwd ? (stored1 != 0) : (stored0 != 0);
                 const int qsrc = have ? wd_edge(ndir, 0) : wd_slot(max_depth, init_slot, 0);
                 const int gsrc = have ? wd_edge(ndir, 1) : wd_slot(max_depth, init_slot, 1);
-                copy_row(wsv(qsrc), q_row);
-                copy_row(wsv(gsrc), g_row);
+                if (regrad) {
+                    double qe[NT], ge[NT];
+                    ldv<NT>(wsv(qsrc), lane, qe);
+                    stv<NT>(q_row, lane, qe);
+                    (void)eval_blockwise(qe, ge);
+                    stv<NT>(g_row, lane, ge);
+                } else {
+                    copy_row(wsv(qsrc), q_row);
+                    copy_row(wsv(gsrc), g_row);
+                }
                 ldv<NT>(wsv(wd_top(nfwd ? 2 : 0)), lane, p);
                 if (fuse) {                          // the edge's p♯ and u travel with it: in registers here
                     stv<NT>(wsv(wd_edge_u(max_depth, reg_edge)), lane, u);
@@ -434,7 +466,6 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 // K2 of the chain's next leapfrog, here (dense_rounds.hpp rounds_k2_kernel, one-product form): the same
                 // operations on the same operands, a wave per 256-coordinate block — the rows q, ∇ℓ, p and M⁻¹pₘ are written once
                 // instead of written by K3, read and written again by K2.
-                const T tgt(P.tp);
                 double t[NT], qv[NT], gv[NT];
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
@@ -442,17 +473,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                     qv[k] = q_row[lane + WAVE * k] + eps_s * t[k];                 // hamiltonian.jl:278
                 }
                 stv<NT>(cps_row, lane, t);
-                double part;
-                if constexpr (T::kElementwise) {
-                    part = tgt.eval(qv, gv, off + lane, D);
-                } else {                                                           // neighbours across the blocks' borders
-                    if (lane == 0) qedge[wave][0] = qv[0];
-                    if (lane == WAVE - 1) qedge[wave][1] = qv[NT - 1];
-                    __syncthreads();
-                    const double left = wave > 0 ? qedge[wave - 1][1] : 0.0;
-                    const double right = wave + 1 < K3B_WPC ? qedge[wave + 1][0] : 0.0;
-                    part = tgt.eval_block(qv, gv, off + lane, lane, D, left, right);
-                }
+                const double part = eval_blockwise(qv, gv);
                 double lsum[1];
                 block_allreduce<1, K3B_WPC>(wave, lane, xch, [&](double (&a)[1]) { a[0] = part; }, lsum);
                 double lq = uni_f64(tgt.finish(lsum[0]));
