@@ -115,7 +115,8 @@ class DeviceContext:
     # ---- error mapping ---------------------------------------------------------------------
     def _raise(self, rc, what):
         if rc == abi.ERR_INVALID_ARGUMENT:
-            raise ValueError(f"ArgumentError in {what}")  # the reference's @argcheck failures
+            detail = abi.lib().dhmc_last_error(self.h).decode() if self.h else ""
+            raise ValueError(f"ArgumentError in {what}" + (f": {detail}" if detail else ""))  # the reference's @argcheck failures
         if rc == abi.ERR_CHAIN_FAILURE:
             st = self.status()
             bad = np.nonzero(st)[0]

@@ -1380,6 +1380,7 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
     double* const mean = (double*)bmean.p;
     double* const S = (double*)bS.p;
+    int refused = 0, first_refused = -1;
     for (int k = 0; k < nest && rc == DHMC_OK; ++k) {
         const double* x = (const double*)s.dev + (size_t)k * J * D;
         hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean);
@@ -1388,8 +1389,19 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; break; }
         rc = device_dense_metric(c, S, ld, c->per_chain_dense ? k : -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
+        // per-chain metrics: every chain stands for itself, as in the reference (mcmc.jl:281-285 runs per chain): a chain whose
+        // estimate is refused keeps its metric, the others are updated all the same
+        if (rc == DHMC_ERR_INVALID_ARGUMENT && c->per_chain_dense) {
+            if (refused++ == 0) first_refused = k;
+            rc = DHMC_OK;
+        }
     }
     stage_free(c, &s);
+    if (rc == DHMC_OK && refused) {
+        c->err = "dhmc_update_metric_dense: the covariance estimate of " + std::to_string(refused) + " chain(s) (first: chain " +
+                 std::to_string(first_refused) + ") is not finite / positive definite; those chains keep their metric";
+        return DHMC_ERR_INVALID_ARGUMENT;
+    }
     return rc;
 }
 

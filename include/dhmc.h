@@ -282,7 +282,9 @@ int dhmc_update_metric_diag(dhmc_ctx* ctx, const double* draws, int64_t n, doubl
  * Symmetric(cov(pm; dims=2)), λ)) (mcmc.jl:210,218-222).  The reference estimates one matrix per chain; the
  * dense M⁻¹ of a context is shared, so the draws of all chains are pooled (J = C·n rows, chain-major) — with
  * chains == 1 this is the reference's estimator.  Returns DHMC_ERR_INVALID_ARGUMENT if the estimate is not
- * positive definite (e.g. J <= D with λ = 0). */
+ * positive definite (e.g. J <= D with λ = 0); the metric then stays as it was.  With dense_per_chain = 1 every chain is
+ * estimated and factorised from its own n draws and stands for itself, as in the reference: a chain whose estimate is refused
+ * keeps its metric, all others are updated, and the call returns DHMC_ERR_INVALID_ARGUMENT (dhmc_last_error names how many). */
 int dhmc_update_metric_dense(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda, int on_device);
 
 /* ---- Diagnostics that call the hot path directly (src/diagnostics.jl), for every chain from its current

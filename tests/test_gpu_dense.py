@@ -221,3 +221,25 @@ def test_per_chain_dense_metric_is_the_references_semantics(pkg):
     dev.set_metric_dense(S); ora.set_metric_dense(S)              # one matrix for every chain
     for c in (0, C - 1):
         assert np.array_equal(dev.metric_dense(c)[0], ora.metric_dense(c)[0])
+
+
+def test_per_chain_dense_update_lets_every_chain_stand_for_itself(pkg):
+    """with dense_per_chain a chain whose covariance estimate is refused (here: a chain whose window draws are all the
+    same point — zero covariance, λ = 0) keeps its metric, while every other chain is updated; the call reports
+    DHMC_ERR_INVALID_ARGUMENT and names the chain.  (The reference fails per chain: each chain is its own mcmc_with_warmup.)"""
+    K, C, n = 6, 4, 40
+    dev = pkg.DeviceContext(K, C, metric=ol.METRIC_DENSE, seed=3, dense_per_chain=True)
+    dev.init(); dev.find_initial_stepsize()
+    a = dev.run(n, da={})
+    draws = a["draws"].copy()
+    draws[2] = draws[2, :1]                                   # chain 2: a degenerate window
+    before = [dev.metric_dense(c)[0] for c in range(C)]
+    with pytest.raises(Exception) as ei:
+        dev.update_metric_dense(draws, 0.0)
+    assert "chain 2" in str(ei.value) or "1 chain" in str(ei.value)
+    after = [dev.metric_dense(c)[0] for c in range(C)]
+    assert np.array_equal(after[2], before[2])                # refused: unchanged
+    for c in (0, 1, 3):
+        assert not np.array_equal(after[c], before[c])        # the others did adapt
+        assert np.allclose(after[c], np.cov(draws[c].T), rtol=1e-10)
+    dev.run(5)                                                # and the context goes on
