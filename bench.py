@@ -291,7 +291,7 @@ def main():
     pg = None
     coll_dev = "cuda"
     backend = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:       # (a launcher's single rank takes the RCCL path too: it is the 8-GPU code)
         import torch.distributed as dist
         # rendezvous over gloo first: do two ranks sit on the same physical GPU (a readiness run of the multi-process path
         # on a 1-GPU box)?  RCCL refuses that ("Duplicate GPU detected"), so then the three small collectives stay on gloo

@@ -239,3 +239,21 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["collective_backend"] in ("gloo", "nccl")
     assert "2048 chains" in d["config"]["workload"]
     assert d["value"] > 1e7 and d["scaling"] == "weak"
+
+
+def test_bench_collectives_run_over_rccl():
+    """The branch of bench.py that an 8-GPU node takes — RCCL process group, barrier with device ids, all-reduce of time and
+    leapfrogs, all-gather of the last draws — executed for real: one rank under torch.distributed.run owns the GPU alone, so
+    the device identities are distinct and the collectives go over RCCL (`collective_backend: "nccl"`)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "1", "--chains", "1024", "--steps", "2",
+                        "--warmup", "1", "--transitions", "40", "--short-warmup", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl"
+    assert d["value"] > 1e7
