@@ -327,11 +327,12 @@ class DeviceFunctorLogDensity(_Target):
         return self._params
 
     @staticmethod
-    def check(dimension, source, name):
-        """Compile only (no GPU needed); returns (ok, compiler log)."""
+    def check(dimension, source, name, metric=abi.METRIC_DIAG):
+        """Compile only (no GPU needed) the kernels of `metric`; returns (ok, compiler log)."""
         import ctypes
         log = ctypes.create_string_buffer(1 << 16)
-        rc = abi.lib().dhmc_check_target_source(source.encode(), name.encode(), ctypes.c_int32(dimension), log, ctypes.c_uint64(len(log)))
+        rc = abi.lib().dhmc_check_target_source(source.encode(), name.encode(), ctypes.c_int32(dimension), ctypes.c_int32(metric), log,
+                                                ctypes.c_uint64(len(log)))
         return rc == abi.OK, log.value.decode(errors="replace")
 
 

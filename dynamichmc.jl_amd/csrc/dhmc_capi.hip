@@ -20,6 +20,7 @@
 
 #include "../../include/dhmc.h"
 #include "dense_factor.hpp"
+#include "dense_rounds_k3b.hpp"
 #include "external_rounds.hpp"
 #include "ess_kernels.hpp"
 #include "logistic_rounds.hpp"
@@ -36,6 +37,10 @@ namespace {
 struct UserKernels {
     hipModule_t mod = nullptr;
     hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr, probe_traj = nullptr, probe_ratio = nullptr;
+    // DHMC_METRIC_DENSE: a second module, compiled when the first dense context of this functor is created
+    hipModule_t dense_mod = nullptr;
+    hipFunction_t k0 = nullptr, k2 = nullptr, k3 = nullptr, run_dense = nullptr, search_dense = nullptr, probe_traj_dense = nullptr,
+                  probe_ratio_dense = nullptr;
 };
 struct UserTarget {
     std::string source, name;
@@ -50,18 +55,27 @@ const char* rtc_prelude() {
     return "typedef unsigned char uint8_t; typedef unsigned int uint32_t; typedef int int32_t;\n"
            "typedef unsigned long long uint64_t; typedef long long int64_t;\n";
 }
+// the kernels a functor needs, as name expressions: the wave-per-chain set of the diagonal metric, or the dense metric's
+// (round engine K0/K2/K3, wave-per-chain run and search, the two probes)
+std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
+    const std::string T = "dhmc::" + name, N = std::to_string(npl);
+    if (!dense)
+        return {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
+                "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
+                "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
+    return {"dhmc::rounds_k0_kernel<" + T + ", " + N + ">", "dhmc::rounds_k2_kernel<" + T + ", " + N + ">",
+            (npl >= 8 ? "dhmc::rounds_k3b_kernel<" : "dhmc::rounds_k3_kernel<") + T + ", " + N + ">",
+            "dhmc::nuts_run_dense_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_dense_kernel<" + T + ", " + N + ">",
+            "dhmc::probe_kernel<" + T + ", " + N + ", true, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", true, 1>"};
+}
 // compile `source` (which defines dhmc::`name`) with the kernel templates for one chain width; *code receives the code object
-constexpr int kRtcKernels = 6;
-int rtc_compile(const std::string& source, const std::string& name, int npl, std::vector<char>* code, std::string (*lowered)[kRtcKernels]) {
+int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered) {
     std::string src = rtc_prelude();
     src += dhmc_rtc_headers;
     src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
     src += source;
     src += "\n";
-    const std::string T = "dhmc::" + name, N = std::to_string(npl);
-    const std::string exprs[kRtcKernels] = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
-                                            "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
-                                            "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
+    const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
     for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
@@ -76,10 +90,10 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, std
         rc = DHMC_ERR_INVALID_ARGUMENT;
     } else {
         if (lowered)
-            for (int i = 0; i < kRtcKernels; ++i) {
+            for (const auto& e : exprs) {
                 const char* low = nullptr;
-                if (hiprtcGetLoweredName(prog, exprs[i].c_str(), &low) != HIPRTC_SUCCESS || !low) { rc = DHMC_ERR_HIP; break; }
-                (*lowered)[i] = low;
+                if (hiprtcGetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) { rc = DHMC_ERR_HIP; break; }
+                lowered->push_back(low);
             }
         if (rc == DHMC_OK && code) {
             size_t cs = 0;
@@ -89,6 +103,14 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, std
     }
     (void)hiprtcDestroyProgram(&prog);
     return rc;
+}
+// load a compiled module and look its kernels up in the order of rtc_kernel_names
+int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low, hipModule_t* mod, std::initializer_list<hipFunction_t*> fns) {
+    if (hipModuleLoadData(mod, code.data()) != hipSuccess) return DHMC_ERR_HIP;
+    size_t i = 0;
+    for (hipFunction_t* f : fns)
+        if (i >= low.size() || hipModuleGetFunction(f, *mod, low[i++].c_str()) != hipSuccess) return DHMC_ERR_HIP;
+    return DHMC_OK;
 }
 int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : 0; }
 }  // namespace
@@ -222,28 +244,41 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
 int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false) {
     hipStream_t cs = use_override ? stream_override : c->stream;
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
-    if (c->user) {     // the caller's functor: the same three kernels, from the run-time compiled module
-        hipFunction_t f = nullptr;
-        unsigned lds = 0;
+    if (c->user) {     // the caller's functor: the same kernels, from the run-time compiled modules
+        const UserKernels& U = *c->user;
+        auto launch = [&](hipFunction_t f, unsigned block, unsigned lds, void** args) {
+            return f && hipModuleLaunchKernel(f, (unsigned)c->cfg.chains, 1, 1, block, 1, 1, lds, cs, args, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+        };
+        DenseMetric dm = M ? *M : DenseMetric{};
         switch (op) {
         case Op::Run: {
             const RunParams& R = *(const RunParams*)P;
-            f = R.l1_in_lds ? c->user->run_lds : c->user->run;
-            lds = (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0));
-            break;
+            void* args[] = {const_cast<void*>(P), &dm};
+            if (M) return launch(U.run_dense, WAVE, (unsigned)lds_bytes_dense(), args);
+            return launch(R.l1_in_lds ? U.run_lds : U.run, WAVE,
+                          (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0)), args);
         }
-        case Op::Init: f = c->user->init; break;
-        case Op::Search: f = c->user->search; lds = (unsigned)(sizeof(double) * c->Dpad); break;
+        case Op::Init: { void* args[] = {const_cast<void*>(P)}; return launch(U.init, WAVE, 0, args); }
+        case Op::Search: {
+            void* args[] = {const_cast<void*>(P), &dm};
+            return M ? launch(U.search_dense, WAVE, 0, args) : launch(U.search, WAVE, (unsigned)(sizeof(double) * c->Dpad), args);
+        }
         case Op::ProbeTrajectory: case Op::ProbeRatios: {     // Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios
-            DenseMetric none{};
-            void* pargs[] = {const_cast<void*>(P), &none};
-            return hipModuleLaunchKernel(op == Op::ProbeTrajectory ? c->user->probe_traj : c->user->probe_ratio, (unsigned)c->cfg.chains, 1, 1,
-                                         WAVE, 1, 1, (unsigned)(sizeof(double) * c->Dpad), cs, pargs, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+            void* args[] = {const_cast<void*>(P), &dm};
+            const bool traj = op == Op::ProbeTrajectory;
+            if (M) return launch(traj ? U.probe_traj_dense : U.probe_ratio_dense, WAVE, 0, args);
+            return launch(traj ? U.probe_traj : U.probe_ratio, WAVE, (unsigned)(sizeof(double) * c->Dpad), args);
+        }
+        case Op::RoundStart: return dispatch_family<StdNormalT>(c->NPL, op, P, cs, M);      // no density in this kernel
+        case Op::RoundK0: case Op::RoundK2: case Op::RoundK3: {
+            RoundArgs a = *(const RoundArgs*)P;
+            void* args[] = {&a.P, &a.R};
+            if (op == Op::RoundK0) return launch(U.k0, WAVE, 0, args);
+            if (op == Op::RoundK2) return launch(U.k2, WAVE, 0, args);
+            return launch(U.k3, c->NPL >= 8 ? WAVE * k3b_waves(c->NPL) : WAVE, 0, args);   // a workgroup per chain from 512 coordinates
         }
         default: return DHMC_ERR_UNSUPPORTED;
         }
-        void* args[] = {const_cast<void*>(P)};
-        return hipModuleLaunchKernel(f, (unsigned)c->cfg.chains, 1, 1, WAVE, 1, 1, lds, cs, args, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
     }
     if (c->builtin_big) return dispatch_family<ExternalT>(c->NPL, op, P, cs, M);
     switch (c->cfg.target) {
@@ -417,7 +452,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (cfg->target >= DHMC_TARGET_USER_BASE) {
             std::lock_guard<std::mutex> lock(g_user_mutex);
             if ((size_t)(cfg->target - DHMC_TARGET_USER_BASE) >= g_user_targets.size()) return DHMC_ERR_INVALID_ARGUMENT;
-            if (cfg->metric != DHMC_METRIC_DIAG || D > 1024) return DHMC_ERR_UNSUPPORTED;
+            if (D > 1024 || (cfg->metric == DHMC_METRIC_DENSE && cfg->dense_per_chain)) return DHMC_ERR_UNSUPPORTED;
             if (cfg->target_params_bytes % sizeof(double) != 0 || (cfg->target_params_bytes && !cfg->target_params)) return DHMC_ERR_INVALID_ARGUMENT;
             break;
         }
@@ -492,15 +527,19 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         auto it = U.built.find(key);
         if (it == U.built.end()) {
             std::vector<char> code;
-            std::string low[kRtcKernels];
-            if ((rc = rtc_compile(U.source, U.name, c->NPL, &code, &low))) return fail(rc);
+            std::vector<std::string> low;
+            if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low))) return fail(rc);
             UserKernels K;
-            if (hipModuleLoadData(&K.mod, code.data()) != hipSuccess) return fail(DHMC_ERR_HIP);
-            if (hipModuleGetFunction(&K.run_lds, K.mod, low[0].c_str()) != hipSuccess || hipModuleGetFunction(&K.run, K.mod, low[1].c_str()) != hipSuccess ||
-                hipModuleGetFunction(&K.init, K.mod, low[2].c_str()) != hipSuccess || hipModuleGetFunction(&K.search, K.mod, low[3].c_str()) != hipSuccess ||
-                hipModuleGetFunction(&K.probe_traj, K.mod, low[4].c_str()) != hipSuccess || hipModuleGetFunction(&K.probe_ratio, K.mod, low[5].c_str()) != hipSuccess)
-                return fail(DHMC_ERR_HIP);
+            if ((rc = rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio}))) return fail(rc);
             it = U.built.emplace(key, K).first;
+        }
+        if (cfg->metric == DHMC_METRIC_DENSE && !it->second.dense_mod) {
+            std::vector<char> code;
+            std::vector<std::string> low;
+            if ((rc = rtc_compile(U.source, U.name, c->NPL, true, &code, &low))) return fail(rc);
+            UserKernels& K = it->second;
+            if ((rc = rtc_load(code, low, &K.dense_mod, {&K.k0, &K.k2, &K.k3, &K.run_dense, &K.search_dense, &K.probe_traj_dense, &K.probe_ratio_dense})))
+                return fail(rc);
         }
         c->user = &it->second;
     }
@@ -635,12 +674,12 @@ int dhmc_register_target_source(const char* hip_source, const char* functor_name
     *target_handle = (int32_t)g_user_targets.size() - 1;
     return DHMC_OK;
 }
-int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, char* log, uint64_t log_bytes) {
-    if (!hip_source || !functor_name) return DHMC_ERR_INVALID_ARGUMENT;
+int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, int32_t metric, char* log, uint64_t log_bytes) {
+    if (!hip_source || !functor_name || (metric != DHMC_METRIC_DIAG && metric != DHMC_METRIC_DENSE)) return DHMC_ERR_INVALID_ARGUMENT;
     const int npl = npl_for_user_dim(dim);
     if (npl == 0) return DHMC_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(g_user_mutex);
-    const int rc = rtc_compile(hip_source, functor_name, npl, nullptr, nullptr);
+    const int rc = rtc_compile(hip_source, functor_name, npl, metric == DHMC_METRIC_DENSE, nullptr, nullptr);
     if (log && log_bytes) {
         const size_t n = std::min<size_t>(g_rtc_log.size(), (size_t)log_bytes - 1);
         std::memcpy(log, g_rtc_log.data(), n);

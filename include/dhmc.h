@@ -193,10 +193,12 @@ int dhmc_host_free(void* p);
  * Lane l holds coordinates l, l+64, … (slot k <-> coordinate l + 64 k; pads are 0); eval fills g = ∇ℓ(q) and returns ℓ (or the
  * lane's partial sum of it).  The source is compiled with hiprtc (-O3 -ffp-contract=off, as the library itself) against the
  * library's kernel templates when a context is created with target = DHMC_TARGET_USER_BASE + *target_handle; compile errors come
- * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().
- * dhmc_check_target_source compiles only (no device needed) for `dim` coordinates and returns the log. */
+ * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().  dim <= 1024; diagonal
+ * metric (the wave-per-chain kernels) or the shared dense metric (a second module, compiled when the first dense context of the
+ * functor is created: the GEMM round engine's kernels around the functor, and the wave-per-chain dense kernels for small batches).
+ * dhmc_check_target_source compiles only (no device needed) the kernels of `metric` for `dim` coordinates and returns the log. */
 int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle);
-int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, char* log, uint64_t log_bytes);
+int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, int32_t metric, char* log, uint64_t log_bytes);
 const char* dhmc_target_source_log(void);   /* the log of the last run-time compilation in this process */
 
 /* ---- lifecycle ----------------------------------------------------------------------- */

@@ -80,3 +80,52 @@ def test_diagnostics_probes_of_a_user_functor_equal_the_builtin_family(pkg):
         assert np.array_equal(ta[k], tb[k]), k
     ra, rb = a.explore_log_acceptance_ratios([0.05, 0.2, 0.8], n_momenta=6), b.explore_log_acceptance_ratios([0.05, 0.2, 0.8], n_momenta=6)
     assert np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("D,C", [(40, 6), (200, 160), (1000, 136)])
+def test_user_functor_with_the_dense_metric_is_bit_equal_to_the_builtin_family(pkg, D, C):
+    """DHMC_METRIC_DENSE for the caller's functor: 6 chains run the wave-per-chain dense kernels, 136+ the GEMM round engine
+    (K0 / K2 / K3 compiled around the functor; at D = 1000 the workgroup-per-chain K3b with the fused position update) — the same
+    kernels as the built-in family's, so the same bits; the small case also against the oracle."""
+    rng = np.random.default_rng(D)
+    mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
+    A = rng.normal(size=(D, D)) / np.sqrt(D)
+    Sigma = np.diag(1 / prec) + 0.1 * (A @ A.T) * np.sqrt(np.outer(1 / prec, 1 / prec))
+    user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
+    blob = ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec)
+
+    def steps(ctx, n):
+        out = {}
+        ctx.set_metric_dense(Sigma)
+        ctx.init(); ctx.find_initial_stepsize()
+        out["eps0"] = ctx.stepsize()
+        out.update({"w_" + k: v for k, v in ctx.run(n, da={}).items()})
+        out.update({"i_" + k: v for k, v in ctx.run(n // 2).items()})
+        q, lq, g = ctx.position()
+        out.update(q=q, lq=lq, g=g)
+        t = ctx.leapfrog_trajectory(0.1, -3, 4, momentum_index=1)
+        out.update(t_delta=t["delta"], t_q=t["q"])
+        return out
+    n = 12 if D == 1000 else 20
+    a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), metric=ol.METRIC_DENSE, seed=4), n)
+    b = steps(pkg.DeviceContext(D, C, target=ol.TARGET_DIAG_NORMAL, target_params=blob, metric=ol.METRIC_DENSE, seed=4), n)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["i_steps"] >= 3).all()
+    if D == 40:
+        o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=blob, metric=ol.METRIC_DENSE, seed=4, threads=6), n)
+        for k in a:
+            assert np.array_equal(a[k], o[k]), k
+
+
+def test_user_functor_dense_warmup_through_the_drop_in_api(pkg):
+    """mcmc_with_warmup(…; warmup_stages = default_warmup_stages(; M = Symmetric)) (mcmc.jl:475-497) with the caller's functor."""
+    D, nu = 12, 5.0
+    scale = np.linspace(0.5, 4.0, D)
+    l = pkg.DeviceFunctorLogDensity(D, uf.STUDENT_T, "StudentT", params=np.concatenate([[nu], scale]))
+    r = pkg.mcmc_with_warmup(11, l, 1200, chains=160, reporter=pkg.NoProgressReport(),
+                             warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric))
+    x = r["posterior_matrix"].reshape(-1, D)
+    sd = scale * np.sqrt(nu / (nu - 2))
+    assert np.abs(x.mean(0) / sd).max() < 0.06
+    assert np.abs(x.std(0) / sd - 1).max() < 0.12

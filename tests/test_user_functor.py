@@ -18,6 +18,13 @@ def test_user_functors_compile_into_the_kernels(pkg, dim):
         assert ok, log
 
 
+@pytest.mark.parametrize("dim", [100, 1000])
+def test_user_functors_compile_into_the_dense_metric_kernels(pkg, dim):
+    """Round engine K0 / K2 / K3 (the workgroup-per-chain K3b from 512 coordinates), the wave-per-chain dense kernels, the probes."""
+    ok, log = pkg.DeviceFunctorLogDensity.check(dim, uf.STUDENT_T, "StudentT", metric=pkg.abi.METRIC_DENSE)
+    assert ok, log
+
+
 def test_compile_errors_come_back_with_the_log(pkg):
     ok, log = pkg.DeviceFunctorLogDensity.check(10, uf.BROKEN, "Broken")
     assert not ok
