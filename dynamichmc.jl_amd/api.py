@@ -154,7 +154,8 @@ class GaussianKineticEnergy:
 
     def __repr__(self):                           # hamiltonian.jl:89-91
         if self.dense:
-            return f"Gaussian kinetic energy (Symmetric), √diag(M⁻¹): {np.sqrt(np.diag(self.Minv))}"
+            d = np.diagonal(self.Minv, axis1=-2, axis2=-1)       # [D], or [C][D] for a per-chain κ
+            return f"Gaussian kinetic energy (Symmetric), √diag(M⁻¹): {np.sqrt(d)}"
         return f"Gaussian kinetic energy (Diagonal), √diag(M⁻¹): {np.sqrt(self.Minv)}"
 
 
@@ -448,7 +449,10 @@ def _state(ctx):
     eps = ctx.stepsize()
     kappa = GaussianKineticEnergy.__new__(GaussianKineticEnergy)
     kappa.dense = ctx.cfg.metric == abi.METRIC_DENSE
-    if kappa.dense:
+    if kappa.dense and ctx.cfg.dense_per_chain:      # the reference's semantics: every chain its own Symmetric M⁻¹ — [C][D][D]
+        mw = [ctx.metric_dense(c) for c in range(ctx.C)]
+        kappa.Minv = np.stack([m for m, _ in mw]); kappa.W = np.stack([w for _, w in mw])
+    elif kappa.dense:
         kappa.Minv, kappa.W = ctx.metric_dense()
     else:
         kappa.Minv = ctx.metric_diag(); kappa.W = np.sqrt(1.0 / kappa.Minv)
@@ -467,6 +471,7 @@ def initialize_warmup_state(slogd, q=None, kappa=None, eps=None, **unknown):
     if kappa is not None:
         _argcheck(kappa.size() == ctx.D, "dimension(ℓ) == size(κ, 1)")    # hamiltonian.jl:147
         if kappa.dense:
+            _argcheck(kappa.Minv.ndim == 2, "a dense κ given at initialization is one matrix (every chain starts from it)")
             ctx.set_metric_dense(kappa.Minv)
         else:
             ctx.set_metric_diag(kappa.Minv)
@@ -495,8 +500,8 @@ def warmup(slogd, stage, warmup_state):
         ad = stage.stepsize_adaptation
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
         arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup)
-        if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210),
-            ctx.update_metric_dense(dev_draws, stage.lam)      # pooled over the context's chains (shared dense M⁻¹)
+        if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210): pooled over the
+            ctx.update_metric_dense(dev_draws, stage.lam)      # context's chains (shared M⁻¹), or chain by chain (per_chain_metric)
         elif stage.M == Diagonal:
             ctx.update_metric_diag(dev_draws, stage.lam)       # mcmc.jl:281-284, from the draws where they are (HBM)
             slogd.reporter.report("adaptation finished")
@@ -527,9 +532,13 @@ def mcmc(slogd, N, warmup_state):
 
 
 def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False, _keep_warmup=True):
+                     reporter=None, device=0, on_device=False, per_chain_metric=False, _keep_warmup=True):
     """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU.  `on_device=True` returns the
-    posterior matrices and statistics as torch CUDA tensors (no PCIe copy of the draws)."""
+    posterior matrices and statistics as torch CUDA tensors (no PCIe copy of the draws).
+    `per_chain_metric` concerns Symmetric (dense) metrics only — a Diagonal κ is always per chain: False (default) adapts ONE
+    M⁻¹ from the pooled draws of all chains, which is what lets the leapfrog's products run as one GEMM over the batch;
+    True gives every chain its own M⁻¹ adapted from its own draws, exactly what C separate calls of the reference do
+    (mcmc.jl:281-284) — the wave-per-chain dense kernels, 2·C·D² doubles of HBM; κ.M⁻¹ then comes back as [C][D][D]."""
     warmup_stages = default_warmup_stages() if warmup_stages is None else warmup_stages
     reporter = default_reporter() if reporter is None else reporter
     rng = _as_rng(rng)
@@ -540,7 +549,8 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     metric = abi.METRIC_DENSE if ((k0 is not None and k0.dense) or wants_dense) else abi.METRIC_DIAG
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
-                        chain_offset=rng.chain_offset, device=device, metric=metric)
+                        chain_offset=rng.chain_offset, device=device, metric=metric,
+                        dense_per_chain=bool(per_chain_metric) and metric == abi.METRIC_DENSE)
     if l.family == abi.TARGET_EXTERNAL:
         ctx.set_logdensity_callback(l.callback())
     slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx, on_device=on_device, keep_warmup=_keep_warmup)
@@ -552,11 +562,12 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
 
 
 def mcmc_with_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False):
+                     reporter=None, device=0, on_device=False, per_chain_metric=False):
     """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C].
     The warmup stages' draws never leave the GPU (the reference discards them too, mcmc.jl:579-583)."""
     r = mcmc_keep_warmup(rng, l, N, chains=chains, initialization=initialization, warmup_stages=warmup_stages,
-                         algorithm=algorithm, reporter=reporter, device=device, on_device=on_device, _keep_warmup=False)
+                         algorithm=algorithm, reporter=reporter, device=device, on_device=on_device,
+                         per_chain_metric=per_chain_metric, _keep_warmup=False)
     out = dict(r["inference"])
     out["kappa"] = r["final_warmup_state"].kappa
     out["eps"] = r["final_warmup_state"].eps
@@ -577,7 +588,10 @@ def mcmc_steps(sampling_logdensity, warmup_state=None):
     if warmup_state is not None:
         _argcheck(warmup_state.eps is not None, "warmup_state.ϵ ≢ nothing")         # mcmc.jl:336
         k = warmup_state.kappa
-        if k.dense:
+        if k.dense and k.Minv.ndim == 3:                       # per-chain Symmetric κ: only as the context's own state
+            _argcheck(bool(ctx.cfg.dense_per_chain) and all(np.array_equal(ctx.metric_dense(c)[0], k.Minv[c]) for c in range(ctx.C)),
+                      "a per-chain dense κ can only be continued on the context that adapted it")
+        elif k.dense:
             if not np.array_equal(ctx.metric_dense()[0], k.Minv):
                 ctx.set_metric_dense(k.Minv)
         elif not np.array_equal(ctx.metric_diag(), np.broadcast_to(k.Minv, (ctx.C, ctx.D))):

@@ -68,7 +68,7 @@ function check(ctx, rc, what; status = nothing)                      # status: t
 end
 
 mutable struct Context
-    h::Ptr{Cvoid}; chains::Int; dim::Int; metric::Int
+    h::Ptr{Cvoid}; chains::Int; dim::Int; metric::Int; dense_per_chain::Bool
     callback::Any                             # keeps the @cfunction of an external model alive
 end
 
@@ -81,7 +81,7 @@ function Context(; dim, chains, target = 0, params = Float64[], seed = 0x23ef614
     h = Ref{Ptr{Cvoid}}()
     rc = GC.@preserve params ccall((:dhmc_create, libdhmc), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || throw(ArgumentError("dhmc_create: code $rc"))
-    finalizer(c -> ccall((:dhmc_destroy, libdhmc), Cint, (Ptr{Cvoid},), c.h), Context(h[], chains, dim, metric, nothing))
+    finalizer(c -> ccall((:dhmc_destroy, libdhmc), Cint, (Ptr{Cvoid},), c.h), Context(h[], chains, dim, metric, dense_per_chain, nothing))
 end
 
 # initialize_warmup_state (mcmc.jl:129-132); q0 is D×C (each column a chain) or nothing
@@ -196,13 +196,20 @@ function stepsize(ctx)
 end
 set_stepsize!(ctx, ϵ::Vector{Float64}) = check(ctx, ccall((:dhmc_set_stepsize, libdhmc), Cint,
     (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, ϵ, length(ϵ) == ctx.chains, 0), "dhmc_set_stepsize")
-function kinetic_energy(ctx)                  # κ: D×C diagonals of M⁻¹ (one per chain), or the shared Symmetric M⁻¹
+function kinetic_energy(ctx)                  # κ: D×C diagonals of M⁻¹ (one per chain), the shared Symmetric M⁻¹, or one Symmetric per chain
     if ctx.metric == 0
         m = Matrix{Float64}(undef, ctx.dim, ctx.chains)
         check(ctx, ccall((:dhmc_get_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx.h, m, 0), "dhmc_get_metric_diag")
         return [DynamicHMC.GaussianKineticEnergy(Diagonal(m[:, c])) for c in 1:ctx.chains]
     end
     M = Matrix{Float64}(undef, ctx.dim, ctx.dim); W = similar(M)
+    if ctx.dense_per_chain
+        return map(0:ctx.chains-1) do c
+            check(ctx, ccall((:dhmc_get_metric_dense_chain, libdhmc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}), ctx.h, c, M, W),
+                  "dhmc_get_metric_dense_chain")
+            DynamicHMC.GaussianKineticEnergy(Symmetric(copy(M)), collect(W'))
+        end
+    end
     check(ctx, ccall((:dhmc_get_metric_dense, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, M, W), "dhmc_get_metric_dense")
     DynamicHMC.GaussianKineticEnergy(Symmetric(M), collect(W'))      # row-major [i][j] read column-major is the transpose
 end
@@ -274,10 +281,12 @@ end
 # mcmc_keep_warmup / mcmc_with_warmup (mcmc.jl:521-532,575-584) with `chains` chains on one GPU
 function DynamicHMC.mcmc_keep_warmup(rng::Integer, ℓ::DeviceLogDensity, N::Integer; chains = 1, initialization = (),
                                      warmup_stages = default_warmup_stages(), algorithm = NUTS(),
-                                     reporter = default_reporter(), device = 0, chain_offset = 0)
+                                     reporter = default_reporter(), device = 0, chain_offset = 0, per_chain_metric = false)
+    # per_chain_metric (Symmetric κ only; a Diagonal κ is always per chain): false — one M⁻¹ adapted from the pooled draws of all
+    # chains (the leapfrog's products are one GEMM); true — every chain its own, as `chains` separate calls of the reference
     dense = any(s -> s isa TuningNUTS{Symmetric}, warmup_stages) || get(initialization, :κ, nothing) isa Matrix
     ctx = Context(; dim = ℓ.dim, chains, target = ℓ.target, params = ℓ.params, seed = UInt64(rng), algorithm,
-                  chain_offset, device, metric = dense ? 1 : 0)
+                  chain_offset, device, metric = dense ? 1 : 0, dense_per_chain = dense && per_chain_metric)
     ℓ.f! === nothing || set_logdensity!(ctx, ℓ.f!)
     sl = SamplingLogDensityAMD(UInt64(rng), ℓ, algorithm, reporter, ctx)
     init!(ctx, get(initialization, :q, nothing))                                         # initialize_warmup_state (mcmc.jl:129-132)

@@ -129,6 +129,25 @@ def test_default_warmup_with_symmetric_metric(pkg):
     assert r["tree_statistics"].acceptance_rate.mean() >= 0.7
 
 
+def test_per_chain_symmetric_warmup_through_the_api_is_what_separate_runs_give(pkg):
+    """mcmc_with_warmup(…; per_chain_metric = True): every chain adapts its own Symmetric κ from its own draws (mcmc.jl:281-284),
+    so chain c of a 4-chain call is, bit for bit, the 1-chain call whose stream starts at chain c."""
+    K = 5
+    l = pkg.MvNormal(np.arange(K) * 0.5, rand_sigma(K))
+    stages = lambda: pkg.default_warmup_stages(M=pkg.Symmetric, middle_steps=20, doubling_stages=3)
+    r = pkg.mcmc_with_warmup(pkg.PhiloxRNG(31), l, 200, chains=4, warmup_stages=stages(), reporter=pkg.NoProgressReport(),
+                             per_chain_metric=True)
+    assert r["kappa"].dense and r["kappa"].Minv.shape == (4, K, K)
+    assert not np.array_equal(r["kappa"].Minv[0], r["kappa"].Minv[1])
+    repr(r["kappa"])
+    for c in (0, 3):
+        one = pkg.mcmc_with_warmup(pkg.PhiloxRNG(31, chain_offset=c), l, 200, chains=1, warmup_stages=stages(),
+                                   reporter=pkg.NoProgressReport(), per_chain_metric=True)
+        assert np.array_equal(one["posterior_matrix"][0], r["posterior_matrix"][c])
+        assert np.array_equal(one["kappa"].Minv[0], r["kappa"].Minv[c])
+        assert np.array_equal(one["eps"], r["eps"][c:c + 1])
+
+
 def test_dense_state_export_import(pkg):
     """The resume blob of a dense context carries the shared M⁻¹ / W as well."""
     K = 10

@@ -140,3 +140,13 @@ def test_external_target_host_side(pkg):
     q = torch.tensor([[1.0, -2.0], [0.5, 0.0]], dtype=torch.float64)
     lq, g = f(q)
     assert torch.equal(lq, torch.tensor([-2.5, -0.125], dtype=torch.float64)) and torch.equal(g, -q)
+
+
+def test_integration_md_reproduces_the_julia_shim_verbatim():
+    """INTEGRATION.md §2 says it shows integration/DynamicHMCAMD.jl verbatim: keep it so."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    shim = open(os.path.join(root, "integration", "DynamicHMCAMD.jl"), encoding="utf-8").read().rstrip("\n")
+    first = md.index("```julia\n") + len("```julia\n")
+    assert md[first:md.index("\n```", first)] == shim
