@@ -316,13 +316,15 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* ctx, const double* eps, int32_t
  *      be reported without moving the draws.  Estimator: multi-chain autocorrelation with Geyer's initial monotone
  *      positive sequence (what the reference's tests obtain from MCMCDiagnosticTools.ess_rhat,
  *      test/sample-correctness_utilities.jl:40-43; that package is not vendored, parity unpinned).  coords, ess,
- *      rhat are HOST arrays; stream may be NULL; 4 <= n <= 7680 in this build. ---------------------------- */
+ *      rhat are HOST arrays; stream may be NULL; n >= 4.  Series of up to 7680 draws are held in LDS; longer ones stay
+ *      in HBM and their autocovariances are computed 1024 lags at a time until every coordinate's sequence has
+ *      truncated — the same arithmetic order, so the same bits either way. ------------------------------------ */
 int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
 /* Bulk ESS and rank-normalised split-R̂ (Vehtari et al. 2021 — MCMCDiagnosticTools.ess_rhat's default kind): every chain
  * is split in two halves (an odd last draw is dropped), the 2·chains·(n/2) draws of a coordinate are replaced by the
  * normal scores of their average ranks, and the estimator of dhmc_ess_rhat runs on those.  Same arguments; n >= 8,
- * n/2 <= 7680. */
+ * chains·n < 2³¹. */
 int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
                   const int32_t* coords, int32_t ncoords, double* ess, double* rhat);
 /* Tail ESS (Vehtari et al. 2021; MCMCDiagnosticTools ess(kind = :tail)): the smaller of the ESS of I(x <= q5%) and I(x >= q95%)

@@ -171,14 +171,54 @@ def test_ess_rhat_kernels_match_host_estimator(pkg):
         pkg.diagnostics.ess_bulk_device(torch.zeros((2, 3, 2), dtype=torch.float64, device="cuda"), kind="plain")   # n < 4
 
 
-def test_ess_rhat_longest_series(pkg):
-    """n = 7680 draws per chain is the longest series one workgroup holds in LDS; beyond it the call is refused."""
+def _ar1(rng, C, N, D, phi):
+    e = rng.normal(size=(C, N, D))
+    x = np.zeros_like(e)
+    x[:, 0] = e[:, 0]
+    for n in range(1, N):
+        x[:, n] = phi * x[:, n - 1] + e[:, n]
+    return x + rng.normal(size=(C, 1, D)) * 0.05
+
+
+def test_ess_long_series_path_gives_the_bits_of_the_lds_path(pkg, monkeypatch):
+    """Series up to 7680 draws are held in LDS; longer ones lie in HBM and their autocovariances are computed a chunk of 1024
+    lags at a time until Geyer's truncation (csrc/ess_kernels.hpp).  Same arithmetic order: forced onto short series
+    (DHMC_ESS_LONG=1) the long path returns the bits of the LDS path — truncation inside the first chunk (φ = 0.6), beyond
+    it (φ = 0.9995: pairs stay positive for thousands of lags) and a series that ends inside a chunk (N = 1500)."""
+    import torch
+    rng = np.random.default_rng(5)
+    for C, N, D, phi in ((6, 3000, 3, 0.6), (4, 7000, 2, 0.9995), (3, 1500, 2, 0.999), (2, 37, 1, -0.4)):
+        t = torch.from_numpy(_ar1(rng, C, N, D, phi)).cuda()
+        res = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("DHMC_ESS_LONG", flag)
+            res[flag] = [pkg.diagnostics.ess_bulk_device(t, kind=k) for k in ("plain", "bulk")] + \
+                        ([pkg.diagnostics.ess_bulk_device(t, kind="tail")] if N >= 100 else [])
+        for a, b in zip(res["0"], res["1"]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True), (C, N, phi)
+    monkeypatch.delenv("DHMC_ESS_LONG")
+
+
+def test_ess_rhat_series_longer_than_lds(pkg):
+    """n = 7680 is the longest series one workgroup holds in LDS; n = 30 000 (split halves of 15 000 for the bulk / tail
+    kinds) goes through the long path, against the host estimators."""
     import torch
     x = torch.randn((2, 7680, 3), dtype=torch.float64, device="cuda")
     ess, rhat = pkg.diagnostics.ess_bulk_device(x, np.array([0, 2], np.int32), kind="plain")
     assert (ess > 0.5 * 2 * 7680).all() and (np.abs(rhat - 1) < 0.01).all()
-    with pytest.raises(RuntimeError):
-        pkg.diagnostics.ess_bulk_device(torch.zeros((1, 7681, 1), dtype=torch.float64, device="cuda"), kind="plain")
+    rng = np.random.default_rng(8)
+    xs = _ar1(rng, 4, 30000, 2, 0.8)
+    t = torch.from_numpy(xs).cuda()
+    ess, rhat = pkg.diagnostics.ess_bulk_device(t, kind="plain")
+    eb, rb = pkg.diagnostics.ess_bulk_device(t)
+    et, _ = pkg.diagnostics.ess_bulk_device(t, kind="tail")
+    for j in range(2):
+        eh, rh = ess_reference.ess_rhat(xs[:, :, j])
+        assert np.isclose(ess[j], eh, rtol=1e-9) and np.isclose(rhat[j], rh, rtol=1e-12)
+        eh, rh = ess_reference.ess_bulk(xs[:, :, j])
+        assert np.isclose(eb[j], eh, rtol=1e-7) and np.isclose(rb[j], rh, rtol=1e-9)
+        assert np.isclose(et[j], ess_reference.ess_tail(xs[:, :, j]), rtol=1e-7)
+    assert (np.abs(ess / (4 * 30000 * (1 - 0.8) / (1 + 0.8)) - 1) < 0.15).all()      # AR(1): ESS = S (1 − φ)/(1 + φ)
 
 
 def test_tree_statistics_summary_on_device(pkg):
