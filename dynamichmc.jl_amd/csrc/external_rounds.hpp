@@ -405,4 +405,183 @@ __global__ __launch_bounds__(64) void ext_search_dense_decide_kernel(ExtSearchPa
     }
 }
 
+// ---- Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios (src/diagnostics.jl:144-227) for a model whose density is
+// the host's callback (or builtin_normal_eval_kernel): what probe_kernel (probe_kernels.hpp) does inside one kernel, here as
+// lock-step leapfrogs of all chains with ONE batched evaluation per step —
+//      momentum -> start (π₀)   then per step:  half (pₘ, q′)  [dense: pₘ·M⁻¹]  callback(Q′)  finish (evaluate_ℓ, p′)  [dense: p′·M⁻¹]  record
+// with the arithmetic of leapfrog_leaf_m / leapfrog_leaf_dense slot by slot.  The chains' own state is never modified.
+struct ExtProbeParams {
+    int D, Dpad, C, chain_offset;
+    uint64_t seed;
+    ChainArrays st;
+    double *q, *p, *g, *pm, *trial, *ps;   // [C][Dpad]: the travelling point, pₘ, the position handed to the callback, p♯ (dense: a GEMM's output)
+    double *p0, *ps0;                      // [C][Dpad]: the momentum the trajectory starts from and its p♯
+    double *pi0, *lq_cur;                  // [C]
+    int32_t* alive;                        // [C]: the chain still steps (a trajectory stops after its first non-finite ℓ, diagnostics.jl:179)
+    uint32_t* status;                      // [C]
+    const double* lq_in;                   // the callback's outputs for `trial`
+    const double* grad_in;
+    int dense;
+};
+
+// p₀ (or z for the dense metric: p₀ = z·Wᵀ is a GEMM) from the caller's momenta p_in [C][n_mom][D] or from the chain's stream
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_momentum_kernel(ExtProbeParams P, const double* __restrict__ p_in, int n_mom, int m,
+                                                               uint32_t momentum_index) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    if (p_in) {
+        const double* src = p_in + ((size_t)chain * n_mom + m) * P.D;
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            P.p0[row + e] = e < P.D ? src[e] : 0.0;
+        }
+        return;
+    }
+    const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
+#pragma unroll 2
+    for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
+        uint64_t r1, r2;
+        stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_PROBE_MOMENTUM, momentum_index + (uint32_t)m, r1, r2);
+        double z0, z1;
+        det_randn2(r1, r2, &z0, &z1);
+        const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
+        if (P.dense) {
+            P.p0[row + e0] = e0 < P.D ? z0 : 0.0;
+            if (2 * kk + 1 < NPL) P.p0[row + e1] = e1 < P.D ? z1 : 0.0;
+        } else {
+            P.p0[row + e0] = P.st.W[row + e0] * z0;
+            if (2 * kk + 1 < NPL) P.p0[row + e1] = P.st.W[row + e1] * z1;
+        }
+    }
+}
+
+// π₀ = logdensity(H, (Q, p₀)); the travelling point back at the start
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_start_kernel(ExtProbeParams P, int ratios) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    LaneAcc<1, NPL> kacc;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double pv = P.p0[row + e];
+        double psv;
+        if (P.dense) psv = P.ps0[row + e];
+        else { psv = P.st.minv[row + e] * pv; P.ps0[row + e] = psv; }
+        kacc.add(0, k, pv, psv);
+    }
+    const double pi0 = uni_f64(joint_logdensity(P.st.lq[chain], wave_allreduce1(kacc.fold(0)) / 2.0));
+    if (lane == 0) {
+        P.pi0[chain] = pi0;
+        if (ratios && !dm_isfinite(pi0)) P.status[chain] |= DHMC_ST_NONFINITE_START_DENSITY;   // stepsize.jl:77-79 throws
+    }
+}
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_restart_kernel(ExtProbeParams P, int ratios) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double qv = P.st.q[row + e];
+        P.q[row + e] = qv; P.trial[row + e] = qv;
+        P.p[row + e] = P.p0[row + e];
+        P.g[row + e] = P.st.g[row + e];
+    }
+    if (lane == 0) {
+        P.lq_cur[chain] = P.st.lq[chain];
+        P.alive[chain] = ratios ? (dm_isfinite(P.pi0[chain]) ? 1 : 0) : 1;
+    }
+}
+
+// first half step (hamiltonian.jl:277-278).  Diagonal metric: q′ here; dense: pₘ only, q′ after the GEMM (pos_kernel)
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_half_kernel(ExtProbeParams P, double eps) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * P.Dpad;
+    const bool go = P.alive[chain] && dm_isfinite(P.lq_cur[chain]);            // diagnostics.jl:179
+    if (lane == 0 && !go) P.alive[chain] = 0;
+    if (!go) return;
+    const double h = eps / 2;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double pm = P.p[row + e] + h * P.g[row + e];
+        P.pm[row + e] = pm;
+        if (!P.dense) P.trial[row + e] = P.q[row + e] + eps * (P.st.minv[row + e] * pm);
+    }
+}
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_pos_kernel(ExtProbeParams P, double eps) {   // dense: q′ = q + ϵ·(pₘ·M⁻¹), the product in P.ps
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (!P.alive[chain]) return;
+    const size_t row = (size_t)chain * P.Dpad;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        P.trial[row + e] = P.q[row + e] + eps * P.ps[row + e];
+    }
+}
+
+// evaluate_ℓ on the callback's outputs, second half step (hamiltonian.jl:279-280): the travelling point becomes (q′, p′, ∇ℓ′)
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_finish_kernel(ExtProbeParams P, double eps) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (!P.alive[chain]) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    const double h = eps / 2;
+    bool pos_finite, valid;
+    const double lq = external_evaluate<NPL>(P.trial + row, P.grad_in + row, lane, P.D, P.lq_in[chain], pos_finite, valid, [&](int k, int e, double gv) {
+        P.p[row + e] = P.pm[row + e] + h * gv;
+        P.g[row + e] = gv;
+        P.q[row + e] = P.trial[row + e];
+    });
+    if (lane == 0) {
+        P.lq_cur[chain] = lq;
+        if (!pos_finite) P.status[chain] |= DHMC_ST_NONFINITE_POSITION;          // hamiltonian.jl:203 throws
+    }
+}
+
+// π of the travelling point and the outputs of this step.  Trajectory (out_lq != null): position index `idx` of npos, range[2 chain + hi_side]
+// = pos; ratios: out_delta[(chain n_mom + m) n_eps + e] (passed as idx with npos = n_mom·n_eps)
+template <int NPL>
+__global__ __launch_bounds__(64) void ext_probe_record_kernel(ExtProbeParams P, int idx, int npos, int pos, int start, double* __restrict__ out_delta,
+                                                             double* __restrict__ out_lq, double* __restrict__ out_q, double* __restrict__ out_p,
+                                                             int32_t* __restrict__ out_range) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (!start && !P.alive[chain]) return;
+    const size_t row = (size_t)chain * P.Dpad;
+    double pi;
+    const double lq = P.lq_cur[chain];
+    if (start) {
+        pi = P.pi0[chain];
+    } else {
+        LaneAcc<1, NPL> kacc;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            const double pv = P.p[row + e];
+            kacc.add(0, k, pv, P.dense ? P.ps[row + e] : P.st.minv[row + e] * pv);
+        }
+        pi = uni_f64(joint_logdensity(lq, wave_allreduce1(kacc.fold(0)) / 2.0));
+    }
+    if (lane == 0) {
+        out_delta[(size_t)chain * npos + idx] = pi - P.pi0[chain];               // diagnostics.jl:196, stepsize.jl:81-83
+        if (out_lq) out_lq[(size_t)chain * npos + idx] = lq;
+        if (out_range && !start) out_range[2 * chain + (pos > 0 ? 1 : 0)] = pos;
+    }
+    if (out_q || out_p) {
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            if (e < P.D) {
+                if (out_q) out_q[((size_t)chain * npos + idx) * P.D + e] = P.q[row + e];
+                if (out_p) out_p[((size_t)chain * npos + idx) * P.D + e] = P.p[row + e];
+            }
+        }
+    }
+}
+
 }  // namespace dhmc

@@ -125,6 +125,8 @@ def _probe_context(l, q, kappa, rng, device):
     ctx = DeviceContext(l.dimension(), q2.shape[0], target=l.family, target_params=l.params(), seed=rng.seed,
                         chain_offset=rng.chain_offset, device=device,
                         metric=abi.METRIC_DENSE if kappa.dense else abi.METRIC_DIAG)
+    if l.family == abi.TARGET_EXTERNAL:                         # the caller's batched model: the probes step all chains around it
+        ctx.set_logdensity_callback(l.callback())
     ctx.init(q2, allow_failure=True)                            # evaluate_ℓ(ℓ, q), non-strict (diagnostics.jl:148,219)
     if (ctx.status() & abi.ST_NONFINITE_POSITION).any():        # hamiltonian.jl:203 throws also when non-strict
         ctx._raise(abi.ERR_CHAIN_FAILURE, "evaluate_ℓ")

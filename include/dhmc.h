@@ -292,7 +292,10 @@ int dhmc_update_metric_dense(dhmc_ctx* ctx, const double* draws, int64_t n, doub
 /* ---- Diagnostics that call the hot path directly (src/diagnostics.jl), for every chain from its current
  *      position; the chains are not modified.  All buffers are HOST pointers.  status [C] (may be NULL)
  *      receives the DHMC_ST_* bits of the reference's throw sites; any non-zero bit makes the call return
- *      DHMC_ERR_CHAIN_FAILURE (outputs are still written). --------------------------------------------- */
+ *      DHMC_ERR_CHAIN_FAILURE (outputs are still written).  Every family and metric: inside one kernel for the
+ *      device functors (built-in or the caller's); as lock-step leapfrogs of all chains around one batched
+ *      evaluation per step for DHMC_TARGET_EXTERNAL (the callback is called last − first times for a trajectory,
+ *      n_momenta · n_eps times for the ratios) and for the normal families beyond 1024 coordinates. ---------- */
 /* leapfrog_trajectory(ℓ, q, ϵ, first:last; κ, p) (diagnostics.jl:214-227): positions first..last relative
  * to the chain's position (first <= 0 <= last, else DHMC_ERR_INVALID_ARGUMENT as the @argcheck of :218), step
  * eps forward and -eps backward, each direction tracked until the first non-finite ℓq (that point included,

@@ -65,6 +65,61 @@ def test_trajectory_and_ratios_match_oracle(pkg, name, D, target, mk):
     assert not dev.status().any()
 
 
+def test_probes_through_the_batched_evaluation_path_match_oracle(pkg):
+    """Beyond 1024 coordinates the density is evaluated for all chains at once between kernels (the engine of
+    DHMC_TARGET_EXTERNAL, with builtin_normal_eval_kernel where the host's callback stands): the probes run as lock-step
+    leapfrogs around that evaluation (external_rounds.hpp ext_probe_*) — bit-equal to the oracle, diagonal and dense metric."""
+    D, C = 1500, 4
+    params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
+    for metric in (ol.METRIC_DIAG, ol.METRIC_DENSE):
+        dev, ora = _pair(pkg, D, C, target=ol.TARGET_TRIDIAG_NORMAL, params=params, metric=metric, seed=23)
+        dev.init(); ora.init()
+        if metric == ol.METRIC_DENSE:
+            idx = np.arange(D)
+            S = 0.6 ** np.abs(idx[:, None] - idx[None, :]) * 0.7
+            dev.set_metric_dense(S); ora.set_metric_dense(S)
+        else:
+            minv = np.random.default_rng(3).uniform(0.5, 2.0, (C, D))
+            dev.set_metric_diag(minv); ora.set_metric_diag(minv)
+        tag = f"big metric={metric}"
+        _same(dev.leapfrog_trajectory(0.1, -3, 4, momentum_index=2), ora.leapfrog_trajectory(0.1, -3, 4, momentum_index=2), tag)
+        p = np.random.default_rng(5).normal(size=(C, D))
+        _same(dev.leapfrog_trajectory(0.2, -2, 0, p=p), ora.leapfrog_trajectory(0.2, -2, 0, p=p), tag + " given p")
+        eps = 2.0 ** np.arange(-4, 1)
+        assert np.array_equal(dev.explore_log_acceptance_ratios(eps, n_momenta=3, momentum_index=1),
+                              ora.explore_log_acceptance_ratios(eps, n_momenta=3, momentum_index=1)), tag
+        ps = np.random.default_rng(6).normal(size=(C, 2, D))
+        assert np.array_equal(dev.explore_log_acceptance_ratios(eps, ps=ps), ora.explore_log_acceptance_ratios(eps, ps=ps)), tag
+        for x, y in zip(dev.position(), ora.position()):
+            assert np.array_equal(x, y)
+        dev.close()
+
+
+def test_probes_of_a_torch_model(pkg):
+    """Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios (diagnostics.jl:144-227) for the caller's own batched model:
+    with D = 1 (nothing to sum) bit-equal to the built-in functor; a trajectory that runs into a non-finite density stops there."""
+    import torch
+    ext = pkg.TorchLogDensity(1, logdensity_and_gradient=lambda q: (-0.5 * (q * q).sum(1), -q))
+    q = np.array([[0.3], [-1.2], [2.0]])
+    a = pkg.diagnostics.leapfrog_trajectory(ext, q, 0.25, range(-4, 6), rng=9)
+    b = pkg.diagnostics.leapfrog_trajectory(pkg.StandardNormal(1), q, 0.25, range(-4, 6), rng=9)
+    assert len(a) == 3 and [len(x) for x in a] == [len(x) for x in b] == [10, 10, 10]
+    for ca, cb in zip(a, b):
+        for ta, tb in zip(ca, cb):
+            assert ta["position"] == tb["position"] and ta["Δ"] == tb["Δ"] and ta["z"]["lq"] == tb["z"]["lq"]
+            assert np.array_equal(ta["z"]["q"], tb["z"]["q"]) and np.array_equal(ta["z"]["p"], tb["z"]["p"])
+    ra = pkg.diagnostics.explore_log_acceptance_ratios(ext, q, np.arange(-6, 2), rng=9, N=5)
+    rb = pkg.diagnostics.explore_log_acceptance_ratios(pkg.StandardNormal(1), q, np.arange(-6, 2), rng=9, N=5)
+    assert ra.shape == (3, 8, 5) and np.array_equal(ra, rb)
+    # a density that is −Inf beyond |q| > 3: the trajectory is tracked up to the first such point (diagnostics.jl:179)
+    def walled(qq):
+        lq = -0.5 * (qq * qq).sum(1)
+        return torch.where((qq.abs() > 3).any(1), torch.full_like(lq, -float("inf")), lq), -qq
+    w = pkg.TorchLogDensity(2, logdensity_and_gradient=walled)
+    tr = pkg.diagnostics.leapfrog_trajectory(w, np.array([2.5, 0.0]), 0.5, range(0, 12), p=np.array([3.0, 0.1]))
+    assert 2 <= len(tr) < 12 and tr[-1]["z"]["lq"] == -np.inf and all(np.isfinite(t["z"]["lq"]) for t in tr[:-1])
+
+
 def test_dense_metric_probes_match_oracle(pkg):
     D, C = 40, 4
     params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
