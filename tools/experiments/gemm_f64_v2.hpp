@@ -113,4 +113,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rows_f64_v2_kernel(const do
 template <int WM, int WN, int FM, int FN, int TK>
 constexpr size_t gemm_v2_lds_bytes() { return sizeof(double) * 2 * TK * ((16 * FM * WM + 16) + (16 * FN * WN + 16)); }
 
+
+// To run the library's square products through a variant (config 3 under contention with K3b — measured: base 1.27e7, 64×64 1.18e7,
+// 128×64 1.21e7, 128×128 0.93e7 with two parts / 1.15e7 with one): forward-declare launch_gemm_rows_v2 in gemm_f64_mfma.hpp, call it first
+// thing in launch_gemm_rows, and build dhmc_capi.hip with -DDHMC_GEMM_ROWS_V2=1|2|3 -include this file (build_variant_capi.sh).
+#ifdef DHMC_GEMM_ROWS_V2      // 1 = 64×64 (2×2 per wave), 2 = 128×64 (4×2), 3 = 128×128 (4×4)
+template <int FM, int FN>
+inline void launch_gemm_rows_v2_t(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list, const int* row_count,
+                                  hipStream_t s) {
+    constexpr int TM = 32 * FM, TN = 32 * FN;
+    constexpr size_t lds = gemm_v2_lds_bytes<2, 2, FM, FN, 16>();
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_rows_f64_v2_kernel<2, 2, FM, FN, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)once;
+    dim3 grid(ld / TN, (nrows + TM - 1) / TM);
+    hipLaunchKernelGGL((gemm_rows_f64_v2_kernel<2, 2, FM, FN, 16>), grid, dim3(256), lds, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count, 0, (size_t)0);
+}
+inline void launch_gemm_rows_v2(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list, const int* row_count,
+                                hipStream_t s) {
+#if DHMC_GEMM_ROWS_V2 == 1
+    launch_gemm_rows_v2_t<2, 2>(A, B, OUT, ld, nrows, row_list, row_count, s);
+#elif DHMC_GEMM_ROWS_V2 == 2
+    if (ld % 64 == 0) launch_gemm_rows_v2_t<4, 2>(A, B, OUT, ld, nrows, row_list, row_count, s);
+    else launch_gemm_rows_v2_t<2, 2>(A, B, OUT, ld, nrows, row_list, row_count, s);
+#else
+    if (ld % 128 == 0) launch_gemm_rows_v2_t<4, 4>(A, B, OUT, ld, nrows, row_list, row_count, s);
+    else launch_gemm_rows_v2_t<2, 2>(A, B, OUT, ld, nrows, row_list, row_count, s);
+#endif
+}
+#endif
+
 }  // namespace dhmc
