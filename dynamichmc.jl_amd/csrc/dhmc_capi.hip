@@ -1386,7 +1386,20 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         c->last_ms = nbuf == 2 ? chunk_ms : ms;     // kernel time only: not the waits for copies between the chunks
     }
     cleanup();
-    if (e != hipSuccess) { c->err = std::string("dhmc_run: ") + hipGetErrorString(e); return DHMC_ERR_HIP; }
+    if (e != hipSuccess) {
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);     // no copy into the caller's arrays may outlive the call
+        c->err = std::string("dhmc_run: ") + hipGetErrorString(e);
+        return DHMC_ERR_HIP;
+    }
+    // staging of a call that could not be chunked (round engines: [C][N] records at once) is given back when it is large;
+    // the chunked engine's two buffers (≤ ≈1 GiB of draws each) stay with the context
+    if (nbuf == 1 && !staged.empty()) {
+        size_t held = 0;
+        for (auto& sb : c->stage[0]) held += sb.cap;
+        if (held > ((size_t)1 << 30))
+            for (auto& sb : c->stage[0])
+                if (sb.p) { (void)hipFree(sb.p); sb.p = nullptr; sb.cap = 0; }
+    }
     return status_code(c);
 }
 
