@@ -76,6 +76,42 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     src += source;
     src += "\n";
     const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
+    // DHMC_RTC_CACHE=<directory>: code objects are kept there, keyed by everything that went into them, so that the next
+    // process (a new Julia session) loads instead of compiling (≈ 2 s diagonal, ≈ 15 s dense per functor and chain width)
+    std::string cache_file;
+    if (const char* dir = std::getenv("DHMC_RTC_CACHE"); dir && *dir && code && lowered) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const std::string& t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        mix(src); mix(dhmc_version()); mix(std::to_string(major) + "." + std::to_string(minor));
+        for (const auto& e : exprs) mix(e);
+        char hex[17];
+        std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
+        cache_file = std::string(dir) + "/dhmc_rtc_" + hex + ".co";
+        if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
+            bool ok = false;
+            char magic[8];
+            uint32_t n = 0;
+            std::vector<std::string> names;
+            if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DHMCRTC1", 8) == 0 && std::fread(&n, 4, 1, f) == 1 && n == exprs.size()) {
+                ok = true;
+                for (uint32_t i = 0; i < n && ok; ++i) {
+                    uint32_t len = 0;
+                    ok = std::fread(&len, 4, 1, f) == 1 && len < 4096;
+                    std::string t(ok ? len : 0, '\0');
+                    ok = ok && (len == 0 || std::fread(&t[0], 1, len, f) == len);
+                    names.push_back(t);
+                }
+                uint64_t cs = 0;
+                ok = ok && std::fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 31);
+                if (ok) { code->resize(cs); ok = std::fread(code->data(), 1, cs, f) == cs; }
+            }
+            std::fclose(f);
+            if (ok) { *lowered = names; g_rtc_log = "(loaded from " + cache_file + ")"; return DHMC_OK; }
+            code->clear();
+        }
+    }
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
     for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
@@ -102,6 +138,21 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
         }
     }
     (void)hiprtcDestroyProgram(&prog);
+    if (rc == DHMC_OK && !cache_file.empty()) {           // written under another name first: a concurrent reader never sees half a file
+        const std::string tmp = cache_file + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&rc);
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            const uint32_t n = (uint32_t)lowered->size();
+            bool ok = std::fwrite("DHMCRTC1", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
+            for (const auto& t : *lowered) {
+                const uint32_t len = (uint32_t)t.size();
+                ok = ok && std::fwrite(&len, 4, 1, f) == 1 && std::fwrite(t.data(), 1, len, f) == len;
+            }
+            const uint64_t cs = code->size();
+            ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code->data(), 1, cs, f) == cs;
+            ok = (std::fclose(f) == 0) && ok;
+            if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) (void)std::remove(tmp.c_str());
+        }
+    }
     return rc;
 }
 // load a compiled module and look its kernels up in the order of rtc_kernel_names

@@ -196,7 +196,9 @@ int dhmc_host_free(void* p);
  * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().  dim <= 1024; diagonal
  * metric (the wave-per-chain kernels) or the shared dense metric (a second module, compiled when the first dense context of the
  * functor is created: the GEMM round engine's kernels around the functor, and the wave-per-chain dense kernels for small batches).
- * dhmc_check_target_source compiles only (no device needed) the kernels of `metric` for `dim` coordinates and returns the log. */
+ * dhmc_check_target_source compiles only (no device needed) the kernels of `metric` for `dim` coordinates and returns the log.
+ * Environment DHMC_RTC_CACHE=<directory>: compiled modules are kept there (keyed by source, functor name, chain width, metric,
+ * library and hiprtc version) and loaded instead of compiled by later processes; an unreadable file is ignored and replaced. */
 int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle);
 int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, int32_t metric, char* log, uint64_t log_bytes);
 const char* dhmc_target_source_log(void);   /* the log of the last run-time compilation in this process */

@@ -129,3 +129,34 @@ def test_user_functor_dense_warmup_through_the_drop_in_api(pkg):
     sd = scale * np.sqrt(nu / (nu - 2))
     assert np.abs(x.mean(0) / sd).max() < 0.06
     assert np.abs(x.std(0) / sd - 1).max() < 0.12
+
+
+def test_code_objects_are_reused_from_the_disk_cache(pkg, tmp_path, monkeypatch):
+    """DHMC_RTC_CACHE=<dir>: the compiled module of a functor is kept on disk and the next registration of the same source (the next
+    process, in practice) loads it instead of compiling — same kernels, same bits; a corrupt file is ignored and replaced."""
+    import glob, time
+    monkeypatch.setenv("DHMC_RTC_CACHE", str(tmp_path))
+    D = 70
+    params = np.concatenate([np.linspace(-1, 1, D), np.linspace(0.5, 2, D)])
+
+    def run():
+        user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=params)       # a new handle every time
+        t0 = time.perf_counter()
+        ctx = pkg.DeviceContext(D, 4, target=user.family, target_params=user.params(), seed=8)
+        dt = time.perf_counter() - t0
+        log = pkg.abi.lib().dhmc_target_source_log().decode()
+        ctx.init(); ctx.find_initial_stepsize()
+        out = ctx.run(6)["draws"]
+        ctx.close()
+        return out, log, dt
+    a, log_a, t_a = run()
+    files = glob.glob(str(tmp_path / "dhmc_rtc_*.co"))
+    assert len(files) == 1 and "loaded from" not in log_a
+    b, log_b, t_b = run()
+    assert "loaded from" in log_b and np.array_equal(a, b) and t_b < t_a
+    with open(files[0], "r+b") as fh:                       # damage the file: it is not trusted, the functor is compiled again
+        fh.seek(0); fh.write(b"garbage!")
+    c, log_c, _ = run()
+    assert "loaded from" not in log_c and np.array_equal(a, c)
+    d, log_d, _ = run()
+    assert "loaded from" in log_d and np.array_equal(a, d)
