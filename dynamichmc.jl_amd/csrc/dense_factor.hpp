@@ -27,7 +27,11 @@ constexpr int DF_NB = 32;
 
 // S[i][j] (ld-padded, zero outside D×D) = Symmetric(src) read from the upper triangle of src (row stride lsrc);
 // *bad |= any non-finite entry
-__global__ void df_symmetrize_kernel(const double* __restrict__ src, int lsrc, int D, double* __restrict__ S, int ld, int* __restrict__ bad) {
+// Batches (per-chain metrics, several chains per launch): every kernel below takes the matrices of batch element blockIdx.z at
+// stride `bs` doubles (flags at stride 2 ints); bs = 0 and a grid of depth 1 is the single-matrix form.
+__global__ void df_symmetrize_kernel(const double* __restrict__ src, int lsrc, int D, double* __restrict__ S, int ld, int* __restrict__ bad,
+                                     size_t src_bs = 0, size_t bs = 0) {
+    src += blockIdx.z * src_bs; S += blockIdx.z * bs; bad += 2 * blockIdx.z;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)ld * ld) return;
     const int i = (int)(idx / ld), j = (int)(idx % ld);
@@ -38,25 +42,29 @@ __global__ void df_symmetrize_kernel(const double* __restrict__ src, int lsrc, i
     }
     S[idx] = v;
 }
-__global__ void df_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+__global__ void df_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n, size_t bs = 0) {
+    src += blockIdx.z * bs; dst += blockIdx.z * bs;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) dst[idx] = src[idx];
 }
-__global__ void df_identity_kernel(double* __restrict__ X, int D, int ld) {
+__global__ void df_identity_kernel(double* __restrict__ X, int D, int ld, size_t bs = 0) {
+    X += blockIdx.z * bs;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)ld * ld) return;
     const int i = (int)(idx / ld), j = (int)(idx % ld);
     X[idx] = (i == j && i < D) ? 1.0 : 0.0;
 }
 // dst = srcᵀ (both [ld][ld]); 32×32 tiles through LDS
-__global__ void df_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int ld) {
+__global__ void df_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int ld, size_t src_bs = 0, size_t dst_bs = 0) {
+    src += blockIdx.z * src_bs; dst += blockIdx.z * dst_bs;
     __shared__ double t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) t[r][threadIdx.x] = src[(size_t)(by + r) * ld + bx + threadIdx.x];
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) dst[(size_t)(bx + r) * ld + by + threadIdx.x] = t[threadIdx.x][r];
 }
-__global__ void df_zero_upper_kernel(double* __restrict__ A, int D, int ld) {
+__global__ void df_zero_upper_kernel(double* __restrict__ A, int D, int ld, size_t bs = 0) {
+    A += blockIdx.z * bs;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)D * D) return;
     const int i = (int)(idx / D), j = (int)(idx % D);
@@ -64,7 +72,8 @@ __global__ void df_zero_upper_kernel(double* __restrict__ A, int D, int ld) {
 }
 
 // ---- Cholesky, block J0..J0+nb: (1) the diagonal block, one workgroup ------------------------------------------
-__global__ __launch_bounds__(64) void df_chol_diag_kernel(double* __restrict__ A, int ld, int J0, int nb, int* __restrict__ notpd) {
+__global__ __launch_bounds__(64) void df_chol_diag_kernel(double* __restrict__ A, int ld, int J0, int nb, int* __restrict__ notpd, size_t bs = 0) {
+    A += blockIdx.z * bs; notpd += 2 * blockIdx.z;
     __shared__ double a[DF_NB][DF_NB + 1];
     const int l = threadIdx.x;                       // row of the block
     if (l < nb)
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(64) void df_chol_diag_kernel(double* __restrict__ A
         for (int j = 0; j <= l; ++j) A[(size_t)(J0 + l) * ld + J0 + j] = a[l][j];
 }
 // (2) the block's columns for the rows below it: a thread per row
-__global__ __launch_bounds__(128) void df_chol_panel_kernel(double* __restrict__ A, int ld, int D, int J0, int nb) {
+__global__ __launch_bounds__(128) void df_chol_panel_kernel(double* __restrict__ A, int ld, int D, int J0, int nb, size_t bs = 0) {
+    A += blockIdx.z * bs;
     __shared__ double Ld[DF_NB][DF_NB + 1];
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) Ld[t / nb][t % nb] = A[(size_t)(J0 + t / nb) * ld + J0 + t % nb];
     __syncthreads();
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(128) void df_chol_panel_kernel(double* __restrict__
 }
 // (3) trailing update: A_ij <- chain over the block's columns k ascending of fma(−A_ik, A_jk, ·), J0+nb <= j <= i < D.
 // 32×32 output tile per workgroup of 256 threads (4 outputs each); tiles above the diagonal exit at once.
-__global__ __launch_bounds__(256) void df_chol_trailing_kernel(double* __restrict__ A, int ld, int D, int J0, int nb) {
+__global__ __launch_bounds__(256) void df_chol_trailing_kernel(double* __restrict__ A, int ld, int D, int J0, int nb, size_t bs = 0) {
+    A += blockIdx.z * bs;
     const int T0 = J0 + nb;
     const int ti = T0 + blockIdx.y * 32, tj = T0 + blockIdx.x * 32;
     if (tj > ti) return;
@@ -139,7 +150,8 @@ __global__ __launch_bounds__(256) void df_chol_trailing_kernel(double* __restric
 
 // ---- X = L⁻¹ (lower triangular), block of rows K0..K0+nb; X starts as the identity -------------------------------
 // (1) the block's rows for every column c < K0+nb: a thread per column
-__global__ __launch_bounds__(128) void df_inv_rows_kernel(const double* __restrict__ L, double* __restrict__ X, int ld, int K0, int nb) {
+__global__ __launch_bounds__(128) void df_inv_rows_kernel(const double* __restrict__ L, double* __restrict__ X, int ld, int K0, int nb, size_t bs = 0) {
+    L += blockIdx.z * bs; X += blockIdx.z * bs;
     __shared__ double Ld[DF_NB][DF_NB + 1];
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) Ld[t / nb][t % nb] = L[(size_t)(K0 + t / nb) * ld + K0 + t % nb];
     __syncthreads();
@@ -163,7 +175,9 @@ __global__ __launch_bounds__(128) void df_inv_rows_kernel(const double* __restri
         if (r < nb) X[(size_t)(K0 + r) * ld + c] = s[r];
 }
 // (2) trailing update: X_ic <- chain over the block's rows k ascending of fma(−L_i,K0+k, X_K0+k,c, ·), i >= K0+nb, c < K0+nb
-__global__ __launch_bounds__(256) void df_inv_trailing_kernel(const double* __restrict__ L, double* __restrict__ X, int ld, int D, int K0, int nb) {
+__global__ __launch_bounds__(256) void df_inv_trailing_kernel(const double* __restrict__ L, double* __restrict__ X, int ld, int D, int K0, int nb,
+                                                              size_t bs = 0) {
+    L += blockIdx.z * bs; X += blockIdx.z * bs;
     const int ti = K0 + nb + blockIdx.y * 32, tc = blockIdx.x * 32;
     __shared__ double Li[32][DF_NB + 1], Xk[DF_NB][33];
     for (int t = threadIdx.x; t < 32 * DF_NB; t += 256) {
@@ -190,50 +204,94 @@ __global__ __launch_bounds__(256) void df_inv_trailing_kernel(const double* __re
     }
 }
 
+// M = XᵀX for a batch of matrices: M_ij = fma chain over r = 0 .. ld−1 ascending from 0 — the operations of the MFMA product
+// launch_gemm(Xᵀ, X) of the single-matrix path, one output per thread (32×32 tiles, X tiles through LDS).
+__global__ __launch_bounds__(256) void df_xtx_kernel(const double* __restrict__ X, double* __restrict__ M, int ld, size_t bs) {
+    X += blockIdx.z * bs; M += blockIdx.z * bs;
+    __shared__ double Xi[32][33], Xj[32][33];
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < ld; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 8 * u;
+            Xi[r][c] = X[(size_t)(k0 + r) * ld + i0 + c];
+            Xj[r][c] = X[(size_t)(k0 + r) * ld + j0 + c];
+        }
+        __syncthreads();
+        for (int k = 0; k < 32; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_fma(Xi[k][r0 + 8 * u], Xj[k][c], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) M[(size_t)(i0 + r0 + 8 * u) * ld + j0 + c] = acc[u];
+}
+// where the flags of a batch element are clear: its S and Wᵀ become the chain's metric (per-chain dense contexts)
+__global__ void df_commit_kernel(const double* __restrict__ S, const double* __restrict__ WT, const int* __restrict__ flags, double* __restrict__ Minv,
+                                 double* __restrict__ WTout, size_t n) {
+    const int b = blockIdx.z;
+    if (flags[2 * b] || flags[2 * b + 1]) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    Minv[(size_t)b * n + idx] = S[(size_t)b * n + idx];
+    WTout[(size_t)b * n + idx] = WT[(size_t)b * n + idx];
+}
+
 // In-place lower Cholesky of the symmetric [D×D] matrix in A (ld-padded); the strict upper triangle is zeroed.
-// *notpd (device int, zeroed by the caller) is set if a pivot is not positive.
-inline void df_cholesky(double* A, int D, int ld, int* notpd, hipStream_t s) {
+// *notpd (device int, zeroed by the caller) is set if a pivot is not positive.  B matrices at stride bs (flags at stride 2).
+inline void df_cholesky(double* A, int D, int ld, int* notpd, hipStream_t s, int B = 1, size_t bs = 0) {
+    const unsigned Bz = (unsigned)B;
     for (int J0 = 0; J0 < D; J0 += DF_NB) {
         const int nb = D - J0 < DF_NB ? D - J0 : DF_NB;
-        hipLaunchKernelGGL(df_chol_diag_kernel, dim3(1), dim3(64), 0, s, A, ld, J0, nb, notpd);
+        hipLaunchKernelGGL(df_chol_diag_kernel, dim3(1, 1, Bz), dim3(64), 0, s, A, ld, J0, nb, notpd, bs);
         const int below = D - J0 - nb;
         if (below > 0) {
-            hipLaunchKernelGGL(df_chol_panel_kernel, dim3((below + 127) / 128), dim3(128), 0, s, A, ld, D, J0, nb);
+            hipLaunchKernelGGL(df_chol_panel_kernel, dim3((below + 127) / 128, 1, Bz), dim3(128), 0, s, A, ld, D, J0, nb, bs);
             const int nt = (below + 31) / 32;
-            hipLaunchKernelGGL(df_chol_trailing_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, D, J0, nb);
+            hipLaunchKernelGGL(df_chol_trailing_kernel, dim3(nt, nt, Bz), dim3(256), 0, s, A, ld, D, J0, nb, bs);
         }
     }
-    hipLaunchKernelGGL(df_zero_upper_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, s, A, D, ld);
+    hipLaunchKernelGGL(df_zero_upper_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256), 1, Bz), dim3(256), 0, s, A, D, ld, bs);
 }
 // X = L⁻¹ for the lower-triangular [D×D] L; X is [ld][ld]
-inline void df_lower_inverse(const double* L, double* X, int D, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(df_identity_kernel, dim3((unsigned)(((size_t)ld * ld + 255) / 256)), dim3(256), 0, s, X, D, ld);
+inline void df_lower_inverse(const double* L, double* X, int D, int ld, hipStream_t s, int B = 1, size_t bs = 0) {
+    const unsigned Bz = (unsigned)B;
+    hipLaunchKernelGGL(df_identity_kernel, dim3((unsigned)(((size_t)ld * ld + 255) / 256), 1, Bz), dim3(256), 0, s, X, D, ld, bs);
     for (int K0 = 0; K0 < D; K0 += DF_NB) {
         const int nb = D - K0 < DF_NB ? D - K0 : DF_NB;
-        hipLaunchKernelGGL(df_inv_rows_kernel, dim3((K0 + nb + 127) / 128), dim3(128), 0, s, L, X, ld, K0, nb);
+        hipLaunchKernelGGL(df_inv_rows_kernel, dim3((K0 + nb + 127) / 128, 1, Bz), dim3(128), 0, s, L, X, ld, K0, nb, bs);
         const int below = D - K0 - nb;
         if (below > 0)
-            hipLaunchKernelGGL(df_inv_trailing_kernel, dim3((K0 + nb + 31) / 32, (below + 31) / 32), dim3(256), 0, s, L, X, ld, D, K0, nb);
+            hipLaunchKernelGGL(df_inv_trailing_kernel, dim3((K0 + nb + 31) / 32, (below + 31) / 32, Bz), dim3(256), 0, s, L, X, ld, D, K0, nb, bs);
     }
 }
 
 // Minv_out <- Symmetric(S_in) and WT_out <- Wᵀ with W Wᵀ = inv(S) (all [ld][ld], zero padded), from S_in already
-// symmetric and padded on the device.  work: 3 buffers of ld² doubles.  *flags: [0] non-finite input (set by the caller's
-// symmetrisation), [1] not positive definite.
-inline void df_dense_metric(const double* S, double* Minv_out, double* WT_out, int D, int ld, double* work, int* flags, hipStream_t s) {
+// symmetric and padded on the device.  work: 3 buffers of B·ld² doubles.  flags [B][2]: [0] non-finite input (set by the caller's
+// symmetrisation), [1] not positive definite.  B > 1: B matrices at stride ld² in S / Minv_out / WT_out, every step one launch
+// for the whole batch (M = XᵀX by df_xtx_kernel instead of the MFMA GEMM: the same fma chains).
+inline void df_dense_metric(const double* S, double* Minv_out, double* WT_out, int D, int ld, double* work, int* flags, hipStream_t s, int B = 1) {
     const size_t n = (size_t)ld * ld;
-    double* L1 = work;            // chol(S), later M = XᵀX and its Cholesky factor W
-    double* X = work + n;
-    double* XT = work + 2 * n;
+    const size_t bs = B > 1 ? n : 0;
+    const unsigned Bz = (unsigned)B;
+    double* L1 = work;                    // chol(S), later M = XᵀX and its Cholesky factor W
+    double* X = work + (size_t)B * n;
+    double* XT = work + 2 * (size_t)B * n;
     const unsigned g = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(df_copy_kernel, dim3(g), dim3(256), 0, s, S, L1, n);
-    df_cholesky(L1, D, ld, flags + 1, s);                                   // L₁ = chol(S)
-    df_lower_inverse(L1, X, D, ld, s);                                      // X = L₁⁻¹
-    hipLaunchKernelGGL(df_transpose_kernel, dim3(ld / 32, ld / 32), dim3(32, 8), 0, s, X, XT, ld);
-    launch_gemm(XT, ld, X, ld, L1, ld, ld, ld, ld, s);                      // M = XᵀX: k-ascending fma chains (fp64 MFMA)
-    df_cholesky(L1, D, ld, flags + 1, s);                                   // W = chol(M)
-    hipLaunchKernelGGL(df_transpose_kernel, dim3(ld / 32, ld / 32), dim3(32, 8), 0, s, L1, WT_out, ld);
-    if (Minv_out != S) hipLaunchKernelGGL(df_copy_kernel, dim3(g), dim3(256), 0, s, S, Minv_out, n);
+    hipLaunchKernelGGL(df_copy_kernel, dim3(g, 1, Bz), dim3(256), 0, s, S, L1, n, bs);
+    df_cholesky(L1, D, ld, flags + 1, s, B, bs);                            // L₁ = chol(S)
+    df_lower_inverse(L1, X, D, ld, s, B, bs);                               // X = L₁⁻¹
+    if (B == 1) {
+        hipLaunchKernelGGL(df_transpose_kernel, dim3(ld / 32, ld / 32), dim3(32, 8), 0, s, X, XT, ld, (size_t)0, (size_t)0);
+        launch_gemm(XT, ld, X, ld, L1, ld, ld, ld, ld, s);                  // M = XᵀX: k-ascending fma chains (fp64 MFMA)
+    } else {
+        hipLaunchKernelGGL(df_xtx_kernel, dim3(ld / 32, ld / 32, Bz), dim3(256), 0, s, X, L1, ld, bs);
+    }
+    df_cholesky(L1, D, ld, flags + 1, s, B, bs);                            // W = chol(M)
+    hipLaunchKernelGGL(df_transpose_kernel, dim3(ld / 32, ld / 32, Bz), dim3(32, 8), 0, s, L1, WT_out, ld, bs, bs);
+    if (Minv_out != S) hipLaunchKernelGGL(df_copy_kernel, dim3(g, 1, Bz), dim3(256), 0, s, S, Minv_out, n, bs);
 }
 
 }  // namespace dhmc

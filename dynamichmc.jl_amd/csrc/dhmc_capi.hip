@@ -1478,25 +1478,57 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     Staged s;
     int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s);
     if (rc) return rc;
-    DevBuf bmean, bS;
-    HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
-    HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
-    double* const mean = (double*)bmean.p;
-    double* const S = (double*)bS.p;
     int refused = 0, first_refused = -1;
-    for (int k = 0; k < nest && rc == DHMC_OK; ++k) {
-        const double* x = (const double*)s.dev + (size_t)k * J * D;
-        hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean);
-        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld);
-        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S);
+    if (!c->per_chain_dense) {
+        DevBuf bmean, bS;
+        HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
+        HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
+        double* const mean = (double*)bmean.p;
+        double* const S = (double*)bS.p;
+        const double* x = (const double*)s.dev;
+        hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S, (size_t)0);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; break; }
-        rc = device_dense_metric(c, S, ld, c->per_chain_dense ? k : -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
-        // per-chain metrics: every chain stands for itself, as in the reference (mcmc.jl:281-285 runs per chain): a chain whose
-        // estimate is refused keeps its metric, the others are updated all the same
-        if (rc == DHMC_ERR_INVALID_ARGUMENT && c->per_chain_dense) {
-            if (refused++ == 0) first_refused = k;
-            rc = DHMC_OK;
+        if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }
+        else rc = device_dense_metric(c, S, ld, -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
+    } else {
+        // per-chain metrics (mcmc.jl:281-285 runs per chain): estimate, regularise and factorise a BATCH of chains per launch
+        // (blockIdx.z = chain; the same kernels, so the same bits as chain by chain), ≈ 1 GiB of work space at a time.  Every chain
+        // stands for itself: one whose estimate is refused keeps its metric, the others are updated all the same.
+        const size_t n = (size_t)ld * ld;
+        const int Bmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)nest, ((size_t)1 << 30) / (5 * n * sizeof(double))));
+        DevBuf bmean, bS, bwork, bflags;
+        HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * (size_t)Bmax * ld));
+        HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)Bmax * n * 2));          // the estimates, and Symmetric(estimate)
+        HIP_TRY(c, hipMalloc(&bwork.p, sizeof(double) * (size_t)Bmax * n * 3));
+        HIP_TRY(c, hipMalloc(&bflags.p, sizeof(int) * 2 * (size_t)Bmax));
+        double* const mean = (double*)bmean.p;
+        double* const S = (double*)bS.p;
+        double* const Ssym = S + (size_t)Bmax * n;
+        double* const work = (double*)bwork.p;
+        int* const flags = (int*)bflags.p;
+        std::vector<int> hflags(2 * (size_t)Bmax);
+        for (int k0 = 0; k0 < nest && rc == DHMC_OK; k0 += Bmax) {
+            const int B = std::min(Bmax, nest - k0);
+            const unsigned Bz = (unsigned)B;
+            const double* x = (const double*)s.dev + (size_t)k0 * J * D;
+            HIP_TRY(c, hipMemsetAsync(flags, 0, sizeof(int) * 2 * (size_t)B, c->stream));
+            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256, 1, Bz), dim3(256), 0, c->stream, D, J, x, mean, (size_t)J * D, (size_t)ld);
+            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64, Bz), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)J * D, (size_t)ld, n);
+            hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256), 1, Bz), dim3(256), 0, c->stream, D, ld, J, lambda, S, n);
+            hipLaunchKernelGGL(df_symmetrize_kernel, dim3((unsigned)((n + 255) / 256), 1, Bz), dim3(256), 0, c->stream, (const double*)S, ld, D, Ssym, ld,
+                               flags, n, n);
+            double* const WTb = work + (size_t)B * n;                                  // the X buffers: free again once M = XᵀX exists
+            df_dense_metric(Ssym, Ssym, WTb, D, ld, work, flags, c->stream, B);
+            hipLaunchKernelGGL(df_commit_kernel, dim3((unsigned)((n + 255) / 256), 1, Bz), dim3(256), 0, c->stream, (const double*)Ssym, (const double*)WTb,
+                               (const int*)flags, c->d_Minv + (size_t)k0 * n, c->d_WT + (size_t)k0 * n, n);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; break; }
+            HIP_TRY(c, hipMemcpyAsync(hflags.data(), flags, sizeof(int) * 2 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int b2 = 0; b2 < B; ++b2)
+                if (hflags[2 * b2] || hflags[2 * b2 + 1]) { if (refused++ == 0) first_refused = k0 + b2; }
         }
     }
     stage_free(c, &s);

@@ -10,7 +10,9 @@
 
 namespace dhmc {
 
-__global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ X, double* __restrict__ mean) {
+// (blockIdx.z: batch element — one chain of a per-chain dense context — at strides x_bs / mean_bs / out_bs doubles)
+__global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ X, double* __restrict__ mean, size_t x_bs = 0, size_t mean_bs = 0) {
+    X += blockIdx.z * x_bs; mean += blockIdx.z * mean_bs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
     double s = 0.0;
@@ -20,7 +22,9 @@ __global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ 
 
 // OUT[i][k] (ld = ldo, i,k < Dpad) = Σ_j (X[j][i]-mean[i])·(X[j][k]-mean[k]); X is [J][D] unpadded; columns >= D give 0.
 __global__ __launch_bounds__(256) void pooled_cov_kernel(int D, int64_t J, const double* __restrict__ X,
-                                                         const double* __restrict__ mean, double* __restrict__ OUT, int ldo) {
+                                                         const double* __restrict__ mean, double* __restrict__ OUT, int ldo,
+                                                         size_t x_bs = 0, size_t mean_bs = 0, size_t out_bs = 0) {
+    X += blockIdx.z * x_bs; mean += blockIdx.z * mean_bs; OUT += blockIdx.z * out_bs;
     const int i0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(256) void pooled_cov_kernel(int D, int64_t J, const
 }
 
 // Σ = S/(J-1), then regularize_M⁻¹(Σ, λ) = (1-λ)Σ + λ Diagonal(diag Σ)   (mcmc.jl:218-222), in place.
-__global__ void cov_regularize_kernel(int D, int ld, int64_t J, double lambda, double* __restrict__ S) {
+__global__ void cov_regularize_kernel(int D, int ld, int64_t J, double lambda, double* __restrict__ S, size_t bs = 0) {
+    S += blockIdx.z * bs;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)D * D) return;
     const int i = (int)(idx / D), k = (int)(idx % D);

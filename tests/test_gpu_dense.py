@@ -242,6 +242,26 @@ def test_per_chain_dense_metric_is_the_references_semantics(pkg):
         assert np.array_equal(dev.metric_dense(c)[0], ora.metric_dense(c)[0])
 
 
+def test_per_chain_dense_update_in_batches_across_block_boundaries(pkg):
+    """The per-chain update estimates and factorises all chains of a batch per launch (blockIdx.z = chain): D = 70 spans three
+    32-step Cholesky blocks and two 64-column covariance tiles; every chain's M⁻¹ and W bit-equal to the oracle's."""
+    K, C, n = 70, 6, 150
+    sig = np.logspace(-0.5, 0.5, K)
+    params = ol.target_params_blob(ol.TARGET_DIAG_NORMAL, K, mu=np.zeros(K), prec=1 / sig ** 2)
+    kw = dict(metric=ol.METRIC_DENSE, target=ol.TARGET_DIAG_NORMAL, seed=33, dense_per_chain=True)
+    dev = pkg.DeviceContext(K, C, target_params=params, **kw)
+    ora = ol.Oracle(K, C, params=params, threads=6, **kw)
+    for e in (dev, ora):
+        e.init(); e.find_initial_stepsize()
+    a, b = dev.run(n, da={}), ora.run(n, da={})
+    same(a, b, "stage")
+    dev.update_metric_dense(a["draws"], 5.0 / n); ora.update_metric_dense(b["draws"], 5.0 / n)
+    for c in range(C):
+        md, Wd = dev.metric_dense(c); mo, Wo = ora.metric_dense(c)
+        assert np.array_equal(md, mo) and np.array_equal(Wd, Wo), c
+    same(dev.run(4, da={}), ora.run(4, da={}), "after the update")
+
+
 def test_per_chain_dense_update_lets_every_chain_stand_for_itself(pkg):
     """with dense_per_chain a chain whose covariance estimate is refused (here: a chain whose window draws are all the
     same point — zero covariance, λ = 0) keeps its metric, while every other chain is updated; the call reports
