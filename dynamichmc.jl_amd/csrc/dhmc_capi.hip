@@ -1056,7 +1056,8 @@ int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
     return status_code(c);
 }
 
-int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {
+namespace {
+int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {
     if (!c || N < 0) return DHMC_ERR_INVALID_ARGUMENT;
     DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1452,6 +1453,86 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 if (sb.p) { (void)hipFree(sb.p); sb.p = nullptr; sb.cap = 0; }
     }
     return status_code(c);
+}
+}  // namespace
+
+// The round engines (dense metric, GEMM-shaped gradients, external models) advance their chains round by round, so a call cannot
+// hand out its first transitions while it computes the last ones.  With HOST outputs of more than ≈ 2 GiB of draws the call is
+// therefore run as several calls of L transitions (the chains resume where they stand: the same transitions, the same bits) into
+// two device staging buffers of ≈ 1 GiB, and chunk k leaves over the copy stream while chunk k + 1 computes — what the diagonal
+// engine does inside one call (run_call).  Dual averaging: initialised by the first chunk, finalised by the last.
+int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_outputs* out) {
+    if (!c || N < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    const bool one_kernel = c->cfg.metric == DHMC_METRIC_DIAG && !c->logistic_rounds && !c->external;
+    const bool host_draws = out && !out->on_device && out->draws;
+    const int64_t per_transition = (int64_t)c->cfg.chains * c->cfg.dim * (int64_t)sizeof(double);
+    int64_t L = N;
+    if (host_draws && !one_kernel && N > 1) {
+        if (c->host_chunk > 0) L = std::min<int64_t>(c->host_chunk, N);
+        else if (per_transition * N > ((int64_t)2 << 30)) L = std::max<int64_t>(1, ((int64_t)1 << 30) / per_transition);
+    }
+    if (L >= N) return run_call(c, N, da, out);
+
+    DHMC_CHECK_USABLE(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    struct F { void* host; size_t elem; int idx; };
+    const F fields[10] = {{out->draws, (size_t)c->cfg.dim * sizeof(double), 0}, {out->logdensities, sizeof(double), 1}, {out->eps, sizeof(double), 2},
+                          {out->pi, sizeof(double), 3}, {out->acceptance_rate, sizeof(double), 4}, {out->steps, sizeof(int64_t), 5},
+                          {out->term_left, sizeof(int64_t), 6}, {out->term_right, sizeof(int64_t), 7}, {out->depth, sizeof(int32_t), 8},
+                          {out->directions, sizeof(uint32_t), 9}};
+    const size_t C = (size_t)c->cfg.chains;
+    for (const F& f : fields) {
+        if (!f.host) continue;
+        for (int b = 0; b < 2; ++b) {
+            auto& sb = c->stage[b][f.idx];
+            const size_t need = C * (size_t)L * f.elem;
+            if (sb.cap < need) {
+                if (sb.p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(sb.p)); sb.p = nullptr; sb.cap = 0; }
+                HIP_TRY(c, hipMalloc(&sb.p, need));
+                sb.cap = need;
+            }
+        }
+    }
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(c, hipEventCreate(&c->ev_k0[b]));
+            HIP_TRY(c, hipEventCreate(&c->ev_k1[b]));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[b], hipEventDisableTiming));
+        }
+    }
+    const int64_t nchunks = (N + L - 1) / L;
+    double ms = 0.0;
+    unsigned long long leapfrogs = 0, rounds = 0;
+    int rc = DHMC_OK;
+    bool used[2] = {false, false};
+    for (int64_t k = 0; k < nchunks; ++k) {
+        const int b = (int)(k & 1);
+        const int64_t n0 = k * L, len = std::min(L, N - n0);
+        if (used[b]) HIP_TRY(c, hipEventSynchronize(c->ev_copy[b]));            // staging buffer b is free again
+        dhmc_outputs dev{};
+        dev.on_device = 1;
+        void** slots[10] = {(void**)&dev.draws, (void**)&dev.logdensities, (void**)&dev.eps, (void**)&dev.pi, (void**)&dev.acceptance_rate,
+                            (void**)&dev.steps, (void**)&dev.term_left, (void**)&dev.term_right, (void**)&dev.depth, (void**)&dev.directions};
+        for (const F& f : fields)
+            if (f.host) *slots[f.idx] = c->stage[b][f.idx].p;
+        dhmc_dual_averaging dk{};
+        if (da) { dk = *da; dk.init = (k == 0) ? da->init : 0; dk.finalize = (k == nchunks - 1) ? da->finalize : 0; }
+        const int r = run_call(c, len, da ? &dk : nullptr, &dev);              // returns with the stream drained
+        ms += c->last_ms; leapfrogs += c->last_leapfrogs; rounds += c->last_rounds;
+        if (r != DHMC_OK && r != DHMC_ERR_CHAIN_FAILURE) { (void)hipStreamSynchronize(c->copy_stream); return r; }
+        if (r != DHMC_OK) rc = r;                                              // (a failed chain: the call goes on, as one call would)
+        for (const F& f : fields) {
+            if (!f.host) continue;
+            HIP_TRY(c, hipMemcpy2DAsync((char*)f.host + (size_t)n0 * f.elem, (size_t)N * f.elem, c->stage[b][f.idx].p, (size_t)len * f.elem,
+                                        (size_t)len * f.elem, C, hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_copy[b], c->copy_stream));
+        used[b] = true;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    c->last_ms = ms; c->last_leapfrogs = leapfrogs; c->last_rounds = rounds;
+    return rc;
 }
 
 int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {

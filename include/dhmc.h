@@ -176,7 +176,7 @@ typedef struct dhmc_outputs {
 
 /* ---- page-locked host memory for result buffers ---------------------------------------- */
 /* dhmc_run with host pointers copies every output field device -> host.  Into PAGE-LOCKED memory those copies run at PCIe
- * speed and — with the diagonal metric, where a call leaves in chunks of transitions — under the next chunk's kernel; into
+ * speed and under the next chunk's kernels (a call with more than ≈ 1–2 GiB of draws leaves in chunks of transitions); into
  * pageable memory the runtime stages them at a fraction of that.  These two calls hand out / take back page-locked
  * memory (hipHostMalloc) for callers that cannot allocate it themselves; any page-locked memory works the same. */
 int dhmc_host_alloc(void** out, uint64_t nbytes);

@@ -383,16 +383,23 @@ def test_host_outputs_in_chunks_equal_device_outputs(pkg, monkeypatch):
     fields = pkg.abi.OUTPUT_FIELDS
     tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32, np.uint32: torch.int32}
 
-    def run(kind, chunk):
+    def run(kind, chunk, engine="diag"):
         if chunk:
             monkeypatch.setenv("DHMC_HOST_CHUNK", str(chunk))
         else:
             monkeypatch.delenv("DHMC_HOST_CHUNK", raising=False)
-        ctx = pkg.DeviceContext(D, C, seed=12)
+        if engine == "diag":
+            ctx = pkg.DeviceContext(D, C, seed=12)
+        elif engine == "dense":                                # the GEMM round engine (one-product recurrence): a call per chunk
+            ctx = pkg.DeviceContext(D, C, seed=12, metric=ol.METRIC_DENSE)
+            ctx.set_metric_dense(np.diag(np.linspace(0.5, 2.0, D)) + 0.05)
+        else:                                                  # the batched-evaluation engine (external models, D > 1024)
+            ctx = pkg.DeviceContext(1100, C, seed=12)
         ctx.init(); ctx.find_initial_stepsize()
+        Dd = ctx.D
         res = []
         for da in ({}, None):
-            shape = lambda k: (C, N, D) if k == "draws" else (C, N)
+            shape = lambda k: (C, N, Dd) if k == "draws" else (C, N)
             if kind == "device":
                 arrs = {k: torch.zeros(shape(k), dtype=tdt[dt], device="cuda") for k, dt in fields}
             elif kind == "pinned":
@@ -411,3 +418,11 @@ def test_host_outputs_in_chunks_equal_device_outputs(pkg, monkeypatch):
         for a, b in zip(ref, got):
             for k in a:
                 assert np.array_equal(a[k], b[k]), (kind, chunk, k)
+    # the round engines: with host outputs a long call runs as calls of L transitions (dhmc_run), chunk k leaving while k + 1 computes
+    for engine in ("dense", "big"):
+        ref = run("device", 0, engine)
+        for kind, chunk in (("pageable", 4), ("pinned", 3), ("pinned", 1)):
+            got = run(kind, chunk, engine)
+            for a, b in zip(ref, got):
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (engine, kind, chunk, k)

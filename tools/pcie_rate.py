@@ -2,7 +2,8 @@
 DeviceContext.run() hand over), BASELINE config 2 (D = 1000, 4096 chains, adapted ϵ / metric).  Never bench.py's `value`
 (that keeps outputs in HBM); DESIGN.md §6 quotes these numbers.
 
-    python tools/pcie_rate.py [transitions per call]      (default 100)
+    python tools/pcie_rate.py [transitions per call] [dense]      (default 100; "dense": BASELINE config 3's dense metric through the
+                                                                   GEMM round engine, whose long host-output calls dhmc_run splits)
 
 Three destinations: pageable numpy arrays (the runtime stages the copies), page-locked arrays (pinned_empty /
 dhmc_host_alloc: asynchronous 2-D copies under the next chunk's kernel), and device buffers for comparison.  Draws are
@@ -18,8 +19,13 @@ import torch
 
 D, C = 1000, 4096
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-ctx = pkg.DeviceContext(D, C, seed=1); ctx.init(); ctx.find_initial_stepsize()
-r = ctx.run(60, da={}, fields=["draws"]); ctx.update_metric_diag(r["draws"][:, 30:]); ctx.run(40, da={}, fields=[])
+DENSE = len(sys.argv) > 2 and sys.argv[2] == "dense"
+if DENSE:
+    import oracle_lib_free_config3 as c3                       # (tools/: the config-3 target without the test tree)
+    ctx = c3.context(pkg, D, C)
+else:
+    ctx = pkg.DeviceContext(D, C, seed=1); ctx.init(); ctx.find_initial_stepsize()
+    r = ctx.run(60, da={}, fields=["draws"]); ctx.update_metric_diag(r["draws"][:, 30:]); ctx.run(40, da={}, fields=[])
 fields = (("draws", np.float64), ("steps", np.int64), ("depth", np.int32), ("acceptance_rate", np.float64), ("logdensities", np.float64))
 shape = lambda k: (C, T, D) if k == "draws" else (C, T)
 
@@ -34,7 +40,7 @@ def timed(arrs, reps=3):
     return {"steps_per_s": lf / dt, "ms_per_call": dt / reps * 1e3, "kernel_ms_per_call": kms / reps, "GB_per_s": nbytes * reps / dt / 1e9}
 
 
-out = {"transitions_per_call": T, "chains": C, "dim": D}
+out = {"transitions_per_call": T, "chains": C, "dim": D, "metric": "dense" if DENSE else "diag", "host_chunk_env": os.environ.get("DHMC_HOST_CHUNK")}
 out["pageable"] = timed({k: np.zeros(shape(k), dt) for k, dt in fields})
 out["page_locked"] = timed({k: pinned_empty(shape(k), dt) for k, dt in fields})
 tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}
