@@ -202,7 +202,9 @@ struct dhmc_ctx {
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     LogisticRound lr{};
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
-    int builtin_big = 0;       // a built-in normal family with more than 1024 coordinates: the same engine, density from builtin_normal_eval_kernel
+    int builtin_big = 0;       // a built-in normal family / the funnel with more than 1024 coordinates: the same engine, density from builtin_normal_eval_kernel
+    int* d_all_rows = nullptr; // DHMC_TARGET_LOGISTIC beyond 1024 coefficients: the row list 0..C-1 and its length, for the GEMMs of the batched gradient
+    double* d_big[2] = {};     // DHMC_TARGET_DENSE_NORMAL beyond 1024 coordinates: q − μ and P(q − μ) of all chains ([C][Dpad] each)
     dhmc_logdensity_fn ext_fn = nullptr;
     void* ext_user = nullptr;
     ExtSearchState* d_ss = nullptr;
@@ -517,7 +519,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->cfg.target_params = nullptr;
     // beyond 1024 coordinates the streaming round-engine kernels serve external models and the built-in normal families
     c->builtin_big = D > 1024 && (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL ||
-                                  cfg->target == DHMC_TARGET_TRIDIAG_NORMAL);
+                                  cfg->target == DHMC_TARGET_TRIDIAG_NORMAL || cfg->target == DHMC_TARGET_FUNNEL ||
+                                  cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_LOGISTIC);
     c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big);
     if (cfg->target == DHMC_TARGET_EXTERNAL)
         if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels
@@ -529,9 +532,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // Round engines pay ≈8 launches per leapfrog round; they win once a round carries enough chains to fill the
     // chip (GEMM rows), otherwise the one-wave-per-chain kernels are faster.  DHMC_*_ROUNDS=0/1 overrides.
     const bool many_chains = cfg->chains >= 128;
-    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && many_chains;
+    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && many_chains && !c->builtin_big;
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
-        c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0;
+        c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0 && !c->builtin_big;
     c->dense_rounds = many_chains;
     c->external = cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
@@ -689,6 +692,15 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemcpy(dxt, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemcpy(dy, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         c->tp.a = dx; c->tp.b = dxt; c->tp.c = dy; c->tp.n = n; c->tp.npad = (int64_t)npad; c->tp.Dpad = (int32_t)Dp;
+        if (c->builtin_big) {             // more than 1024 coefficients: the gradient of all chains between the kernels (external_eval)
+            if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
+            c->lr.nz = (int)((npad + DHMC_LOGISTIC_BLOCK - 1) / DHMC_LOGISTIC_BLOCK);
+            if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
+            if ((rc = dev_alloc(c, &c->lr.S1P, (size_t)c->lr.nz * C))) return fail(rc);
+            if ((rc = dev_alloc(c, &c->d_all_rows, C + 1))) return fail(rc);
+            hipLaunchKernelGGL(builtin_all_rows_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, nullptr, (int)C, c->d_all_rows, c->d_all_rows + C);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(DHMC_ERR_HIP);
+        }
         if (c->logistic_rounds) {
             if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
@@ -699,6 +711,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             c->lr.act_count = c->lr.act + C;
         }
     }
+    if (c->builtin_big && cfg->target == DHMC_TARGET_DENSE_NORMAL)
+        for (int i = 0; i < 2; ++i)
+            if ((rc = dev_alloc(c, &c->d_big[i], C * Dp))) return fail(rc);
     if (c->external) {
         if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
         if ((rc = dev_alloc(c, &c->d_ss, C))) return fail(rc);
@@ -779,8 +794,36 @@ int dhmc_destroy(dhmc_ctx* c) {
 namespace {
 // ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
 int external_eval(dhmc_ctx* c, const double* q) {
+    if (c->builtin_big && c->cfg.target == DHMC_TARGET_LOGISTIC) {
+        // the GEMM gradient of the logistic round engine over all chains (logistic_rounds.hpp), folded by builtin_logistic_fold_kernel
+        const int C = c->cfg.chains, ld = c->Dpad, npad = (int)c->tp.npad;
+        RunParams P{};
+        P.D = c->cfg.dim; P.Dpad = ld; P.C = C; P.tp = c->tp;
+        RoundBuffers R{};
+        LogisticRound L = c->lr;
+        L.act = c->d_all_rows; L.act_count = c->d_all_rows + C;                                                          // every chain, every time
+        launch_gemm_list(q, ld, c->tp.b, npad, L.H, npad, C, ld, npad, L.act, L.act_count, c->stream);                    // η = Q·Xᵀ
+        hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, c->stream, P, R, L);            // r, the blocks' sums
+        launch_gemm_splitk(L.H, npad, c->tp.a, ld, L.P, ld, (size_t)C * ld, C, npad, ld, DHMC_LOGISTIC_BLOCK, L.act, L.act_count,
+                           c->stream);                                                                                   // Xᵀr, block by block
+        const dim3 g(C), b(WAVE);
+        if (c->NPL == 32) hipLaunchKernelGGL((builtin_logistic_fold_kernel<32>), g, b, 0, c->stream, C, ld, q, L, c->lr.S1, c->rb.tbuf);
+        else hipLaunchKernelGGL((builtin_logistic_fold_kernel<64>), g, b, 0, c->stream, C, ld, q, L, c->lr.S1, c->rb.tbuf);
+        return DHMC_OK;
+    }
+    if (c->builtin_big && c->cfg.target == DHMC_TARGET_DENSE_NORMAL) {
+        const dim3 g(c->cfg.chains), b(WAVE);
+        const int ld = c->Dpad;
+        if (c->NPL == 32) hipLaunchKernelGGL((builtin_dense_normal_pre_kernel<32>), g, b, 0, c->stream, ld, q, c->tp.a, c->d_big[0]);
+        else hipLaunchKernelGGL((builtin_dense_normal_pre_kernel<64>), g, b, 0, c->stream, ld, q, c->tp.a, c->d_big[0]);
+        launch_gemm_rows(c->d_big[0], c->tp.b, c->d_big[1], ld, c->cfg.chains, nullptr, nullptr, c->stream);      // P·d for every chain
+        if (c->NPL == 32) hipLaunchKernelGGL((builtin_dense_normal_post_kernel<32>), g, b, 0, c->stream, ld, (const double*)c->d_big[0], (const double*)c->d_big[1], c->lr.S1, c->rb.tbuf);
+        else hipLaunchKernelGGL((builtin_dense_normal_post_kernel<64>), g, b, 0, c->stream, ld, (const double*)c->d_big[0], (const double*)c->d_big[1], c->lr.S1, c->rb.tbuf);
+        return DHMC_OK;
+    }
     if (c->builtin_big) {
-        const int kind = c->cfg.target == DHMC_TARGET_STD_NORMAL ? 0 : c->cfg.target == DHMC_TARGET_DIAG_NORMAL ? 1 : 2;
+        const int kind = c->cfg.target == DHMC_TARGET_STD_NORMAL ? 0 : c->cfg.target == DHMC_TARGET_DIAG_NORMAL ? 1 :
+                         c->cfg.target == DHMC_TARGET_TRIDIAG_NORMAL ? 2 : 3;
         const dim3 g(c->cfg.chains), b(WAVE);
         if (c->NPL == 32)
             hipLaunchKernelGGL((builtin_normal_eval_kernel<32>), g, b, 0, c->stream, kind, c->cfg.dim, c->Dpad, q, c->tp.a, c->tp.b, c->lr.S1, c->rb.tbuf);

@@ -44,7 +44,7 @@ __device__ __forceinline__ double external_evaluate(const double* __restrict__ q
 // the host's callback stands for an external model — lq [C], grad [C][ld] — so the same round engine (init, step-size
 // search, per-draw loops) serves them up to 4096 dimensions.  One wave per chain; the arithmetic (element order, the
 // ABI's blocked dot product) is the functors' of targets.hpp / oracle/targets.hpp.
-//   kind 0: standard normal; 1: diagonal normal (a = μ, b = precision); 2: tridiagonal precision (a = diag, b = off)
+//   kind 0: standard normal; 1: diagonal normal (a = μ, b = precision); 2: tridiagonal precision (a = diag, b = off); 3: Neal's funnel
 template <int NPL>
 __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D, int ld, const double* __restrict__ q,
                                                                 const double* __restrict__ a, const double* __restrict__ b,
@@ -52,6 +52,26 @@ __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D
     const int chain = blockIdx.x, lane = threadIdx.x;
     const double* qr = q + (size_t)chain * ld;
     double* gr = grad + (size_t)chain * ld;
+    if (kind == 3) {                                   // Neal's funnel, the arithmetic of FunnelT::eval (targets.hpp) slot by slot
+        const double v = uni_f64(qr[0]);
+        const double ev = det_exp(-v);
+        LaneAcc<1, NPL> fa;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            const double x = e == 0 ? 0.0 : qr[e];
+            fa.add(0, k, x, x);
+            gr[e] = -(ev * qr[e]);
+        }
+        const double S = wave_allreduce1(fa.fold(0));
+        const double hd = 0.5 * (double)(D - 1);
+        const double hes = (0.5 * ev) * S;
+        if (lane == 0) {
+            lq[chain] = ((-(v * v) / 18.0) - hes) - hd * v;
+            gr[0] = ((-v / 9.0) + hes) - hd;
+        }
+        return;
+    }
     LaneAcc<1, NPL> acc;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -73,6 +93,65 @@ __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D
     }
     const double s = wave_allreduce1(acc.fold(0));
     if (lane == 0) lq[chain] = -0.5 * s;
+}
+
+// DHMC_TARGET_DENSE_NORMAL beyond 1024 coordinates: d = q − μ, then P·d for all chains as ONE product d·P (k-ascending fma chains,
+// what DenseNormalT's sym_matvec runs per chain), then ∇ℓ = −Pd and ℓ = −½ d·(Pd) in the ABI's dot order
+template <int NPL>
+__global__ __launch_bounds__(64) void builtin_dense_normal_pre_kernel(int ld, const double* __restrict__ q, const double* __restrict__ mu,
+                                                                     double* __restrict__ d) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * ld;
+#pragma unroll 4
+    for (int k = 0; k < NPL; ++k) d[row + lane + WAVE * k] = q[row + lane + WAVE * k] - mu[lane + WAVE * k];
+}
+template <int NPL>
+__global__ __launch_bounds__(64) void builtin_dense_normal_post_kernel(int ld, const double* __restrict__ d, const double* __restrict__ Pd,
+                                                                      double* __restrict__ lq, double* __restrict__ grad) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * ld;
+    LaneAcc<1, NPL> acc;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        const double t = Pd[row + e];
+        acc.add(0, k, d[row + e], t);
+        grad[row + e] = -t;
+    }
+    const double s = wave_allreduce1(acc.fold(0));
+    if (lane == 0) lq[chain] = -0.5 * s;
+}
+
+// DHMC_TARGET_LOGISTIC beyond 1024 coefficients: the GEMM gradient of logistic_rounds.hpp for ALL chains as the batched evaluation —
+// H = Q·Xᵀ, logistic_link_kernel (r and the blocks' log-likelihood sums), P_z = R·X block by block — and this kernel, the fold of
+// rounds_k2_logistic_kernel: G = ((P₀ + P₁) + P₂) + …, ∇ℓ = G − q, ℓ = (the blocks' sums in ascending order) − ½ q·q
+template <int NPL>
+__global__ __launch_bounds__(64) void builtin_logistic_fold_kernel(int C, int ld, const double* __restrict__ q, LogisticRound L,
+                                                                  double* __restrict__ lq_out, double* __restrict__ grad) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)chain * ld, zs = (size_t)C * ld;
+    LaneAcc<1, NPL> qq;
+#pragma unroll 2
+    for (int k = 0; k < NPL; ++k) {
+        const int e = lane + WAVE * k;
+        double g = L.P[row + e];
+        for (int z = 1; z < L.nz; ++z) g = g + L.P[(size_t)z * zs + row + e];
+        const double x = q[row + e];
+        qq.add(0, k, x, x);
+        grad[row + e] = g - x;
+    }
+    double s1 = 0.0;
+    for (int z = 0; z < L.nz; ++z) {
+        const double b = L.S1P[(size_t)z * C + chain];
+        s1 = z == 0 ? b : s1 + b;
+    }
+    const double lq = s1 - 0.5 * wave_allreduce1(qq.fold(0));
+    if (lane == 0) lq_out[chain] = lq;
+}
+__global__ void builtin_all_rows_kernel(int C, int* __restrict__ act, int* __restrict__ act_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) act[i] = i;
+    if (i == 0) *act_count = C;
 }
 
 // initialize_warmup_state (mcmc.jl:129-132) without the density: positions (given, or random_position mcmc.jl:108 from

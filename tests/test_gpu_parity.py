@@ -249,7 +249,7 @@ def test_empty_and_unrecorded_runs(pkg):
     with pytest.raises(RuntimeError, match="unsupported"):
         pkg.DeviceContext(4097, 1)                                 # D > 4096 is outside this build (DHMC_ERR_UNSUPPORTED)
     with pytest.raises(RuntimeError, match="unsupported"):
-        pkg.DeviceContext(1025, 1, target=ol.TARGET_FUNNEL)        # beyond 1024 only the normal families and external models
+        pkg.DeviceContext(1025, 1, target=ol.TARGET_ALWAYS_DIVERGENT)   # beyond 1024: the sampling families and external models
     with pytest.raises(ValueError):
         dev.run(-1)
 
@@ -338,12 +338,15 @@ def test_dense_context_keeps_its_metric_across_init(pkg):
     assert np.array_equal(e.metric_diag(), np.ones((3, D)))        # the diagonal one is reset
 
 
-@pytest.mark.parametrize("family,D,metric", [("std", 1500, "diag"), ("diag", 2500, "diag"), ("tridiag", 1100, "diag"), ("tridiag", 1100, "dense")])
+@pytest.mark.parametrize("family,D,metric", [("std", 1500, "diag"), ("diag", 2500, "diag"), ("tridiag", 1100, "diag"), ("tridiag", 1100, "dense"),
+                                             ("funnel", 1300, "diag"), ("mvnormal", 1100, "diag"), ("logistic", 1100, "diag")])
 def test_builtin_normal_families_beyond_1024_dimensions(pkg, family, D, metric):
     """The reference has no dimension limit (hamiltonian.jl:56-87).  Beyond the register-resident kernels' 1024 coordinates
-    the built-in normal families run through the streaming round engine (32 / 64 slots per lane, K3 as 8 / 16 waves per
-    chain) with their density evaluated by builtin_normal_eval_kernel: init, step-size search, adaptive stage with a
-    metric update and a fixed stage, bit for bit against the oracle."""
+    the built-in normal families and the funnel run through the streaming round engine (32 / 64 slots per lane, K3 as 8 / 16
+    waves per chain) with their density evaluated for all chains between the kernels (builtin_normal_eval_kernel; the full-
+    precision normal as one product (q − μ)·P over the chains; the logistic regression's gradient as the two GEMMs of its round
+    engine over all chains): init, step-size search, adaptive stage with a metric update and
+    a fixed stage, bit for bit against the oracle."""
     rng = np.random.default_rng(D)
     C = 3
     if family == "std":
@@ -351,6 +354,18 @@ def test_builtin_normal_families_beyond_1024_dimensions(pkg, family, D, metric):
     elif family == "diag":
         tgt = ol.TARGET_DIAG_NORMAL
         params = ol.target_params_blob(tgt, D, mu=rng.normal(size=D), prec=1 / (rng.normal(size=D) ** 2 + 0.1))
+    elif family == "funnel":
+        tgt, params = ol.TARGET_FUNNEL, None
+    elif family == "logistic":                                 # 2 500 observations: two blocks of the ABI's Σ over observations
+        tgt = ol.TARGET_LOGISTIC
+        X = rng.normal(size=(2500, D)) / 30
+        y = (rng.random(2500) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+        params = ol.target_params_blob(tgt, D, X=X, y=y)
+    elif family == "mvnormal":
+        tgt = ol.TARGET_DENSE_NORMAL
+        idx = np.arange(D)
+        P = np.diag(np.linspace(0.5, 2.0, D)) + 0.3 * 0.5 ** np.abs(idx[:, None] - idx[None, :])
+        params = ol.target_params_blob(tgt, D, mu=rng.normal(size=D), P=P)
     else:
         tgt = ol.TARGET_TRIDIAG_NORMAL
         params = ol.target_params_blob(tgt, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))
