@@ -284,8 +284,8 @@ class TorchLogDensity(_Target):
     """The user's own model (the reference accepts any LogDensityProblems object, hamiltonian.jl:146-147,204): a batched
     PyTorch function evaluated on the GPU for all chains at once, once per leapfrog round.  Either
     `logdensity_and_gradient(q) -> (lq [C], grad [C][D])`, or just `logdensity(q) -> lq [C]` (any differentiable torch
-    code; the gradient then comes from autograd).  q is a float64 CUDA tensor [C][D].  Diagonal (D <= 4096) or dense
-    (D <= 1024) metric."""
+    code; the gradient then comes from autograd).  q is a float64 CUDA tensor [C][D].  Diagonal or (shared) dense
+    metric, D <= 4096."""
     family = abi.TARGET_EXTERNAL
 
     def __init__(self, dimension, logdensity=None, logdensity_and_gradient=None):
@@ -313,7 +313,7 @@ class DeviceFunctorLogDensity(_Target):
     of the built-in families (include/dhmc.h dhmc_register_target_source), compiled at run time into the
     library's own per-draw / initialisation / step-size-search kernels — no host round trip per leapfrog, as `north_star`
     asks ("the user ∇log π is supplied as a device function").  `params`: doubles handed to the functor's constructor.
-    Diagonal metric, dimension <= 1024."""
+    Diagonal or shared dense metric, dimension <= 1024."""
 
     def __init__(self, dimension, source, name, params=None):
         self.D = int(dimension)
