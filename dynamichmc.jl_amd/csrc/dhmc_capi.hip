@@ -196,7 +196,7 @@ struct dhmc_ctx {
     hipEvent_t ev_joins[4] = {};
     int dense_rounds = 1;
     int fuse_k2 = 1;           // DHMC_FUSE_K2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
-    int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (round engine only)
+    int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (either dense engine)
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
@@ -535,7 +535,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && many_chains && !c->builtin_big;
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
         c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0 && !c->builtin_big;
-    c->dense_rounds = many_chains;
+    // dense metric: the GEMM round engine from 128 chains or beyond 256 coordinates; below both, the wave-per-chain kernel (a matvec
+    // per chain from L2, no launches per round: 2–9× faster for a handful of small chains) — the same bits either way
+    c->dense_rounds = many_chains || D > 256;
     c->external = cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
@@ -1128,6 +1130,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.N = N; P.st = c->st; P.tp = c->tp; P.leapfrog_counter = c->d_counter;
     P.l1_in_lds = c->l1_in_lds;
     P.k3_block = c->k3_block;
+    P.one_product = c->cfg.metric == DHMC_METRIC_DENSE && c->dense_products == 1;
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;
@@ -1288,9 +1291,8 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
         c->last_rounds = rounds;
-    } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && (c->dense_rounds || c->dense_products == 1)) {
-        // (the one-product recurrence exists in this engine only, so it is the engine of every chain count then: results
-        // must not depend on how many chains a context holds)
+    } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
+        // (both dense engines run either recurrence with the same bits, so which one serves a context is a matter of speed only)
         P.one_product = c->dense_products == 1;
         P.fuse_k2 = c->fuse_k2;
         // Round-based dense engine (dense_rounds.hpp): every round is one leapfrog for every chain.  The chains

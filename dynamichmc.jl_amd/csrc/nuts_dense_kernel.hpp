@@ -95,6 +95,50 @@ __device__ __forceinline__ void leapfrog_leaf_dense(const T& tgt, const DenseMet
     pi_out = uni_f64(joint_logdensity(lq, K));
 }
 
+// The same step with ONE M⁻¹ product (dense_rounds.hpp, oracle/hamiltonian.hpp leapfrog with one_product): u = M⁻¹∇ℓq is carried next
+// to ∇ℓq, M⁻¹pₘ = p♯ + (ϵ/2)·u and p♯′ = M⁻¹pₘ + (ϵ/2)·u′ follow by linearity, u′ = M⁻¹∇ℓq′ is the step's only product.
+template <class T, int NPL>
+__device__ __forceinline__ void leapfrog_leaf_dense1(const T& tgt, const DenseMetric& M, int Dpad, int lane, int D,
+                                                     double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
+                                                     double (&ps)[NPL], double (&u)[NPL], double eps, double& lq_out, double& pi_out,
+                                                     bool& pos_finite) {
+    const double h = eps / 2;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        p[k] = p[k] + h * g[k];                                  // pₘ  (:277)
+        ps[k] = ps[k] + h * u[k];                                // M⁻¹pₘ
+        q[k] = q[k] + eps * ps[k];                               // :278
+    }
+    const double lres = tgt.eval(q, g, lane, D);                 // :279
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) p[k] = p[k] + h * g[k];        // :280
+    sym_matvec<NPL>(M.Minv, Dpad, D, lane, g, u);                // u′ = M⁻¹ ∇ℓq′
+    LaneAcc<1, NPL> kacc;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        ps[k] = ps[k] + h * u[k];                                // p♯′
+        kacc.add(0, k, p[k], ps[k]);
+    }
+    double lq, K;
+    if constexpr (T::kDeferred) {
+        double r[2] = {lres, kacc.fold(0)};
+        wave_allreduce<2>(r);
+        lq = tgt.finish(r[0]);
+        K = r[1] / 2.0;
+    } else {
+        lq = lres;
+        K = wave_allreduce1(kacc.fold(0)) / 2.0;
+    }
+    lq = uni_f64(lq);
+    pos_finite = true;
+    bool gfin = true;
+    if (!T::kFiniteLqImpliesFiniteQ || !dm_isfinite(lq)) pos_finite = all_finite<T, NPL>(q);
+    if constexpr (!T::kFiniteLqImpliesFiniteGrad) gfin = all_finite<T, NPL>(g);
+    lq = demote_lq(lq, pos_finite, gfin);
+    lq_out = lq;
+    pi_out = uni_f64(joint_logdensity(lq, K));
+}
+
 // combine_turn_statistics (NUTS.jl:132-139) with explicit p♯ vectors; x earlier in time, y later.
 template <int NPL, class XM, class XMS, class XP, class XPS, class XR, class YM, class YMS, class YP, class YPS, class YR,
           class NF, class NFS>
@@ -151,6 +195,8 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
     const int nslots = ws_nslots(max_depth);
 
     double q[NPL], p[NPL], g[NPL], ps[NPL], cf[NPL], cfs[NPL], cr[NPL];
+    double u[NPL];                                   // one-product recurrence only: M⁻¹∇ℓq of the travelling point
+    const bool one_product = P.one_product != 0;
     ldv<NPL>(P.st.q + row, lane, q);
     ldv<NPL>(P.st.g + row, lane, g);
     double lq_cur = P.st.lq[chain];
@@ -190,6 +236,10 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);
 
         sample_momentum_dense<NPL>(key, PURPOSE_MOMENTUM, tr, M, Dpad, D, lane, p, ps);
+        if (one_product) {                           // the transition's anchor: a fresh product (make_phasepoint in the oracle)
+            sym_matvec<NPL>(M.Minv, Dpad, D, lane, g, u);
+            stv<NPL>(wsv(wd_u0(max_depth)), lane, u);
+        }
         uint32_t dirs;
         {
             uint32_t w[4];
@@ -246,8 +296,10 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
             if (reg_edge != 2 && reg_edge != dir) {
                 stv<NPL>(wsv(wd_edge(reg_edge, 0)), lane, q);
                 if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(wd_edge(reg_edge, 1)), lane, g);
+                if (one_product) stv<NPL>(wsv(wd_edge_u(max_depth, reg_edge)), lane, u);
                 if (reg_edge == 1) stored1 = true; else stored0 = true;
                 const bool have = fwd ? stored1 : stored0;
+                if (one_product) ldv<NPL>(wsv(have ? wd_edge_u(max_depth, dir) : wd_u0(max_depth)), lane, u);
                 const int qsrc = have ? wd_edge(dir, 0) : wd_slot(max_depth, init_slot, 0);
                 const int gsrc = have ? wd_edge(dir, 1) : wd_slot(max_depth, init_slot, 1);
                 ldv<NPL>(wsv(qsrc), lane, q);
@@ -268,7 +320,8 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
-                leapfrog_leaf_dense<T, NPL>(tgt, M, Dpad, lane, D, q, p, g, ps, eps_s, lq_leaf, pi_leaf, pos_finite);
+                if (one_product) leapfrog_leaf_dense1<T, NPL>(tgt, M, Dpad, lane, D, q, p, g, ps, u, eps_s, lq_leaf, pi_leaf, pos_finite);
+                else leapfrog_leaf_dense<T, NPL>(tgt, M, Dpad, lane, D, q, p, g, ps, eps_s, lq_leaf, pi_leaf, pos_finite);
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
                 total_steps += 1;
