@@ -200,6 +200,8 @@ struct dhmc_ctx {
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
+    int logistic_batched = 0;  // … and with it (or beyond 1024 coefficients) ℓ, ∇ℓ of all chains by the same GEMMs wherever they are needed
+                               // outside a round: initialisation, step-size search, the Diagnostics probes (external_eval)
     LogisticRound lr{};
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
     int builtin_big = 0;       // a built-in normal family / the funnel with more than 1024 coordinates: the same engine, density from builtin_normal_eval_kernel
@@ -532,12 +534,15 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // Round engines pay ≈8 launches per leapfrog round; they win once a round carries enough chains to fill the
     // chip (GEMM rows), otherwise the one-wave-per-chain kernels are faster.  DHMC_*_ROUNDS=0/1 overrides.
     const bool many_chains = cfg->chains >= 128;
-    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && many_chains && !c->builtin_big;
+    // logistic regression, diagonal metric: the GEMM engine whatever the chain count — the wave-per-chain functor re-reads X twice per
+    // gradient and chain (4 chains, N = 10⁵, p = 256: 306 ms per leapfrog against 0.27; N = 10³, p = 16: 140 µs against 105)
+    c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && !c->builtin_big;
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
         c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0 && !c->builtin_big;
     // dense metric: the GEMM round engine from 128 chains or beyond 256 coordinates; below both, the wave-per-chain kernel (a matvec
     // per chain from L2, no launches per round: 2–9× faster for a handful of small chains) — the same bits either way
     c->dense_rounds = many_chains || D > 256;
+    c->logistic_batched = cfg->target == DHMC_TARGET_LOGISTIC && (c->builtin_big || c->logistic_rounds);
     c->external = cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);
     if (const char* e = std::getenv("DHMC_L1_LDS")) c->l1_in_lds = std::atoi(e) != 0;  // tuning knob
@@ -694,7 +699,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (hipMemcpy(dxt, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         if (hipMemcpy(dy, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(DHMC_ERR_HIP);
         c->tp.a = dx; c->tp.b = dxt; c->tp.c = dy; c->tp.n = n; c->tp.npad = (int64_t)npad; c->tp.Dpad = (int32_t)Dp;
-        if (c->builtin_big) {             // more than 1024 coefficients: the gradient of all chains between the kernels (external_eval)
+        if (c->logistic_batched) {        // the gradient of all chains by GEMMs, in the rounds and between other kernels (external_eval)
             if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
             c->lr.nz = (int)((npad + DHMC_LOGISTIC_BLOCK - 1) / DHMC_LOGISTIC_BLOCK);
             if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
@@ -703,14 +708,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             hipLaunchKernelGGL(builtin_all_rows_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, nullptr, (int)C, c->d_all_rows, c->d_all_rows + C);
             if (hipDeviceSynchronize() != hipSuccess) return fail(DHMC_ERR_HIP);
         }
-        if (c->logistic_rounds) {
-            if ((rc = dev_alloc(c, &c->lr.H, C * npad))) return fail(rc);
+        if (c->logistic_rounds) {         // (H, P, S1P: above)
             if ((rc = dev_alloc(c, &c->lr.S1, C))) return fail(rc);
-            c->lr.nz = (int)((npad + DHMC_LOGISTIC_BLOCK - 1) / DHMC_LOGISTIC_BLOCK);
-            if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
-            if ((rc = dev_alloc(c, &c->lr.S1P, (size_t)c->lr.nz * C))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.act, C + 1))) return fail(rc);
             c->lr.act_count = c->lr.act + C;
+            if ((rc = dev_alloc(c, &c->d_ss, C))) return fail(rc);      // the batched step-size search's per-chain state
         }
     }
     if (c->builtin_big && cfg->target == DHMC_TARGET_DENSE_NORMAL)
@@ -794,9 +796,19 @@ int dhmc_destroy(dhmc_ctx* c) {
 
 // ---- DHMC_TARGET_EXTERNAL (external_rounds.hpp) -------------------------------------------------
 namespace {
+#define DHMC_EXT_NPL_FWD(KERNEL, GRID, ...)                                                                    \
+    switch (c->NPL) {                                                                                          \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    default: hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
+    }
 // ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
 int external_eval(dhmc_ctx* c, const double* q) {
-    if (c->builtin_big && c->cfg.target == DHMC_TARGET_LOGISTIC) {
+    if (c->logistic_batched) {
         // the GEMM gradient of the logistic round engine over all chains (logistic_rounds.hpp), folded by builtin_logistic_fold_kernel
         const int C = c->cfg.chains, ld = c->Dpad, npad = (int)c->tp.npad;
         RunParams P{};
@@ -808,9 +820,7 @@ int external_eval(dhmc_ctx* c, const double* q) {
         hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, c->stream, P, R, L);            // r, the blocks' sums
         launch_gemm_splitk(L.H, npad, c->tp.a, ld, L.P, ld, (size_t)C * ld, C, npad, ld, DHMC_LOGISTIC_BLOCK, L.act, L.act_count,
                            c->stream);                                                                                   // Xᵀr, block by block
-        const dim3 g(C), b(WAVE);
-        if (c->NPL == 32) hipLaunchKernelGGL((builtin_logistic_fold_kernel<32>), g, b, 0, c->stream, C, ld, q, L, c->lr.S1, c->rb.tbuf);
-        else hipLaunchKernelGGL((builtin_logistic_fold_kernel<64>), g, b, 0, c->stream, C, ld, q, L, c->lr.S1, c->rb.tbuf);
+        DHMC_EXT_NPL_FWD(builtin_logistic_fold_kernel, dim3(C), C, ld, q, L, c->lr.S1, c->rb.tbuf)
         return DHMC_OK;
     }
     if (c->builtin_big && c->cfg.target == DHMC_TARGET_DENSE_NORMAL) {
@@ -875,13 +885,14 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
     }
     InitParams P{c->cfg.dim, c->Dpad, c->cfg.chains, c->cfg.chain_offset, c->cfg.seed, (const double*)s.dev, c->st, c->tp};
     int rc = DHMC_OK;
-    if (c->external) { DHMC_EXT_NPL(external_init_positions_kernel, dim3(c->cfg.chains), P) }
+    const bool batched = c->external || c->logistic_batched;     // ℓ, ∇ℓ of all chains between kernels (callback / library GEMMs)
+    if (batched) { DHMC_EXT_NPL(external_init_positions_kernel, dim3(c->cfg.chains), P) }
     else rc = dispatch(c, Op::Init, &P);
     if (rc) { stage_free(c, &s); return rc; }
     c->poisoned = true;    // st.q is being overwritten: inconsistent with ℓq, ∇ℓ until the evaluation below has succeeded
     HIP_TRY(c, hipGetLastError());
     stage_free(c, &s);
-    if (c->external) {     // the positions are set; ℓ and ∇ℓ come from the callback, then evaluate_ℓ(strict) (mcmc.jl:131)
+    if (batched) {         // the positions are set; ℓ and ∇ℓ come from the callback, then evaluate_ℓ(strict) (mcmc.jl:131)
         if ((rc = external_eval(c, c->st.q))) return rc;
         DHMC_EXT_NPL(external_init_finish_kernel, dim3(c->cfg.chains), c->cfg.dim, c->Dpad, c->st, c->lr.S1, c->rb.tbuf)
         HIP_TRY(c, hipGetLastError());
@@ -1073,7 +1084,7 @@ int dhmc_find_initial_stepsize(dhmc_ctx* c, const dhmc_stepsize_search* p) {
         HIP_TRY(c, hipGetLastError());
         return status_code(c);
     }
-    if (c->external) {
+    if (c->external || c->logistic_batched) {
         // the same bracketing search, all chains per callback: trial positions -> callback -> one decision per chain
         ExtSearchParams E{c->cfg.dim, c->Dpad, C, c->cfg.chain_offset, c->cfg.seed, d.initial_eps, d.log_threshold, d.maxiter_crossing,
                           c->st, c->d_ss, c->rb.cps, c->rb.cp, c->lr.S1, c->rb.tbuf, c->rb.list_count};
@@ -1272,6 +1283,14 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         if (e == hipSuccess) { rc = dispatch(c, Op::RoundStart, &ra); if (rc) { cleanup(); return rc; } }
         unsigned long long rounds = 0;
         int done = 0;
+        // the done-counter is read through page-locked memory one batch of four rounds behind (as in the dense engine below): the
+        // host never drains the stream inside the loop; the rounds enqueued after the last chain finished find no chain in a leaf
+        // phase and an empty row list
+        if (!c->h_done && e == hipSuccess) {
+            e = hipHostMalloc((void**)&c->h_done, 2 * 8 * sizeof(int), hipHostMallocDefault);
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming);
+        }
+        long long batch = 0;
         while (e == hipSuccess && done < C) {
             for (int rep = 0; rep < 4 && e == hipSuccess; ++rep, ++rounds) {
                 launch_logistic_op(0, c->NPL, ra, c->lr, c->stream);                                   // p = W∘z, p♯
@@ -1287,8 +1306,14 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }
             }
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&done, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            int* slot = c->h_done + 8 * (batch & 1);
+            if (e == hipSuccess) e = hipMemcpyAsync(slot, c->rb.done_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_done[batch & 1], c->stream);
+            if (batch >= 1 && e == hipSuccess) {
+                e = hipEventSynchronize(c->ev_done[(batch - 1) & 1]);
+                done = c->h_done[8 * ((batch - 1) & 1)];
+            }
+            batch += 1;
         }
         c->last_rounds = rounds;
     } else if (e == hipSuccess && c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds) {
@@ -1774,7 +1799,7 @@ int dhmc_leapfrog_trajectory(dhmc_ctx* c, double eps, int32_t first, int32_t las
         HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * D));
         HIP_TRY(c, hipMemcpyAsync(dp.p, p, sizeof(double) * C * D, hipMemcpyHostToDevice, c->stream));
     }
-    if (c->external) {           // the density is the host's callback: one batched evaluation per step (external_rounds.hpp)
+    if (c->external || c->logistic_batched) {   // the density is evaluated for all chains between kernels: one batched evaluation per step
         ExtProbe X;
         int rc;
         if ((rc = X.init(c, (uint32_t*)dst.p))) return rc;
@@ -1834,7 +1859,7 @@ int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n
         HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * n_momenta * D));
         HIP_TRY(c, hipMemcpyAsync(dp.p, ps, sizeof(double) * C * n_momenta * D, hipMemcpyHostToDevice, c->stream));
     }
-    if (c->external) {
+    if (c->external || c->logistic_batched) {
         ExtProbe X;
         int rc;
         if ((rc = X.init(c, (uint32_t*)dst.p))) return rc;

@@ -36,6 +36,10 @@ CASES = [
     ("funnel30", 30, ol.TARGET_FUNNEL, None),
     ("tridiag200", 200, ol.TARGET_TRIDIAG_NORMAL, lambda D: ol.target_params_blob(
         ol.TARGET_TRIDIAG_NORMAL, D, diag=np.full(D, 2.5), off=np.full(D - 1, -1.0))),
+    # logistic regression: ℓ, ∇ℓ of all chains by the GEMMs of its round engine between the probe's kernels (2 500 observations: two blocks)
+    ("logistic40", 40, ol.TARGET_LOGISTIC, lambda D: ol.target_params_blob(
+        ol.TARGET_LOGISTIC, D, X=np.random.default_rng(2).normal(size=(2500, D)) / 6,
+        y=(np.random.default_rng(3).random(2500) < 0.4).astype(float))),
 ]
 
 
