@@ -204,7 +204,8 @@ struct dhmc_ctx {
                                // outside a round: initialisation, step-size search, the Diagnostics probes (external_eval)
     LogisticRound lr{};
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
-    int builtin_big = 0;       // a built-in normal family / the funnel with more than 1024 coordinates: the same engine, density from builtin_normal_eval_kernel
+    int builtin_big = 0;       // a built-in family whose density the LIBRARY evaluates for all chains between kernels, where an external model's
+                               // callback stands (more than 1024 coordinates; the logistic regression with a dense metric): the same engine
     int* d_all_rows = nullptr; // DHMC_TARGET_LOGISTIC beyond 1024 coefficients: the row list 0..C-1 and its length, for the GEMMs of the batched gradient
     double* d_big[2] = {};     // DHMC_TARGET_DENSE_NORMAL beyond 1024 coordinates: q − μ and P(q − μ) of all chains ([C][Dpad] each)
     dhmc_logdensity_fn ext_fn = nullptr;
@@ -523,6 +524,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->builtin_big = D > 1024 && (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL ||
                                   cfg->target == DHMC_TARGET_TRIDIAG_NORMAL || cfg->target == DHMC_TARGET_FUNNEL ||
                                   cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_LOGISTIC);
+    // … and the logistic regression with a shared dense metric at ANY width: its functor re-reads X twice per gradient and chain
+    // (hundreds of ms per leapfrog at N = 10⁵), the batched evaluation is two GEMMs over all chains
+    if (cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DENSE && !cfg->dense_per_chain) c->builtin_big = 1;
     c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big);
     if (cfg->target == DHMC_TARGET_EXTERNAL)
         if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels

@@ -209,6 +209,30 @@ def test_dense_metric_adaptation_at_1000_dimensions(pkg):
     same(dev.run(3, da={}), ora.run(3, da={}), "after the metric update")
 
 
+def test_logistic_regression_with_a_dense_metric_matches_oracle(pkg):
+    """Symmetric warmup of a logistic regression: the dense round engine with ℓ, ∇ℓ of all chains evaluated by the family's two
+    GEMMs between the kernels (the functor would re-read X twice per gradient and chain) — search, adaptive stage, dense metric
+    update, fixed stage and a probe, bit for bit against the oracle; 2 500 observations = two blocks of the ABI's Σ over them."""
+    D, C, N = 24, 5, 2500
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(N, D)) / 5
+    y = (rng.random(N) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+    params = ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y)
+    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_LOGISTIC, target_params=params, seed=6)
+    ora = ol.Oracle(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_LOGISTIC, params=params, seed=6, threads=5)
+    for e in (dev, ora):
+        e.init(); e.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora.stepsize())
+    a, b = dev.run(40, da={}), ora.run(40, da={})
+    same(a, b, "adaptive stage")
+    dev.update_metric_dense(a["draws"], 5.0 / 40); ora.update_metric_dense(b["draws"], 5.0 / 40)
+    assert np.array_equal(dev.metric_dense()[0], ora.metric_dense()[0])
+    same(dev.run(10), ora.run(10), "fixed stage")
+    ta, tb = dev.leapfrog_trajectory(0.05, -2, 3, momentum_index=1), ora.leapfrog_trajectory(0.05, -2, 3, momentum_index=1)
+    for k in ("delta", "logdensity", "q", "p"):
+        assert np.array_equal(ta[k], tb[k]), k
+
+
 def test_per_chain_dense_metric_is_the_references_semantics(pkg):
     """dense_per_chain = 1: every chain has its own M⁻¹ and adapts it from its OWN draws (mcmc.jl:281-285, what C independent
     reference runs do), instead of one shared matrix from the pooled draws.  Per-chain M⁻¹ / W and the chains' continuation
