@@ -206,7 +206,7 @@ struct dhmc_ctx {
     int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
     int builtin_big = 0;       // a built-in family whose density the LIBRARY evaluates for all chains between kernels, where an external model's
                                // callback stands (more than 1024 coordinates; the logistic regression with a dense metric): the same engine
-    int* d_all_rows = nullptr; // DHMC_TARGET_LOGISTIC beyond 1024 coefficients: the row list 0..C-1 and its length, for the GEMMs of the batched gradient
+    int* d_all_rows = nullptr; // logistic_batched: the row list 0..C-1 and its length, for the GEMMs of the batched gradient
     double* d_big[2] = {};     // DHMC_TARGET_DENSE_NORMAL beyond 1024 coordinates: q − μ and P(q − μ) of all chains ([C][Dpad] each)
     dhmc_logdensity_fn ext_fn = nullptr;
     void* ext_user = nullptr;
