@@ -26,7 +26,7 @@ __all__ = [
     "mcmc_with_warmup", "mcmc_keep_warmup", "mcmc_steps", "mcmc_next_step",
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
     "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent", "TorchLogDensity", "DeviceFunctorLogDensity",
-    "NoProgressReport", "LogProgressReport", "default_reporter", "DynamicHMCError",
+    "NoProgressReport", "LogProgressReport", "ProgressMeterReport", "report", "make_mcmc_reporter", "default_reporter", "DynamicHMCError",
     "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
 ]
 
@@ -355,23 +355,126 @@ class PhiloxRNG:
     chain_offset: int = 0
 
 
-class NoProgressReport:
-    """reporting.jl:14."""
+REPORT_SIGDIGITS = 3       # reporting.jl:8
 
-    def report(self, *a, **k):
+
+def _sig(x, digits=REPORT_SIGDIGITS):
+    x = float(x)
+    return x if x == 0 or not np.isfinite(x) else float(f"{x:.{digits}g}")
+
+
+class NoProgressReport:
+    """reporting.jl:14-46: nothing is reported; its MCMC reporter is itself."""
+
+    def report(self, message_or_step=None, **meta):
         pass
+
+    def make_mcmc_reporter(self, total_steps, currently_warmup=False, **meta):
+        return self
+
+    step_chunk = 0            # transitions between step reports (0: the stage runs as one call)
 
 
 class LogProgressReport:
-    """reporting.jl:62-69, called once per stage / per batched sweep (not per draw)."""
+    """reporting.jl:62-76: progress as log lines (`@info` there, `printer` here).  `report(message; meta...)` prints the message;
+    `make_mcmc_reporter(total_steps)` returns a LogMCMCReport whose `report(step)` prints "MCMC progress" when `step_interval`
+    steps or `time_interval_s` seconds have passed since the last report (a *step* is a NUTS transition of ALL chains here)."""
 
     def __init__(self, chain_id=None, step_interval=100, time_interval_s=1000.0, printer=print):
-        self.chain_id, self.step_interval, self.time_interval_s, self.printer = chain_id, step_interval, time_interval_s, printer
-        self._t0 = time.time()
+        self.chain_id, self.step_interval, self.time_interval_s, self.printer = chain_id, int(step_interval), float(time_interval_s), printer
 
-    def report(self, message, **meta):
+    def _emit(self, message, meta):
+        if self.chain_id is not None:                                         # _log_meta (reporting.jl:83-85)
+            meta = dict(chain_id=self.chain_id, **meta)
         extra = ", ".join(f"{k} = {v}" for k, v in meta.items())
         self.printer(f"[ Info: {message}" + (f"  {extra}" if extra else ""))
+
+    def report(self, message, **meta):                                        # reporting.jl:87-90
+        self._emit(str(message), meta)
+
+    def make_mcmc_reporter(self, total_steps, currently_warmup=False, **meta):   # reporting.jl:115-118
+        self._emit("Starting MCMC", dict(total_steps=int(total_steps), **meta))
+        return LogMCMCReport(self, int(total_steps))
+
+    step_chunk = 0
+
+
+class LogMCMCReport:
+    """reporting.jl:100-137: the state of the last emitted progress line for a stage with a known number of steps."""
+
+    def __init__(self, log_progress_report, total_steps):
+        self.log_progress_report, self.total_steps = log_progress_report, total_steps
+        self.last_reported_step, self.last_reported_time = -1, time.perf_counter()
+
+    @property
+    def step_chunk(self):
+        return max(1, self.log_progress_report.step_interval)
+
+    def report(self, message_or_step, **meta):
+        r = self.log_progress_report
+        if isinstance(message_or_step, str):                                  # reporting.jl:110-113
+            r._emit(message_or_step, meta)
+            return
+        step = int(message_or_step)
+        _argcheck(1 <= step <= self.total_steps, "1 ≤ step ≤ total_steps")    # reporting.jl:123
+        d_steps = step - self.last_reported_step
+        now = time.perf_counter()
+        d_time = now - self.last_reported_time
+        if self.last_reported_step < 0 or d_steps >= r.step_interval or d_time >= r.time_interval_s:
+            sps = d_time / d_steps
+            progress = dict(step=step, seconds_per_step=_sig(sps, 2), estimated_seconds_left=_sig((self.total_steps - step) * sps, 2))
+            r._emit("MCMC progress", dict(progress, **meta))
+            self.last_reported_step, self.last_reported_time = step, now
+
+
+class ProgressMeterReport:
+    """reporting.jl:140-175: a progress bar per stage (ProgressMeter.jl there; tqdm here when it is installed, else a plain
+    counter line per update); messages are not shown."""
+
+    def __init__(self, updates=100, stream=None):
+        self.updates, self.stream = max(1, int(updates)), stream
+
+    def report(self, message_or_step=None, **meta):
+        pass
+
+    def make_mcmc_reporter(self, total_steps, currently_warmup=False, **meta):
+        return ProgressMeterReportMCMC(bool(currently_warmup), int(total_steps), self.updates, self.stream)
+
+    step_chunk = 0
+
+
+class ProgressMeterReportMCMC:
+    def __init__(self, currently_warmup, total_steps, updates, stream):
+        self.currently_warmup, self.total_steps, self.last = currently_warmup, total_steps, 0
+        self.step_chunk = max(1, total_steps // updates)
+        desc = "Warmup: " if currently_warmup else "MCMC: "
+        try:
+            from tqdm import tqdm
+            self.bar = tqdm(total=total_steps, desc=desc, file=stream, leave=True)
+        except ImportError:                                                   # pragma: no cover
+            self.bar, self.desc, self.stream = None, desc, stream
+
+    def report(self, message_or_step=None, **meta):
+        if isinstance(message_or_step, str) or message_or_step is None:
+            return
+        step = int(message_or_step)
+        if self.bar is not None:
+            self.bar.update(step - self.last)                                 # ProgressMeter.next! once per step there
+            if step >= self.total_steps:
+                self.bar.close()
+        else:                                                                 # pragma: no cover
+            print(f"{self.desc}{step}/{self.total_steps}", file=self.stream)
+        self.last = step
+
+
+def report(reporter, message_or_step, **meta):
+    """reporting.jl:32: `report(reporter, message::AbstractString; meta...)` / `report(reporter, step::Integer; meta...)`."""
+    return reporter.report(message_or_step, **meta)
+
+
+def make_mcmc_reporter(reporter, total_steps, currently_warmup=False, **meta):
+    """reporting.jl:49: a reporter for a stage with a known number of steps."""
+    return reporter.make_mcmc_reporter(total_steps, currently_warmup=currently_warmup, **meta)
 
 
 def default_reporter():
@@ -424,15 +527,40 @@ def _host(arrs):
     return out
 
 
-def _run(slogd, N, da=None, keep=True):
-    """One dhmc_run of all chains.  The outputs are written to HBM and only come to the host when the caller keeps
-    them as numpy arrays (`keep` and not `on_device`); returns (arrays, draws usable for the metric update)."""
+def _run(slogd, N, da=None, keep=True, mcmc_reporter=None):
+    """The N transitions of a stage for all chains.  The outputs are written to HBM and only come to the host when the caller
+    keeps them as numpy arrays (`keep` and not `on_device`); returns (arrays, draws usable for the metric update).
+    One dhmc_run — unless the stage's reporter wants step reports (reporting.jl:120-137: `report(mcmc_reporter, i; ϵ)` per draw,
+    mcmc.jl:279,378): then the stage runs as calls of `mcmc_reporter.step_chunk` transitions (the chains resume where they stand:
+    the same transitions, the same bits; dual averaging initialised by the first call and finalised by the last) with a report
+    after each."""
     ctx = slogd.ctx
     bufs = _device_buffers(ctx, N)
+    chunk = int(getattr(mcmc_reporter, "step_chunk", 0) or 0)
+    if chunk <= 0 or chunk >= N:
+        if bufs is None:
+            arrs = ctx.run(N, da=da)
+        else:
+            ctx.run_into(N, bufs, da=da)
+        if mcmc_reporter is not None and N > 0 and chunk > 0:
+            mcmc_reporter.report(N, **({"ϵ": _sig(np.median(ctx.stepsize()))} if da is not None else {}))
+    else:
+        if bufs is None:
+            arrs = {name: np.zeros((ctx.C, N, ctx.D) if name == "draws" else (ctx.C, N), dt) for name, dt in abi.OUTPUT_FIELDS}
+        big = arrs if bufs is None else bufs
+        for n0 in range(0, N, chunk):
+            L = min(chunk, N - n0)
+            dk = None if da is None else dict(da, init=int(n0 == 0), finalize=int(n0 + L >= N))
+            if bufs is None:
+                part = ctx.run(L, da=dk)
+            else:
+                part = _device_buffers(ctx, L)
+                ctx.run_into(L, part, da=dk)
+            for k, v in part.items():
+                big[k][:, n0:n0 + L] = v
+            mcmc_reporter.report(n0 + L, **({"ϵ": _sig(np.median(ctx.stepsize()))} if da is not None else {}))
     if bufs is None:
-        arrs = ctx.run(N, da=da)
         return arrs, arrs["draws"]
-    ctx.run_into(N, bufs, da=da)
     if not keep:
         return None, bufs["draws"]
     return (bufs if slogd.on_device else _host(bufs)), bufs["draws"]
@@ -489,7 +617,7 @@ def warmup(slogd, stage, warmup_state):
         _argcheck(warmup_state.eps is None, "stepsize ϵ manually specified, won't perform initial search")
         ctx.find_initial_stepsize(stage.initial_eps, stage.log_threshold, stage.maxiter_crossing)
         st = _state(ctx)
-        slogd.reporter.report("found initial stepsize", eps=float(np.median(st.eps)))
+        slogd.reporter.report("found initial stepsize", **{"ϵ": _sig(np.median(st.eps))})              # mcmc.jl:141-142
         return None, st
     if isinstance(stage, TuningNUTS):                         # mcmc.jl:258-286
         if stage.M == Symmetric and ctx.cfg.metric != abi.METRIC_DENSE:
@@ -499,14 +627,16 @@ def warmup(slogd, stage, warmup_state):
         _argcheck(warmup_state.eps is not None, "ϵ > 0")       # stepsize.jl:135
         ad = stage.stepsize_adaptation
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
-        arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup)
+        mcmc_reporter = make_mcmc_reporter(slogd.reporter, stage.N, currently_warmup=True,         # mcmc.jl:268-270
+                                           tuning="stepsize" if stage.M is None else "stepsize and " + str(stage.M) + " metric")
+        arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup, mcmc_reporter=mcmc_reporter)
         if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210): pooled over the
             ctx.update_metric_dense(dev_draws, stage.lam)      # context's chains (shared M⁻¹), or chain by chain (per_chain_metric)
         elif stage.M == Diagonal:
             ctx.update_metric_diag(dev_draws, stage.lam)       # mcmc.jl:281-284, from the draws where they are (HBM)
-            slogd.reporter.report("adaptation finished")
         st = _state(ctx)
-        slogd.reporter.report("warmup stage finished", N=stage.N, eps=float(np.median(st.eps)))
+        if stage.M is not None:
+            mcmc_reporter.report("adaptation finished", adapted_kinetic_energy=repr(st.kappa))        # mcmc.jl:283
         if arrs is None:
             return None, st
         draws, ts, lds, epss = _collect(arrs)
@@ -525,9 +655,9 @@ def _warmup(slogd, stages, initial_warmup_state):             # mcmc.jl:450-457
 def mcmc(slogd, N, warmup_state):
     """mcmc.jl:366-381."""
     _argcheck(warmup_state.eps is not None, "ϵ > 0")
-    arrs, _ = _run(slogd, N)
+    mcmc_reporter = make_mcmc_reporter(slogd.reporter, N, currently_warmup=False)                  # mcmc.jl:372
+    arrs, _ = _run(slogd, N, mcmc_reporter=mcmc_reporter)
     draws, ts, lds, _ = _collect(arrs)
-    slogd.reporter.report("inference finished", N=N)
     return dict(posterior_matrix=draws, tree_statistics=ts, logdensities=lds)
 
 

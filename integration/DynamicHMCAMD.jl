@@ -12,9 +12,11 @@
 module DynamicHMCAMD
 import DynamicHMC
 using DynamicHMC: NUTS, DualAveraging, FixedStepsize, InitialStepsizeSearch, TuningNUTS, DynamicHMCError,
-                  TreeStatisticsNUTS, InvalidTree, Directions, default_warmup_stages, default_reporter, report,
+                  TreeStatisticsNUTS, InvalidTree, Directions, default_warmup_stages, default_reporter, report, make_mcmc_reporter,
+                  NoProgressReport, LogProgressReport,
                   REPORT_SIGDIGITS
 using LinearAlgebra: Diagonal, Symmetric
+using Statistics: median
 using AMDGPU: ROCArray                      # device-resident results (run!(...; on_device = true)) and external models
 const libdhmc = "libdhmc_amd.so"            # dynamichmc.jl_amd/lib/
 
@@ -96,7 +98,7 @@ find_initial_stepsize!(ctx, s::InitialStepsizeSearch) = check(ctx,
 # the per-draw loops (mcmc.jl:271-280 with `da`, :374-379 without)
 # on_device: the draws stay in HBM (a ROCArray, for dhmc_update_metric_* / dhmc_ess_* on device pointers); the per-draw
 # scalars always come to the host
-function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing, on_device::Bool = false)
+function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing, on_device::Bool = false, da_init::Bool = true, da_finalize::Bool = true)
     D, C = ctx.dim, ctx.chains
     mk(T, dims...) = on_device ? ROCArray{T}(undef, dims...) : pinned_array(T, dims...)
     pm = mk(Float64, D, N, C)                          # posterior_matrix[:, i] per chain (mcmc.jl:275)
@@ -105,7 +107,7 @@ function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing, on_device::Boo
     depth = mk(Int32, N, C); dirs = mk(UInt32, N, C)
     out = Outputs(on_device, 0, pointer(pm), pointer(ℓs), pointer(ϵs), pointer(π), pointer(a), pointer(steps),
                   pointer(tl), pointer(tr), pointer(depth), pointer(dirs))
-    daref = da === nothing ? C_NULL : Ref(DualAveragingABI(da.δ, da.γ, da.κ, da.t₀, 1, 1, 0))
+    daref = da === nothing ? C_NULL : Ref(DualAveragingABI(da.δ, da.γ, da.κ, da.t₀, da_init, da_finalize, 0))   # a stage run as several calls: init first, finalize last
     rc = GC.@preserve pm ℓs ϵs π a steps tl tr depth dirs ccall((:dhmc_run, libdhmc), Cint,
             (Ptr{Cvoid}, Int64, Ptr{DualAveragingABI}, Ref{Outputs}), ctx.h, N, daref, out)
     check(ctx, rc, "dhmc_run")
@@ -229,6 +231,24 @@ struct SamplingLogDensityAMD{L,O,S}
     rng::UInt64; ℓ::L; algorithm::O; reporter::S; ctx::Context
 end
 
+# The N transitions of a stage with the reference's step reports (mcmc.jl:279,378 -> reporting.jl:120-137).  With NoProgressReport: one
+# dhmc_run.  Any other reporter: the stage runs as calls of `step_interval` transitions (ProgressMeterReport: N ÷ 100) — the chains resume
+# where they stand, so these are the same transitions with the same bits — and report(mcmc_reporter, step; ϵ) follows each call.
+function run_reported!(sl, N; da = nothing, currently_warmup, meta...)
+    mcmc_reporter = make_mcmc_reporter(sl.reporter, N; currently_warmup, meta...)
+    chunk = sl.reporter isa NoProgressReport ? N : sl.reporter isa LogProgressReport ? sl.reporter.step_interval : max(1, N ÷ 100)
+    (chunk ≥ N || N == 0) && return run!(sl.ctx, N; da), mcmc_reporter
+    parts = map(0:chunk:N-1) do n0
+        L = min(chunk, N - n0)
+        r = run!(sl.ctx, L; da, da_init = n0 == 0, da_finalize = n0 + L ≥ N)
+        ϵ = round(median(stepsize(sl.ctx)); sigdigits = REPORT_SIGDIGITS)
+        da === nothing ? report(mcmc_reporter, n0 + L) : report(mcmc_reporter, n0 + L; ϵ)
+        r
+    end
+    ((posterior_matrix = cat((p.posterior_matrix for p in parts)...; dims = 2), tree_statistics = vcat((p.tree_statistics for p in parts)...),
+      ϵs = vcat((p.ϵs for p in parts)...), logdensities = vcat((p.logdensities for p in parts)...)), mcmc_reporter)
+end
+
 # warmup(sampling_logdensity, stage, warmup_state) -> (results, warmup_state′): the reference's seam (iv), src/mcmc.jl:99,134,258
 DynamicHMC.warmup(sl::SamplingLogDensityAMD, ::Nothing, warmup_state) = (nothing, warmup_state)
 function DynamicHMC.warmup(sl::SamplingLogDensityAMD, s::InitialStepsizeSearch, warmup_state)
@@ -241,19 +261,20 @@ end
 function DynamicHMC.warmup(sl::SamplingLogDensityAMD, tuning::TuningNUTS{M}, warmup_state) where {M}
     (; N, stepsize_adaptation, λ) = tuning
     ctx = sl.ctx
-    results = run!(ctx, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing)   # mcmc.jl:271-280 for all chains
+    results, mcmc_reporter = run_reported!(sl, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing,
+                                           currently_warmup = true, tuning = M ≡ Nothing ? "stepsize" : "stepsize and $(M) metric")   # mcmc.jl:268-280
     if M ≡ Diagonal
         update_metric!(ctx, results.posterior_matrix, λ)                                              # mcmc.jl:209,281-284
     elseif M ≡ Symmetric
         update_metric_dense!(ctx, results.posterior_matrix, λ)                                        # mcmc.jl:210,218-222 (pooled)
     end
-    M ≢ Nothing && report(sl.reporter, "adaptation finished", adapted_kinetic_energy = kinetic_energy(ctx))
+    M ≢ Nothing && report(mcmc_reporter, "adaptation finished", adapted_kinetic_energy = kinetic_energy(ctx))
     results, current_warmup_state(ctx)
 end
 
 # mcmc(sampling_logdensity, N, warmup_state) (mcmc.jl:366-381)
 DynamicHMC.mcmc(sl::SamplingLogDensityAMD, N, warmup_state) =
-    let r = run!(sl.ctx, N); (posterior_matrix = r.posterior_matrix, tree_statistics = r.tree_statistics, logdensities = r.logdensities) end
+    let (r, _) = run_reported!(sl, N; currently_warmup = false); (posterior_matrix = r.posterior_matrix, tree_statistics = r.tree_statistics, logdensities = r.logdensities) end
 
 # stepwise (mcmc.jl:335-351): κ and ϵ of `warmup_state` are the context's unless the caller changed them
 struct MCMCStepsAMD; sl::SamplingLogDensityAMD; end

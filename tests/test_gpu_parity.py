@@ -441,3 +441,27 @@ def test_host_outputs_in_chunks_equal_device_outputs(pkg, monkeypatch):
             for a, b in zip(ref, got):
                 for k in a:
                     assert np.array_equal(a[k], b[k]), (engine, kind, chunk, k)
+
+
+def test_step_reports_do_not_change_the_run(pkg):
+    """test/test_logging.jl runs mcmc_with_warmup with every reporter.  A reporter that wants step reports (reporting.jl:120-137,
+    mcmc.jl:279,378) makes a stage run as calls of `step_interval` transitions with a report after each: the same transitions, the
+    same bits as one call per stage — diagonal and Symmetric warmup — and the lines the reference's log would show."""
+    import io
+    l = pkg.DiagNormal(np.linspace(-1, 1, 7), np.linspace(0.5, 2, 7))
+    for M in (pkg.Diagonal, pkg.Symmetric):
+        stages = lambda: pkg.default_warmup_stages(M=M, middle_steps=20, doubling_stages=3)
+        ref = pkg.mcmc_with_warmup(4, l, 230, chains=5, warmup_stages=stages(), reporter=pkg.NoProgressReport())
+        lines = []
+        got = pkg.mcmc_with_warmup(4, l, 230, chains=5, warmup_stages=stages(), reporter=pkg.LogProgressReport(step_interval=60, printer=lines.append))
+        bar = pkg.mcmc_with_warmup(4, l, 230, chains=5, warmup_stages=stages(), reporter=pkg.ProgressMeterReport(updates=7, stream=io.StringIO()))
+        for r in (got, bar):
+            assert np.array_equal(ref["posterior_matrix"], r["posterior_matrix"]) and np.array_equal(ref["eps"], r["eps"])
+            assert np.array_equal(ref["tree_statistics"].steps, r["tree_statistics"].steps)
+            assert np.array_equal(ref["kappa"].Minv, r["kappa"].Minv)
+        assert any("found initial stepsize" in x for x in lines) and any("adaptation finished" in x for x in lines)
+        starts = [x for x in lines if "Starting MCMC" in x]
+        assert len(starts) == len(stages()) - 1 + 1 and "total_steps = 230" in starts[-1]           # every TuningNUTS stage + inference
+        inf = [x for x in lines[lines.index(starts[-1]):] if "MCMC progress" in x]
+        assert [int(x.split("step = ")[1].split(",")[0]) for x in inf] == [60, 120, 180]        # (230 − 180 < step_interval)
+        assert any("MCMC progress" in x and "ϵ = " in x for x in lines)                                # warmup steps carry ϵ

@@ -150,3 +150,28 @@ def test_integration_md_reproduces_the_julia_shim_verbatim():
     shim = open(os.path.join(root, "integration", "DynamicHMCAMD.jl"), encoding="utf-8").read().rstrip("\n")
     first = md.index("```julia\n") + len("```julia\n")
     assert md[first:md.index("\n```", first)] == shim
+
+
+def test_reporter_protocol():
+    """test/test_logging.jl: every reporter takes messages and steps, directly and through make_mcmc_reporter, without error;
+    and the thresholds of LogMCMCReport (reporting.jl:120-137): a line for the first step, then every `step_interval` steps."""
+    import io
+    pkg = load_package()
+    lines = []
+    for reporter in (pkg.NoProgressReport(), pkg.ProgressMeterReport(stream=io.StringIO()), pkg.LogProgressReport(printer=lines.append)):
+        pkg.report(reporter, "")
+        for warm in (True, False):
+            m = pkg.make_mcmc_reporter(reporter, 1000, currently_warmup=warm)
+            pkg.report(m, "")
+            pkg.report(m, 1)
+    lines.clear()
+    r = pkg.LogProgressReport(chain_id=7, step_interval=100, printer=lines.append)
+    m = pkg.make_mcmc_reporter(r, 1000, currently_warmup=True, tuning="stepsize")
+    for step in range(1, 1001):
+        pkg.report(m, step, **{"ϵ": 0.5})
+    progress = [l for l in lines if "MCMC progress" in l]
+    assert "Starting MCMC" in lines[0] and "total_steps = 1000" in lines[0] and "tuning = stepsize" in lines[0]
+    assert len(progress) == 10 and "step = 1," in progress[0] and "step = 101," in progress[1] and "step = 901," in progress[-1]
+    assert all("chain_id = 7" in l and "ϵ = 0.5" in l and "estimated_seconds_left" in l for l in progress)
+    with pytest.raises(ValueError):
+        pkg.report(m, 1001)                                    # @argcheck 1 ≤ step ≤ total_steps (reporting.jl:123)
