@@ -27,7 +27,7 @@ __all__ = [
     "stack_posterior_matrices", "pool_posterior_matrices", "TreeStatisticsNUTS",
     "StandardNormal", "DiagNormal", "TridiagNormal", "MvNormal", "Funnel", "LogisticRegression", "AlwaysDivergent", "TorchLogDensity", "DeviceFunctorLogDensity",
     "NoProgressReport", "LogProgressReport", "ProgressMeterReport", "report", "make_mcmc_reporter", "default_reporter", "DynamicHMCError",
-    "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity",
+    "Diagonal", "Symmetric", "PhiloxRNG", "WarmupState", "EvaluatedLogDensity", "PhasePoint",
 ]
 
 Diagonal = "Diagonal"
@@ -165,6 +165,13 @@ class EvaluatedLogDensity:
     q: np.ndarray
     lq: np.ndarray
     grad: np.ndarray
+
+
+@dataclass
+class PhasePoint:
+    """hamiltonian.jl:225-234: a point in phase space, z = (Q, p) — for C chains p is [C][D]."""
+    Q: EvaluatedLogDensity
+    p: np.ndarray
 
 
 @dataclass
