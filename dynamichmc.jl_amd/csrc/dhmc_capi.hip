@@ -709,6 +709,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             if ((rc = dev_alloc(c, &c->lr.P, (size_t)c->lr.nz * C * Dp))) return fail(rc);
             if ((rc = dev_alloc(c, &c->lr.S1P, (size_t)c->lr.nz * C))) return fail(rc);
             if ((rc = dev_alloc(c, &c->d_all_rows, C + 1))) return fail(rc);
+            if (c->builtin_big && !c->lr.act) {                          // row list of a round (the rounds engine below has its own)
+                if ((rc = dev_alloc(c, &c->lr.act, C + 4))) return fail(rc);
+                c->lr.act_count = c->lr.act + C;
+            }
             hipLaunchKernelGGL(builtin_all_rows_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, nullptr, (int)C, c->d_all_rows, c->d_all_rows + C);
             if (hipDeviceSynchronize() != hipSuccess) return fail(DHMC_ERR_HIP);
         }
@@ -811,7 +815,9 @@ namespace {
     default: hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
     }
 // ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
-int external_eval(dhmc_ctx* c, const double* q) {
+// `active` (the logistic family's GEMM evaluation only): the rows of the chains in a leaf phase, listed in c->lr.act by the caller —
+// the round loops pass it, so that chains which have finished their transitions are not multiplied
+int external_eval(dhmc_ctx* c, const double* q, bool active = false) {
     if (c->logistic_batched) {
         // the GEMM gradient of the logistic round engine over all chains (logistic_rounds.hpp), folded by builtin_logistic_fold_kernel
         const int C = c->cfg.chains, ld = c->Dpad, npad = (int)c->tp.npad;
@@ -819,12 +825,12 @@ int external_eval(dhmc_ctx* c, const double* q) {
         P.D = c->cfg.dim; P.Dpad = ld; P.C = C; P.tp = c->tp;
         RoundBuffers R{};
         LogisticRound L = c->lr;
-        L.act = c->d_all_rows; L.act_count = c->d_all_rows + C;                                                          // every chain, every time
+        if (!(active && c->lr.act)) { L.act = c->d_all_rows; L.act_count = c->d_all_rows + C; }                          // else: every chain
         launch_gemm_list(q, ld, c->tp.b, npad, L.H, npad, C, ld, npad, L.act, L.act_count, c->stream);                    // η = Q·Xᵀ
         hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, c->stream, P, R, L);            // r, the blocks' sums
         launch_gemm_splitk(L.H, npad, c->tp.a, ld, L.P, ld, (size_t)C * ld, C, npad, ld, DHMC_LOGISTIC_BLOCK, L.act, L.act_count,
                            c->stream);                                                                                   // Xᵀr, block by block
-        DHMC_EXT_NPL_FWD(builtin_logistic_fold_kernel, dim3(C), C, ld, q, L, c->lr.S1, c->rb.tbuf)
+        DHMC_EXT_NPL_FWD(builtin_logistic_fold_kernel, dim3(C), C, ld, q, L, c->lr.S1, c->rb.tbuf)                         // (listed chains only)
         return DHMC_OK;
     }
     if (c->builtin_big && c->cfg.target == DHMC_TARGET_DENSE_NORMAL) {
@@ -1243,7 +1249,8 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 e = hipMemsetAsync(R.list_count, 0, sizeof(int), c->stream);
                 if (!P.one_product) launch_gemm_rows(R.cp, c->d_Minv, R.tbuf, ld, C, nullptr, nullptr, c->stream);   // M⁻¹pₘ
                 DHMC_EXT_NPL(rounds_k2a_dense_external_kernel, dim3(C), ra.P, ra.R)                    // q′ (one product: M⁻¹pₘ = p♯ + (ϵ/2)u)
-                rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
+                if (c->logistic_batched && c->lr.act) launch_logistic_op(4, c->NPL, ra, c->lr, c->stream);   // the rows of this round
+                rc = external_eval(c, c->st.q, true);                                                  // ℓ(q′), ∇ℓ(q′)
                 if (rc) { c->poisoned = true; cleanup(); return rc; }   // st.q holds trial positions: see DHMC_CHECK_USABLE
                 DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′
                 if (P.one_product) launch_gemm_rows(c->st.g, c->d_Minv, R.cu, ld, C, nullptr, nullptr, c->stream);   // u′ = ∇ℓq′·M⁻¹
@@ -1268,7 +1275,8 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 if ((rc = dispatch(c, Op::RoundK0, &ra))) { cleanup(); return rc; }
                 e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
                 launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
-                rc = external_eval(c, c->st.q);                                                        // ℓ(q′), ∇ℓ(q′)
+                if (c->logistic_batched && c->lr.act) launch_logistic_op(4, c->NPL, ra, c->lr, c->stream);   // the rows of this round
+                rc = external_eval(c, c->st.q, true);                                                  // ℓ(q′), ∇ℓ(q′)
                 if (rc) { c->poisoned = true; cleanup(); return rc; }   // st.q holds trial positions: see DHMC_CHECK_USABLE
                 DHMC_EXT_NPL(rounds_k2_external_kernel, dim3(C), ra.P, ra.R, c->lr)                    // evaluate_ℓ, p′, p♯
                 if ((rc = dispatch(c, Op::RoundK3, &ra))) { cleanup(); return rc; }

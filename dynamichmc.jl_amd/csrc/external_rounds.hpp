@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64) void builtin_dense_normal_post_kernel(int ld, c
 template <int NPL>
 __global__ __launch_bounds__(64) void builtin_logistic_fold_kernel(int C, int ld, const double* __restrict__ q, LogisticRound L,
                                                                   double* __restrict__ lq_out, double* __restrict__ grad) {
-    const int chain = blockIdx.x, lane = threadIdx.x;
+    if ((int)blockIdx.x >= *L.act_count) return;
+    const int chain = L.act[blockIdx.x], lane = threadIdx.x;       // the listed chains (all of them outside the rounds)
     const size_t row = (size_t)chain * ld, zs = (size_t)C * ld;
     LaneAcc<1, NPL> qq;
 #pragma unroll 2
