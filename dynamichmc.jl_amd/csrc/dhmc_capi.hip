@@ -523,7 +523,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // beyond 1024 coordinates the streaming round-engine kernels serve external models and the built-in normal families
     c->builtin_big = D > 1024 && (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL ||
                                   cfg->target == DHMC_TARGET_TRIDIAG_NORMAL || cfg->target == DHMC_TARGET_FUNNEL ||
-                                  cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_LOGISTIC);
+                                  cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_LOGISTIC ||
+                                  cfg->target == DHMC_TARGET_ALWAYS_DIVERGENT);
     // … and the logistic regression with a shared dense metric at ANY width: its functor re-reads X twice per gradient and chain
     // (hundreds of ms per leapfrog at N = 10⁵), the batched evaluation is two GEMMs over all chains
     if (cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DENSE && !cfg->dense_per_chain) c->builtin_big = 1;
@@ -845,7 +846,7 @@ int external_eval(dhmc_ctx* c, const double* q, bool active = false) {
     }
     if (c->builtin_big) {
         const int kind = c->cfg.target == DHMC_TARGET_STD_NORMAL ? 0 : c->cfg.target == DHMC_TARGET_DIAG_NORMAL ? 1 :
-                         c->cfg.target == DHMC_TARGET_TRIDIAG_NORMAL ? 2 : 3;
+                         c->cfg.target == DHMC_TARGET_TRIDIAG_NORMAL ? 2 : c->cfg.target == DHMC_TARGET_FUNNEL ? 3 : 4;
         const dim3 g(c->cfg.chains), b(WAVE);
         if (c->NPL == 32)
             hipLaunchKernelGGL((builtin_normal_eval_kernel<32>), g, b, 0, c->stream, kind, c->cfg.dim, c->Dpad, q, c->tp.a, c->tp.b, c->lr.S1, c->rb.tbuf);

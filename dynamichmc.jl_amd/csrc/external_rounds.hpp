@@ -44,7 +44,7 @@ __device__ __forceinline__ double external_evaluate(const double* __restrict__ q
 // the host's callback stands for an external model — lq [C], grad [C][ld] — so the same round engine (init, step-size
 // search, per-draw loops) serves them up to 4096 dimensions.  One wave per chain; the arithmetic (element order, the
 // ABI's blocked dot product) is the functors' of targets.hpp / oracle/targets.hpp.
-//   kind 0: standard normal; 1: diagonal normal (a = μ, b = precision); 2: tridiagonal precision (a = diag, b = off); 3: Neal's funnel
+//   kind 0: standard normal; 1: diagonal normal (a = μ, b = precision); 2: tridiagonal precision (a = diag, b = off); 3: Neal's funnel; 4: AlwaysDivergentTest
 template <int NPL>
 __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D, int ld, const double* __restrict__ q,
                                                                 const double* __restrict__ a, const double* __restrict__ b,
@@ -52,6 +52,18 @@ __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D
     const int chain = blockIdx.x, lane = threadIdx.x;
     const double* qr = q + (size_t)chain * ld;
     double* gr = grad + (size_t)chain * ld;
+    if (kind == 4) {                                   // the reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73): ℓ = 0 at the origin, −Inf elsewhere
+        bool zero = true;
+#pragma unroll 4
+        for (int k = 0; k < NPL; ++k) {
+            const int e = lane + WAVE * k;
+            gr[e] = e < D ? 1.0 : 0.0;
+            zero = zero && (qr[e] == 0.0);
+        }
+        zero = wave_all(zero);
+        if (lane == 0) lq[chain] = zero ? 0.0 : -dm_inf();
+        return;
+    }
     if (kind == 3) {                                   // Neal's funnel, the arithmetic of FunnelT::eval (targets.hpp) slot by slot
         const double v = uni_f64(qr[0]);
         const double ev = det_exp(-v);

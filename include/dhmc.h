@@ -103,12 +103,12 @@ extern "C" {
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
                                     * (dhmc_set_logdensity_callback); dim <= 4096, diagonal or shared dense metric. params: none */
 /* Dimension limits.  dim <= 1024: every family, every metric (register/LDS-resident kernels, GEMM round engines).
- * 1024 < dim <= 4096: DHMC_TARGET_EXTERNAL and every sampling family (STD / DIAG / TRIDIAG / DENSE normal, funnel, logistic
- * regression), diagonal or shared dense metric, through the streaming round engine: the library evaluates the density of all
+ * 1024 < dim <= 4096: DHMC_TARGET_EXTERNAL and every built-in family (STD / DIAG / TRIDIAG / DENSE normal, funnel, logistic
+ * regression, the always-divergent test density), diagonal or shared dense metric, through the streaming round engine: the library evaluates the density of all
  * chains itself where the callback would stand — the normal families and the funnel in one kernel, the dense normal as one
  * product (q − μ)·P over the chains, the logistic gradient as its two GEMMs over the chains — with the families' arithmetic
- * (dhmc_set_logdensity_callback is then DHMC_ERR_INVALID_ARGUMENT).  dim > 4096, per-chain dense metrics beyond 1024 and
- * DHMC_TARGET_ALWAYS_DIVERGENT beyond 1024: DHMC_ERR_UNSUPPORTED. */
+ * (dhmc_set_logdensity_callback is then DHMC_ERR_INVALID_ARGUMENT).  dim > 4096 and per-chain dense metrics beyond 1024:
+ * DHMC_ERR_UNSUPPORTED. */
 #define DHMC_TARGET_USER_BASE 1000  /* + the handle dhmc_register_target_source returned: the caller's own DEVICE FUNCTOR, compiled at run
                                     * time into the library's own per-draw, initialisation and step-size-search kernels — no host round
                                     * trip per leapfrog, the same kernels the built-in families run.  Diagonal or shared dense metric, dim <= 1024.

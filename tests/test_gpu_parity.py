@@ -248,8 +248,12 @@ def test_empty_and_unrecorded_runs(pkg):
     assert np.array_equal(dev.position()[0], ora.position()[0])
     with pytest.raises(RuntimeError, match="unsupported"):
         pkg.DeviceContext(4097, 1)                                 # D > 4096 is outside this build (DHMC_ERR_UNSUPPORTED)
-    with pytest.raises(RuntimeError, match="unsupported"):
-        pkg.DeviceContext(1025, 1, target=ol.TARGET_ALWAYS_DIVERGENT)   # beyond 1024: the sampling families and external models
+    big, obig = make_pair(pkg, 1030, 2, target=ol.TARGET_ALWAYS_DIVERGENT, seed=3)      # beyond 1024 coordinates every family runs through
+    q0 = np.zeros((2, 1030))                                                         # the batched-evaluation engine: the reference's
+    big.init(q0); obig.init(q0); big.set_stepsize(0.3); obig.set_stepsize(0.3)       # AlwaysDivergentTest (test_NUTS.jl:58-85) there
+    a, b = big.run(3), obig.run(3)
+    assert_same(a, b, "always divergent, D = 1030")
+    assert (a["steps"] == 1).all() and (a["depth"] == 0).all() and (a["acceptance_rate"] == 0).all()
     with pytest.raises(ValueError):
         dev.run(-1)
 
