@@ -634,7 +634,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (const char* e = std::getenv("DHMC_DENSE_ROUNDS")) c->dense_rounds = std::atoi(e) != 0;  // 0: wave-per-chain matvec kernel
         if (c->per_chain_dense) c->dense_rounds = 0;   // the GEMM engine shares one M⁻¹ across the rows of a product
         c->dense_products = c->per_chain_dense ? 2 : 1;
-        if (const char* e = std::getenv("DHMC_DENSE_PRODUCTS")) { const int v = std::atoi(e); if (v == 2 || (v == 1 && c->dense_products == 1)) c->dense_products = v; }
+        if (const char* e = std::getenv("DHMC_DENSE_PRODUCTS")) { const int v = std::atoi(e); if (v == 1 || v == 2) c->dense_products = v; }
         std::vector<double> I((size_t)D * D, 0.0);
         for (int i = 0; i < D; ++i) I[(size_t)i * D + i] = 1.0;
         if ((rc = upload_dense_metric(c, I, I))) return fail(rc);
@@ -993,7 +993,6 @@ int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
 
 int dhmc_set_dense_products(dhmc_ctx* c, int32_t products) {
     if (!c || c->cfg.metric != DHMC_METRIC_DENSE || (products != 1 && products != 2)) return DHMC_ERR_INVALID_ARGUMENT;
-    if (products == 1 && c->per_chain_dense) return DHMC_ERR_UNSUPPORTED;
     c->dense_products = products;
     return DHMC_OK;
 }

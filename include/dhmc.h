@@ -252,8 +252,8 @@ int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, doub
  *      reference's operation order, like the pooled adaptation: per-step energies agree to ≈1e-12, trees are the same —
  *      tests/test_gpu_tolerance.py).  Both dense engines — the GEMM rounds (from 128 chains or beyond 256 coordinates) and the
  *      wave-per-chain kernel (a handful of small chains) — run either recurrence with the same bits.
- * dense_per_chain contexts always use 2 (asking for 1 there: DHMC_ERR_UNSUPPORTED).  May be
- * changed between dhmc_run calls.  DHMC_DENSE_PRODUCTS=2 in the environment makes 2 the default. */
+ * dense_per_chain contexts — the reference's semantics — default to 2 and take 1 on request.  May be changed between
+ * dhmc_run calls.  DHMC_DENSE_PRODUCTS=1|2 in the environment sets the default of every dense context. */
 int dhmc_set_dense_products(dhmc_ctx* ctx, int32_t products);
 int dhmc_get_dense_products(const dhmc_ctx* ctx);   /* 1 or 2; 0 for a context without a dense metric */
 /* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */

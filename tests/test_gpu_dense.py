@@ -266,6 +266,21 @@ def test_per_chain_dense_metric_is_the_references_semantics(pkg):
         assert np.array_equal(dev.metric_dense(c)[0], ora.metric_dense(c)[0])
 
 
+def test_per_chain_dense_metric_takes_the_one_product_recurrence_on_request(pkg):
+    K, C = 20, 4
+    kw = dict(metric=ol.METRIC_DENSE, seed=5, dense_per_chain=True)
+    dev = pkg.DeviceContext(K, C, **kw); ora = ol.Oracle(K, C, threads=4, **kw)
+    assert dev.dense_products() == 2
+    dev.set_dense_products(1); ora.set_dense_products(1)
+    for e in (dev, ora):
+        e.init(); e.find_initial_stepsize()
+    a, b = dev.run(60, da={}), ora.run(60, da={})
+    same(a, b, "stage")
+    dev.update_metric_dense(a["draws"], 5.0 / 60); ora.update_metric_dense(b["draws"], 5.0 / 60)
+    same(dev.run(20), ora.run(20), "after the per-chain update")
+    assert not np.array_equal(dev.metric_dense(0)[0], dev.metric_dense(1)[0])
+
+
 def test_per_chain_dense_update_in_batches_across_block_boundaries(pkg):
     """The per-chain update estimates and factorises all chains of a batch per launch (blockIdx.z = chain): D = 70 spans three
     32-step Cholesky blocks and two 64-column covariance tiles; every chain's M⁻¹ and W bit-equal to the oracle's."""
