@@ -167,10 +167,30 @@ __device__ __forceinline__ void sym_matvec(const double* __restrict__ S, int Dpa
                                            const double (&v)[NPL], double (&out)[NPL]) {
 #pragma unroll
     for (int s = 0; s < NPL; ++s) out[s] = 0.0;
+    // rows of S are fetched UB at a time (a lone wave otherwise waits out one L2 round trip per row); the fma chain of every
+    // output stays k ascending
+    constexpr int UB = NPL <= 2 ? 8 : (NPL <= 4 ? 4 : (NPL <= 8 ? 2 : 1));
 #pragma unroll
     for (int s2 = 0; s2 < NPL; ++s2) {
         const int kcount = (D - WAVE * s2) < WAVE ? (D - WAVE * s2) : WAVE;
-        for (int l2 = 0; l2 < kcount; ++l2) {
+        int l2 = 0;
+        if constexpr (UB > 1) {
+            for (; l2 + UB <= kcount; l2 += UB) {
+                double r[UB][NPL], vk[UB];
+#pragma unroll
+                for (int b = 0; b < UB; ++b) {
+                    const double* __restrict__ rowk = S + (size_t)(WAVE * s2 + l2 + b) * Dpad;
+#pragma unroll
+                    for (int s = 0; s < NPL; ++s) r[b][s] = rowk[lane + WAVE * s];
+                    vk[b] = readlane_f64(v[s2], l2 + b);
+                }
+#pragma unroll
+                for (int b = 0; b < UB; ++b)
+#pragma unroll
+                    for (int s = 0; s < NPL; ++s) out[s] = __builtin_fma(r[b][s], vk[b], out[s]);
+            }
+        }
+        for (; l2 < kcount; ++l2) {
             const double vk = readlane_f64(v[s2], l2);
             const double* __restrict__ rowk = S + (size_t)(WAVE * s2 + l2) * Dpad;
 #pragma unroll
