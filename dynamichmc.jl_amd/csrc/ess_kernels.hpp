@@ -28,6 +28,21 @@ __device__ __forceinline__ double ess_block_sum(double v, double* red) {
     return r;
 }
 
+// Σ_c p[c·stride] over the chains in ascending order (eight loads in flight; the sum itself stays sequential)
+__device__ __forceinline__ double ess_chain_sum(const double* __restrict__ p, size_t stride, int64_t C) {
+    double s = 0.0;
+    int64_t c = 0;
+    for (; c + 8 <= C; c += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + x[u];
+    }
+    for (; c < C; ++c) s = s + p[(size_t)c * stride];
+    return s;
+}
+
 // grid (ncoords, C); dynamic LDS: N doubles
 __global__ __launch_bounds__(ESS_THREADS) void ess_acov_kernel(const double* __restrict__ draws, int64_t N, int64_t D,
                                                               const int32_t* __restrict__ coords, int64_t C,
@@ -64,9 +79,7 @@ __global__ __launch_bounds__(ESS_THREADS) void ess_finish_kernel(const double* _
     const int j = blockIdx.x;
     const double* a = acov + (size_t)j * C * N;
     for (int64_t t = threadIdx.x; t < N; t += ESS_THREADS) {
-        double s = 0.0;
-        for (int64_t c = 0; c < C; ++c) s = s + a[(size_t)c * N + t];
-        macov[t] = s / (double)C;
+        macov[t] = ess_chain_sum(a + t, (size_t)N, C) / (double)C;
     }
     // mean and (ddof = 1) variance of the chain means
     double s = 0.0;
@@ -160,9 +173,7 @@ __global__ __launch_bounds__(ESS_THREADS) void ess_finish_chunk_kernel(const dou
     const double* a = acov + (size_t)j * C * ESS_LAG_CHUNK;
     const int64_t nl = N - t0 < ESS_LAG_CHUNK ? N - t0 : ESS_LAG_CHUNK;
     for (int64_t t = threadIdx.x; t < nl; t += ESS_THREADS) {
-        double s = 0.0;
-        for (int64_t c = 0; c < C; ++c) s = s + a[(size_t)c * ESS_LAG_CHUNK + t];
-        macov[t] = s / (double)C;
+        macov[t] = ess_chain_sum(a + t, (size_t)ESS_LAG_CHUNK, C) / (double)C;
     }
     double mm = 0.0, ssq = 0.0;
     if (t0 == 0) {
