@@ -538,15 +538,16 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     c->Dpad = c->NPL * WAVE;
     // Round engines pay ≈8 launches per leapfrog round; they win once a round carries enough chains to fill the
     // chip (GEMM rows), otherwise the one-wave-per-chain kernels are faster.  DHMC_*_ROUNDS=0/1 overrides.
-    const bool many_chains = cfg->chains >= 128;
     // logistic regression, diagonal metric: the GEMM engine whatever the chain count — the wave-per-chain functor re-reads X twice per
     // gradient and chain (4 chains, N = 10⁵, p = 256: 306 ms per leapfrog against 0.27; N = 10³, p = 16: 140 µs against 105)
     c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && !c->builtin_big;
     if (const char* e = std::getenv("DHMC_LOGISTIC_ROUNDS"))
         c->logistic_rounds = cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DIAG && std::atoi(e) != 0 && !c->builtin_big;
-    // dense metric: the GEMM round engine from 128 chains or beyond 256 coordinates; below both, the wave-per-chain kernel (a matvec
-    // per chain from L2, no launches per round: 2–9× faster for a handful of small chains) — the same bits either way
-    c->dense_rounds = many_chains || D > 256;
+    // dense metric: the wave-per-chain kernel (a matvec per chain from L2, several rows in flight, no launches per round) up to 128
+    // coordinates at any chain count and up to 256 below 2048 chains — measured, D = 64 / 128 / 256: 346 / 110 / 29 M leapfrogs/s at
+    // 4096 chains against 51 / 76 / 52 for the GEMM rounds, 58 / 33 / 23 against 3 / 3 / 10 at 256–512 chains — the rounds otherwise;
+    // the same bits either way
+    c->dense_rounds = D > 256 || (D > 128 && cfg->chains >= 2048);
     c->logistic_batched = cfg->target == DHMC_TARGET_LOGISTIC && (c->builtin_big || c->logistic_rounds);
     c->external = cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big;
     c->nvec = (cfg->metric == DHMC_METRIC_DENSE || c->logistic_rounds || c->external) ? wd_nvec(cfg->max_depth) : ws_nvec(cfg->max_depth);

@@ -250,8 +250,8 @@ int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, doub
  *      rounding does not accumulate across transitions.  2·D² flops per leapfrog.  Every elementwise step is a separate
  *      multiply and add in the order written.  The DEFAULT of a shared dense metric (a stated deviation from the
  *      reference's operation order, like the pooled adaptation: per-step energies agree to ≈1e-12, trees are the same —
- *      tests/test_gpu_tolerance.py).  Both dense engines — the GEMM rounds (from 128 chains or beyond 256 coordinates) and the
- *      wave-per-chain kernel (a handful of small chains) — run either recurrence with the same bits.
+ *      tests/test_gpu_tolerance.py).  Both dense engines — the wave-per-chain kernel (up to 128 coordinates, and up to 256 below 2048
+ *      chains) and the GEMM rounds (otherwise) — run either recurrence with the same bits.
  * dense_per_chain contexts — the reference's semantics — default to 2 and take 1 on request.  May be changed between
  * dhmc_run calls.  DHMC_DENSE_PRODUCTS=1|2 in the environment sets the default of every dense context. */
 int dhmc_set_dense_products(dhmc_ctx* ctx, int32_t products);

@@ -82,8 +82,8 @@ def test_lds_trajectory_layout_with_a_target_that_is_not_coordinate_wise(pkg):
 @pytest.mark.parametrize("products", [1, 2])
 def test_dense_round_engine_equals_wave_kernel(pkg, products):
     """Both dense engines run both recurrences (the reference's two products per leapfrog, or one with u = M⁻¹∇ℓ carried) with the
-    same bits, so which of them serves a context — the wave-per-chain kernel below 128 chains and 257 coordinates, the GEMM rounds
-    otherwise — is a matter of speed only."""
+    same bits, so which of them serves a context — the wave-per-chain kernel for narrow chains, the GEMM rounds for wide ones or very
+    many — is a matter of speed only."""
     rng = np.random.default_rng(3)
     K = 96
     A = rng.normal(size=(K, K)); Minv = np.linalg.inv(A.T @ A / K + 0.1 * np.eye(K))
