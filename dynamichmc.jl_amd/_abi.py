@@ -72,7 +72,7 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
            "dhmc_set_logdensity_callback", "dhmc_ess_bulk", "dhmc_ess_tail", "dhmc_summarize_tree_statistics",
            "dhmc_set_dense_products", "dhmc_get_dense_products", "dhmc_host_alloc", "dhmc_host_free",
-           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log"]
+           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log", "dhmc_detmath_selftest"]
 
 _lib = None
 

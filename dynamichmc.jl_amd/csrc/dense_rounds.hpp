@@ -76,7 +76,7 @@ __device__ __forceinline__ void begin_transition_request(const RunParams& P, con
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_MOMENTUM, tr, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
         cp_row[e0] = e0 < P.D ? z0 : 0.0;
         if (2 * kk + 1 < NPLr) cp_row[e1] = e1 < P.D ? z1 : 0.0;
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(64) void rounds_start_kernel(RunParams P, RoundBuff
         S.total_steps = 0;
         S.init_slot = 0;
         if (P.adapt && P.da_init) {   // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
-            double le = det_log(S.eps);
-            S.da.mu = det_log(10.0) + le;
+            double le = det_log_u(S.eps);
+            S.da.mu = det_log_u(10.0) + le;
             S.da.m = 1;
             S.da.Hbar = 0.0;
             S.da.logeps = le;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void rounds_k0_kernel(RunParams P, RoundBuffers
     uint32_t w[4];
     philox4x32_10(0u, PURPOSE_DIRECTIONS, S.tr, key.seed_hi, key.k0, key.k1, w);
     const uint32_t dirs0 = uni_u32(w[0]);
-    const double eps = uni_f64(P.adapt ? det_exp(S.da.logeps) : S.eps);   // current_ϵ (stepsize.jl:163)
+    const double eps = uni_f64(P.adapt ? det_exp_u(S.da.logeps) : S.eps);   // current_ϵ (stepsize.jl:163)
     const bool fwd = (dirs0 & 1u) != 0;
     const double eps_s = fwd ? eps : -eps;
     const double h = eps_s / 2;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
         uint64_t r1, r2;
         stream_raw64(key, S.nrand, PURPOSE_TREE, S.tr, r1, r2);
         S.nrand += 1;
-        return uni_f64(det_randexp(r1));
+        return uni_f64(det_randexp_t<dm_uniform>(r1));
     };
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(S.free_mask);
@@ -408,11 +408,11 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     if (invalid) {
         for (int l2 = level; l2 < depth0; ++l2) {
             if ((j >> l2) & 1u) {
-                v_lsa = uni_f64(det_logaddexp(S.lv_vlsa[l2], v_lsa));
+                v_lsa = uni_f64(det_logaddexp_u(S.lv_vlsa[l2], v_lsa));
                 v_steps += (int64_t)S.lv_vsteps[l2];
             }
         }
-        S.vtop_lsa = uni_f64(det_logaddexp(S.vtop_lsa, v_lsa));
+        S.vtop_lsa = uni_f64(det_logaddexp_u(S.vtop_lsa, v_lsa));
         S.vtop_steps += v_steps;
         finished = true;
     }
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
     if (finished) {
         // ---- end of the transition (NUTS.jl:238-240; mcmc.jl:272-278, 375-377) --------------------
         const double eps_used = fwd ? S.eps_s : -S.eps_s;
-        double a = det_exp(S.vtop_lsa) / (double)S.vtop_steps;
+        double a = det_exp_u(S.vtop_lsa) / (double)S.vtop_steps;
         const double acc_rate = uni_f64(a < 1.0 ? a : 1.0);
         S.init_slot = S.zeta_top;
         S.lq_cur = S.sl_lq[S.init_slot];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
             const double m = (double)S.da.m;
             S.da.Hbar += (P.delta - acc_rate - S.da.Hbar) / (m + (double)P.t0);
             S.da.logeps = S.da.mu - __builtin_sqrt(m) / P.gamma * S.da.Hbar;
-            S.da.logeps_bar += det_pow_pos(m, -P.kappa) * (S.da.logeps - S.da.logeps_bar);
+            S.da.logeps_bar += det_pow_pos_u(m, -P.kappa) * (S.da.logeps - S.da.logeps_bar);
         }
         S.n += 1;
         S.tr += 1;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
                 P.st.lq[chain] = S.lq_cur;
                 if (P.adapt) {
                     P.st.da[chain] = S.da;
-                    if (P.da_finalize) P.st.eps[chain] = det_exp(S.da.logeps_bar);
+                    if (P.da_finalize) P.st.eps[chain] = det_exp_u(S.da.logeps_bar);
                 }
                 P.st.transition[chain] = S.tr;
                 P.st.status[chain] = S.status;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
         uint64_t r1, r2;
         stream_raw64(key, nrand, PURPOSE_TREE, tr, r1, r2);
         nrand += 1;
-        return uni_f64(det_randexp(r1));
+        return uni_f64(det_randexp_t<dm_uniform>(r1));
     };
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(free_mask);
@@ -329,11 +329,11 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     if (invalid) {
         for (int l2 = level; l2 < depth0; ++l2) {
             if ((j >> l2) & 1u) {
-                v_lsa = uni_f64(det_logaddexp(S.lv_vlsa[l2], v_lsa));
+                v_lsa = uni_f64(det_logaddexp_u(S.lv_vlsa[l2], v_lsa));
                 v_steps += (int64_t)S.lv_vsteps[l2];
             }
         }
-        vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));
+        vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa));
         vtop_steps += v_steps;
         finished = true;
     }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     if (finished) {
         // ---- end of the transition (NUTS.jl:238-240; mcmc.jl:272-278, 375-377) --------------------
         const double eps_used = fwd ? eps_s : -eps_s;
-        double a = det_exp(vtop_lsa) / (double)vtop_steps;
+        double a = det_exp_u(vtop_lsa) / (double)vtop_steps;
         const double acc_rate = uni_f64(a < 1.0 ? a : 1.0);
         init_slot = zeta_top;
         lq_cur = S.sl_lq[init_slot];
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
             const double m = (double)da.m;
             da.Hbar += (P.delta - acc_rate - da.Hbar) / (m + (double)P.t0);
             da.logeps = da.mu - __builtin_sqrt(m) / P.gamma * da.Hbar;
-            da.logeps_bar += det_pow_pos(m, -P.kappa) * (da.logeps - da.logeps_bar);
+            da.logeps_bar += det_pow_pos_u(m, -P.kappa) * (da.logeps - da.logeps_bar);
         }
         n_done += 1;
         tr += 1;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 uint64_t r1, r2;
                 stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_MOMENTUM, tr, r1, r2);
                 double z0, z1;
-                det_randn2(r1, r2, &z0, &z1);
+                det_randn2_v(r1, r2, &z0, &z1);
                 const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
                 R.cp[row + e0] = e0 < D ? z0 : 0.0;
                 R.cp[row + e1] = e1 < D ? z1 : 0.0;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 P.st.lq[chain] = lq_cur;
                 if (P.adapt) {
                     P.st.da[chain] = da;
-                    if (P.da_finalize) P.st.eps[chain] = det_exp(da.logeps_bar);
+                    if (P.da_finalize) P.st.eps[chain] = det_exp_u(da.logeps_bar);
                 }
                 P.st.transition[chain] = tr;
                 P.st.status[chain] = status;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D
     }
     if (kind == 3) {                                   // Neal's funnel, the arithmetic of FunnelT::eval (targets.hpp) slot by slot
         const double v = uni_f64(qr[0]);
-        const double ev = det_exp(-v);
+        const double ev = det_exp_u(-v);
         LaneAcc<1, NPL> fa;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void builtin_normal_eval_kernel(int kind, int D
         const double hd = 0.5 * (double)(D - 1);
         const double hes = (0.5 * ev) * S;
         if (lane == 0) {
-            lq[chain] = ((-(v * v) / 18.0) - hes) - hd * v;
-            gr[0] = ((-v / 9.0) + hes) - hd;
+            lq[chain] = (((v * v) * (-1.0 / 18.0)) - hes) - hd * v;
+            gr[0] = ((v * (-1.0 / 9.0)) + hes) - hd;
         }
         return;
     }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void ext_search_begin_kernel(ExtSearchParams P)
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_SEARCH_MOMENTUM, tr, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
         const double pa = P.st.W[row + e0] * z0;
         P.p0[row + e0] = pa;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void ext_search_dense_z_kernel(ExtSearchParams 
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_SEARCH_MOMENTUM, tr, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
         z[row + e0] = e0 < P.D ? z0 : 0.0;
         if (2 * kk + 1 < NPL) z[row + e1] = e1 < P.D ? z1 : 0.0;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) void ext_probe_momentum_kernel(ExtProbeParams P
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), PURPOSE_PROBE_MOMENTUM, momentum_index + (uint32_t)m, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         const int e0 = lane + WAVE * (2 * kk), e1 = e0 + WAVE;
         if (P.dense) {
             P.p0[row + e0] = e0 < P.D ? z0 : 0.0;

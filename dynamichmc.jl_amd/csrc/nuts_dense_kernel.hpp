@@ -48,7 +48,7 @@ __device__ __forceinline__ void sample_momentum_dense(const ChainKey& key, uint3
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), purpose, transition, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         z[2 * kk] = (lane + WAVE * (2 * kk) < D) ? z0 : 0.0;
         if (2 * kk + 1 < NPL) z[2 * kk + 1] = (lane + WAVE * (2 * kk + 1) < D) ? z1 : 0.0;
     }
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
     unsigned long long total_steps = 0;
 
     if (P.adapt && P.da_init) {
-        double le = det_log(eps_fixed);
-        da.mu = det_log(10.0) + le;
+        double le = det_log_u(eps_fixed);
+        da.mu = det_log_u(10.0) + le;
         da.m = 1;
         da.Hbar = 0.0;
         da.logeps = le;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
 
     for (int64_t n = 0; n < P.N; ++n) {
         const uint32_t tr = tr0 + (uint32_t)n;
-        const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);
+        const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);
 
         sample_momentum_dense<NPL>(key, PURPOSE_MOMENTUM, tr, M, Dpad, D, lane, p, ps);
         if (one_product) {                           // the transition's anchor: a fresh product (make_phasepoint in the oracle)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         auto rexp_fill = [&](uint32_t base) {
             uint64_t r1, r2;
             stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
-            rexp_vals = det_randexp(r1);
+            rexp_vals = det_randexp_v(r1);
             rexp_base = base;
         };
         rexp_fill(0);
@@ -426,11 +426,11 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
                 if (invalid) {
                     for (int l2 = level; l2 < depth; ++l2) {
                         if ((j >> l2) & 1u) {
-                            v_lsa = uni_f64(det_logaddexp(lv_vlsa[l2], v_lsa));
+                            v_lsa = uni_f64(det_logaddexp_u(lv_vlsa[l2], v_lsa));
                             v_steps += (int64_t)lv_vsteps[l2];
                         }
                     }
-                    vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));
+                    vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa));
                     vtop_steps += v_steps;
                     finished = true;
                 }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         }
 
         const double acc_rate = [&]() {
-            double a = det_exp(vtop_lsa) / (double)vtop_steps;
+            double a = det_exp_u(vtop_lsa) / (double)vtop_steps;
             return uni_f64(a < 1.0 ? a : 1.0);
         }();
         init_slot = zeta_top;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
             const double m = (double)da.m;
             da.Hbar += (P.delta - acc_rate - da.Hbar) / (m + (double)P.t0);
             da.logeps = da.mu - __builtin_sqrt(m) / P.gamma * da.Hbar;
-            da.logeps_bar += det_pow_pos(m, -P.kappa) * (da.logeps - da.logeps_bar);
+            da.logeps_bar += det_pow_pos_u(m, -P.kappa) * (da.logeps - da.logeps_bar);
         }
     }
 
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         P.st.lq[chain] = lq_cur;
         if (P.adapt) {
             P.st.da[chain] = da;
-            if (P.da_finalize) P.st.eps[chain] = det_exp(da.logeps_bar);
+            if (P.da_finalize) P.st.eps[chain] = det_exp_u(da.logeps_bar);
         }
         P.st.transition[chain] = tr0 + (uint32_t)P.N;
         P.st.status[chain] = status;

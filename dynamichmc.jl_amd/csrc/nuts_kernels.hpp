@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "../../include/dhmc.h"
 #include "../../include/dhmc_detmath.h"
+#include "detmath_dev.hpp"
 #include "philox_dev.hpp"
 #include "targets.hpp"
 #include "wave.hpp"
@@ -262,15 +263,13 @@ __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
     return acc[0] < 0 || acc[1] < 0;
 }
 
-// Two logaddexp's in one pass: even lanes evaluate (a1, b1), odd lanes (a2, b2); the results
-// come back as scalars.  (The scalar transcendentals of the tree logic are wave-uniform; doing
-// two different ones in different lanes halves their dependent-chain latency.)
-__device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, double b2, int lane,
+// The two logaddexp's of a merge (visited statistic and ω).  Wave-uniform arguments: each is ≈ 20 vector instructions with its
+// softplus cell fetched by one scalar load (detmath_dev.hpp); ABI v1's pair — exp, log and two divisions evaluated in even / odd
+// lanes — was 177.
+__device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, double b2, int,
                                                double& r1, double& r2) {
-    const bool odd = (lane & 1) != 0;
-    const double r = det_logaddexp(odd ? a2 : a1, odd ? b2 : b1);
-    r1 = readlane_f64(r, 0);
-    r2 = readlane_f64(r, 1);
+    r1 = uni_f64(det_logaddexp_u(a1, b1));
+    r2 = uni_f64(det_logaddexp_u(a2, b2));
 }
 
 // p = W .* randn (hamiltonian.jl:124) from the chain's stream.
@@ -282,7 +281,7 @@ __device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t pu
         uint64_t r1, r2;
         stream_raw64(key, (uint32_t)(lane + WAVE * kk), purpose, transition, r1, r2);
         double z0, z1;
-        det_randn2(r1, r2, &z0, &z1);
+        det_randn2_v(r1, r2, &z0, &z1);
         p[2 * kk] = Wrow[lane + WAVE * (2 * kk)] * z0;
         if (2 * kk + 1 < NPL) p[2 * kk + 1] = Wrow[lane + WAVE * (2 * kk + 1)] * z1;
     }
@@ -372,8 +371,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     unsigned long long total_steps = 0;
 
     if (P.adapt && P.da_init) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
-        double le = det_log(eps_fixed);
-        da.mu = det_log(10.0) + le;
+        double le = det_log_u(eps_fixed);
+        da.mu = det_log_u(10.0) + le;
         da.m = 1;
         da.Hbar = 0.0;
         da.logeps = le;
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     for (int64_t n = 0; n < P.N; ++n) {
         PH(1)   // momentum refresh + transition setup
         const uint32_t tr = tr0 + (uint32_t)n;
-        const double eps = uni_f64(P.adapt ? det_exp(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
+        const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
 
         // ---- sample_tree (NUTS.jl:232-241): p, directions, π₀ --------------------------
         sample_momentum<NPL>(key, PURPOSE_MOMENTUM, tr, Wrow, lane, p);
@@ -438,7 +437,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         auto rexp_fill = [&](uint32_t base) {
             uint64_t r1, r2;
             stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
-            rexp_vals = det_randexp(r1);
+            rexp_vals = det_randexp_v(r1);
             rexp_base = base;
         };
         rexp_fill(0);
@@ -661,11 +660,11 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                     // statistic (trees.jl:244,249-250)
                     for (int l2 = level; l2 < depth; ++l2) {
                         if ((j >> l2) & 1u) {
-                            v_lsa = uni_f64(det_logaddexp(lv_vlsa.get(l2), v_lsa));
+                            v_lsa = uni_f64(det_logaddexp_u(lv_vlsa.get(l2), v_lsa));
                             v_steps += (int64_t)lv_vsteps.get(l2);
                         }
                     }
-                    vtop_lsa = uni_f64(det_logaddexp(vtop_lsa, v_lsa));   // trees.jl:294
+                    vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa)); // trees.jl:294
                     vtop_steps += v_steps;
                     finished = true;                                       // trees.jl:297
                 }
@@ -675,7 +674,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         // ---- TreeStatisticsNUTS and the new position (NUTS.jl:238-240) -----------------
         PH(8)   // end of transition
         const double acc_rate = [&]() {
-            double a = det_exp(vtop_lsa) / (double)vtop_steps;             // NUTS.jl:87
+            double a = det_exp_u(vtop_lsa) / (double)vtop_steps;           // NUTS.jl:87
             return uni_f64(a < 1.0 ? a : 1.0);
         }();
         init_slot = zeta_top;
@@ -710,7 +709,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             const double m = (double)da.m;
             da.Hbar += (P.delta - acc_rate - da.Hbar) / (m + (double)P.t0);
             da.logeps = da.mu - __builtin_sqrt(m) / P.gamma * da.Hbar;
-            da.logeps_bar += det_pow_pos(m, -P.kappa) * (da.logeps - da.logeps_bar);
+            da.logeps_bar += det_pow_pos_u(m, -P.kappa) * (da.logeps - da.logeps_bar);
         }
     }
 
@@ -723,7 +722,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         P.st.lq[chain] = lq_cur;
         if (P.adapt) {
             P.st.da[chain] = da;
-            if (P.da_finalize) P.st.eps[chain] = det_exp(da.logeps_bar);   // final_ϵ (stepsize.jl:170; mcmc.jl:285)
+            if (P.da_finalize) P.st.eps[chain] = det_exp_u(da.logeps_bar); // final_ϵ (stepsize.jl:170; mcmc.jl:285)
         }
         P.st.transition[chain] = tr0 + (uint32_t)P.N;
         P.st.status[chain] = status;

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/dhmc.h"
 #include "../../include/dhmc_detmath.h"
+#include "detmath_dev.hpp"
 #include "wave.hpp"
 
 namespace dhmc {
@@ -194,7 +195,7 @@ struct FunnelT {
     template <int NPL>
     __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
         double v = readlane_f64(q[0], 0);
-        double ev = det_exp(-v);
+        double ev = det_exp_u(-v);
         LaneAcc<1, NPL> acc;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -204,10 +205,10 @@ struct FunnelT {
         double S = wave_allreduce1(acc.fold(0));
         double hd = 0.5 * (double)(D - 1);
         double hes = (0.5 * ev) * S;
-        double lq = ((-(v * v) / 18.0) - hes) - hd * v;
+        double lq = (((v * v) * (-1.0 / 18.0)) - hes) - hd * v;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) g[k] = -(ev * q[k]);
-        if (lane == 0) g[0] = ((-v / 9.0) + hes) - hd;
+        if (lane == 0) g[0] = ((v * (-1.0 / 9.0)) + hes) - hd;
         return lq;
     }
     __device__ __forceinline__ double finish(double s) const { return s; }
@@ -260,9 +261,9 @@ struct LogisticT {
                     eta = __builtin_fma(XT[(size_t)(WAVE * s2 + l2) * Npad + n], bd, eta);
                 }
             }
-            const double t = det_exp(-__builtin_fabs(eta));
+            const double t = det_exp_v(-__builtin_fabs(eta));
             const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-            const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg(t);
+            const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg_t<dm_vector>(t);
             const bool valid = n < N;
             const double yn = y[n];
             const double r = valid ? yn - sig : 0.0;

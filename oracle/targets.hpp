@@ -100,8 +100,8 @@ struct Funnel : Target {
         double S = wave_dot(x.data(), x.data(), D);
         double hd = 0.5 * (double)(D - 1);
         double hes = (0.5 * ev) * S;
-        lq = ((-(v * v) / 18.0) - hes) - hd * v;
-        g[0] = ((-v / 9.0) + hes) - hd;
+        lq = (((v * v) * (-1.0 / 18.0)) - hes) - hd * v;
+        g[0] = ((v * (-1.0 / 9.0)) + hes) - hd;
         for (int i = 1; i < D; ++i) g[i] = -(ev * q[i]);
     }
 };

@@ -65,7 +65,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB_PATH)
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".hpp", ".cpp"))]
-    srcs += [os.path.join(ROOT, "include", f) for f in ("dhmc.h", "dhmc_detmath.h")]
+    srcs += [os.path.join(ROOT, "include", f) for f in ("dhmc.h", "dhmc_detmath.h", "dhmc_detmath_tables.h")]
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
