@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
         uint64_t r1, r2;
         stream_raw64(key, S.nrand, PURPOSE_TREE, S.tr, r1, r2);
         S.nrand += 1;
-        return uni_f64(det_randexp_t<dm_uniform>(r1));
+        return uni_f64(det_randexp_t<dm_u>(r1));
     };
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(S.free_mask);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
         uint64_t r1, r2;
         stream_raw64(key, nrand, PURPOSE_TREE, tr, r1, r2);
         nrand += 1;
-        return uni_f64(det_randexp_t<dm_uniform>(r1));
+        return uni_f64(det_randexp_t<dm_u>(r1));
     };
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(free_mask);

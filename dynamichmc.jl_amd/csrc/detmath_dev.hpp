@@ -10,57 +10,50 @@
 //   dm_vector    the arguments differ per lane (log and sin/cos of the momentum refresh, Exp(1) draws): table rows are
 //                gathered per lane, compile-time polynomial coefficients sit in scalar registers.
 //
-// Why the Horner chains are inline assembly: for fma(s, x, constant) the compiler's own choice is two v_mov_b32 of the
-// constant into a vector register pair followed by v_fmac_f64 — three vector instructions per step instead of one — and
-// around single-instruction asm statements it inserts a wait state per step; a whole chain per asm block has neither.
-// v_fma_f64 reads at most one scalar operand (constant-bus limit of gfx9), so the leading coefficient is moved to the
-// accumulator first (v_mov_b64).
+// How the Horner chains get one instruction per step: for fma(s, x, constant) the compiler's own choice is two v_mov_b32 of the
+// constant into a vector register pair followed by v_fmac_f64 — three vector instructions instead of one.  Passing each
+// coefficient through an EMPTY asm statement with an "s" constraint pins it to a scalar register pair without emitting
+// anything, and the compiler then selects v_fma_f64 with the scalar operand (the constant-bus limit of gfx9 allows one per
+// instruction: the leading coefficient is the one it moves to the accumulator).  No instruction is written in asm: round 4's
+// first version spelled the chains (and Philox's v_mad_u64_u32) out as asm blocks, and gfx950's software-managed hazards —
+// two wait states between a VALU write of an SGPR (a v_readlane reload of a spilled SGPR is one) and a VALU read of it, one
+// between a VALU write of a VGPR and a v_readfirstlane of it — are tracked by the compiler for its own instructions only:
+// stale operands, wild scalar loads, and with the wait states added by hand still two funnel cases at D = 1000 in the fuzz
+// sweep whose trees differed from the oracle's.  tools/isa_hazard_verify.py checks the built library for those hazards.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/dhmc_detmath.h"
 
 namespace dhmc {
 
-struct dm_asm_horner {
+__device__ __forceinline__ double dm_in_sgpr(double c) {
+    asm("" : "+s"(c));
+    return c;
+}
+
+struct dm_sgpr_horner {
     template <int N>
     static __device__ __forceinline__ double run(double x, const double (&c)[N]) {
-        static_assert(N == 4 || N == 5 || N == 6 || N == 8, "Horner chains of the ABI's polynomials");
-        double s;
-        if constexpr (N == 4) {
-            asm("v_mov_b64 %0, %5\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %2"
-                : "=&v"(s) : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]));
-        } else if constexpr (N == 5) {
-            asm("v_mov_b64 %0, %6\n\tv_fma_f64 %0, %0, %1, %5\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %3\n\t"
-                "v_fma_f64 %0, %0, %1, %2"
-                : "=&v"(s) : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]));
-        } else if constexpr (N == 6) {
-            asm("v_mov_b64 %0, %7\n\tv_fma_f64 %0, %0, %1, %6\n\tv_fma_f64 %0, %0, %1, %5\n\tv_fma_f64 %0, %0, %1, %4\n\t"
-                "v_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %2"
-                : "=&v"(s) : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]));
-        } else {
-            asm("v_mov_b64 %0, %9\n\tv_fma_f64 %0, %0, %1, %8\n\tv_fma_f64 %0, %0, %1, %7\n\tv_fma_f64 %0, %0, %1, %6\n\t"
-                "v_fma_f64 %0, %0, %1, %5\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %2"
-                : "=&v"(s) : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]));
-        }
+        double s = dm_in_sgpr(c[N - 1]);
+#pragma unroll
+        for (int k = N - 2; k >= 0; --k) s = __builtin_fma(s, x, dm_in_sgpr(c[k]));
         return s;
     }
 };
 
 struct dm_uniform {
-    static __device__ __forceinline__ int idx(int i) {      // opaque to the optimiser: everything derived from the index is scalar code
-        int s;
-        asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(i));
-        return s;
+    // The index is uniform and the compiler can prove it — and then keeps it, and the address arithmetic behind it, in vector
+    // registers.  The empty asm makes the value opaque, so v_readfirstlane stays and everything derived from it is scalar code.
+    // (v_readfirstlane itself comes from the builtin, see above.)
+    static __device__ __forceinline__ int idx(int i) {
+        asm volatile("" : "+v"(i));
+        return (int)__builtin_amdgcn_readfirstlane((unsigned)i);
     }
     template <int N>
-    static __device__ __forceinline__ double horner_const(double x, const double (&c)[N]) { return dm_asm_horner::run<N>(x, c); }
+    static __device__ __forceinline__ double horner_const(double x, const double (&c)[N]) { return dm_sgpr_horner::run<N>(x, c); }
     template <int N>
-    static __device__ __forceinline__ double horner_row(double x, const double (&c)[N]) { return dm_asm_horner::run<N>(x, c); }
-    static __device__ __forceinline__ double max_nonnan(double x, double y) {       // v_max_f64: one instruction where a select is three
-        double r;
-        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-        return r;
-    }
+    static __device__ __forceinline__ double horner_row(double x, const double (&c)[N]) { return dm_sgpr_horner::run<N>(x, c); }
+    static __device__ __forceinline__ double max_nonnan(double x, double y) { return __builtin_fmax(x, y); }   // v_max_f64
     typedef double v8d __attribute__((ext_vector_type(8)));
     static __device__ __forceinline__ void row8(const double* row, double (&c)[8]) {  // uniform, 64-byte aligned: s_load_dwordx16
         const v8d v = *reinterpret_cast<const v8d*>(row);
@@ -72,22 +65,39 @@ struct dm_uniform {
 struct dm_vector {
     static __device__ __forceinline__ int idx(int i) { return i; }
     template <int N>
-    static __device__ __forceinline__ double horner_const(double x, const double (&c)[N]) { return dm_asm_horner::run<N>(x, c); }
+    static __device__ __forceinline__ double horner_const(double x, const double (&c)[N]) { return dm_sgpr_horner::run<N>(x, c); }
     template <int N>
     static __device__ __forceinline__ double horner_row(double x, const double (&c)[N]) { return dm_generic::horner_const<N>(x, c); }
     static __device__ __forceinline__ double max_nonnan(double x, double y) { return dm_uniform::max_nonnan(x, y); }
     static __device__ __forceinline__ void row8(const double* row, double (&c)[8]) { dm_generic::row8(row, c); }
 };
 
+// Debugging switches (tools/experiments/build_variant_fast.sh): the compiler's own code in place of a policy, per use.
+#ifdef DHMC_UNI_GENERIC
+typedef dm_generic dm_u;
+#else
+typedef dm_uniform dm_u;
+#endif
+#ifdef DHMC_VEC_GENERIC
+typedef dm_generic dm_v;
+#else
+typedef dm_vector dm_v;
+#endif
+#ifdef DHMC_REXP_GENERIC
+typedef dm_generic dm_rexp;
+#else
+typedef dm_v dm_rexp;
+#endif
+
 // wave-uniform arguments
-__device__ __forceinline__ double det_exp_u(double x) { return det_exp_t<dm_uniform>(x); }
-__device__ __forceinline__ double det_log_u(double x) { return det_log_t<dm_uniform>(x); }
-__device__ __forceinline__ double det_logaddexp_u(double x, double y) { return det_logaddexp_t<dm_uniform>(x, y); }
-__device__ __forceinline__ double det_pow_pos_u(double x, double y) { return det_pow_pos_t<dm_uniform>(x, y); }
+__device__ __forceinline__ double det_exp_u(double x) { return det_exp_t<dm_u>(x); }
+__device__ __forceinline__ double det_log_u(double x) { return det_log_t<dm_u>(x); }
+__device__ __forceinline__ double det_logaddexp_u(double x, double y) { return det_logaddexp_t<dm_u>(x, y); }
+__device__ __forceinline__ double det_pow_pos_u(double x, double y) { return det_pow_pos_t<dm_u>(x, y); }
 // per-lane arguments
-__device__ __forceinline__ double det_exp_v(double x) { return det_exp_t<dm_vector>(x); }
-__device__ __forceinline__ double det_log_v(double x) { return det_log_t<dm_vector>(x); }
-__device__ __forceinline__ double det_randexp_v(uint64_t r) { return det_randexp_t<dm_vector>(r); }
-__device__ __forceinline__ void det_randn2_v(uint64_t r1, uint64_t r2, double* z0, double* z1) { det_randn2_t<dm_vector>(r1, r2, z0, z1); }
+__device__ __forceinline__ double det_exp_v(double x) { return det_exp_t<dm_v>(x); }
+__device__ __forceinline__ double det_log_v(double x) { return det_log_t<dm_v>(x); }
+__device__ __forceinline__ double det_randexp_v(uint64_t r) { return det_randexp_t<dm_rexp>(r); }
+__device__ __forceinline__ void det_randn2_v(uint64_t r1, uint64_t r2, double* z0, double* z1) { det_randn2_t<dm_v>(r1, r2, z0, z1); }
 
 }  // namespace dhmc

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, RoundBuf
             const int64_t n = n0 + u * WAVE + lane;
             const double t = det_exp_v(-__builtin_fabs(eta[u]));
             const double sig = eta[u] >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-            const double l1pe = (eta[u] > 0 ? eta[u] : 0.0) + det_log1p_nonneg_t<dm_vector>(t);
+            const double l1pe = (eta[u] > 0 ? eta[u] : 0.0) + det_log1p_nonneg_t<dm_v>(t);
             const bool valid = n < N;
             if (n < ne) h[n] = valid ? y[u] - sig : 0.0;
             if (valid) lpart = lpart + (y[u] * eta[u] - l1pe);

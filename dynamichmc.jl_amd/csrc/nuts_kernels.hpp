@@ -272,18 +272,47 @@ __device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, 
     r2 = uni_f64(det_logaddexp_u(a2, b2));
 }
 
-// p = W .* randn (hamiltonian.jl:124) from the chain's stream.
+// p = W .* randn (hamiltonian.jl:124) from the chain's stream.  The Box–Muller pairs are taken in batches of four: Philox and the
+// argument reductions of the whole batch first, then ALL its table rows (log cell, sin/cos cell: per-lane gathers) and W
+// slots requested together, then the arithmetic.  A lone wave waits out every memory round trip it takes one at a time, and
+// these rows come from L2 as often as not (the chain's workspace traffic streams through the CU's 32 KB L1): pair by pair the
+// refresh of a 1024-coordinate row cost 16 exposed round trips (round 4: +500 clocks per leapfrog against ABI v1's table-free
+// polynomials, more than the shorter arithmetic saved), in batches it costs four.
 template <int NPL>
 __device__ __forceinline__ void sample_momentum(const ChainKey& key, uint32_t purpose, uint32_t transition,
                                                 const double* __restrict__ Wrow, int lane, double (&p)[NPL]) {
+    constexpr int NP = (NPL + 1) / 2;
+    constexpr int B = NP < 4 ? NP : 4;
 #pragma unroll
-    for (int kk = 0; kk < (NPL + 1) / 2; ++kk) {
-        uint64_t r1, r2;
-        stream_raw64(key, (uint32_t)(lane + WAVE * kk), purpose, transition, r1, r2);
-        double z0, z1;
-        det_randn2_v(r1, r2, &z0, &z1);
-        p[2 * kk] = Wrow[lane + WAVE * (2 * kk)] * z0;
-        if (2 * kk + 1 < NPL) p[2 * kk + 1] = Wrow[lane + WAVE * (2 * kk + 1)] * z1;
+    for (int b0 = 0; b0 < NP; b0 += B) {
+        dm_randn2_reduced R[B];
+        double lrow[B][3], srow[B][2], w0[B], w1[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int kk = b0 + i;
+            uint64_t r1, r2;
+            stream_raw64(key, (uint32_t)(lane + WAVE * kk), purpose, transition, r1, r2);
+            dm_randn2_reduce(r1, r2, &R[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int kk = b0 + i;
+            const double* __restrict__ lp = DM_LOG_TBL[R[i].jl];
+            const double* __restrict__ sp = DM_SINCOS_TBL[R[i].js];
+            lrow[i][0] = lp[0]; lrow[i][1] = lp[1]; lrow[i][2] = lp[2];
+            srow[i][0] = sp[0]; srow[i][1] = sp[1];
+            w0[i] = Wrow[lane + WAVE * (2 * kk)];
+            w1[i] = (2 * kk + 1 < NPL) ? Wrow[lane + WAVE * (2 * kk + 1)] : 0.0;
+        }
+        asm volatile("" ::: "memory");           // every request of the batch is in flight before the first answer is used
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int kk = b0 + i;
+            double z0, z1;
+            dm_randn2_finish<dm_v>(R[i], lrow[i][0], lrow[i][1], lrow[i][2], srow[i][0], srow[i][1], &z0, &z1);
+            p[2 * kk] = w0[i] * z0;
+            if (2 * kk + 1 < NPL) p[2 * kk + 1] = w1[i] * z1;
+        }
     }
 }
 

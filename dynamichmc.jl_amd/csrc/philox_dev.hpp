@@ -13,13 +13,14 @@ struct ChainKey {
     uint32_t k0, k1, seed_hi;
 };
 
-// 32 x 32 -> 64 bit product as ONE v_mad_u64_u32 (the compiler emits v_mul_hi_u32 + v_mul_lo_u32, two quarter-rate
-// instructions, for the same thing).
-__device__ __forceinline__ void mul_wide_u32(uint32_t m, uint32_t c, uint32_t& hi, uint32_t& lo) {
-    uint64_t d;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "s"(m), "v"(c) : "vcc");
-    hi = (uint32_t)(d >> 32);
-    lo = (uint32_t)d;
+// The two 32 x 32 -> 64 bit products of a Philox round: the compiler emits ONE v_mad_u64_u32 for each (ROCm 7.2; older
+// compilers chose v_mul_hi_u32 + v_mul_lo_u32 and rounds 2-3 wrote the instruction in asm — see csrc/detmath_dev.hpp for why no
+// instruction is written in asm any more).
+__device__ __forceinline__ void philox_round_products(uint32_t m0, uint32_t m1, uint32_t c0, uint32_t c2,
+                                                      uint32_t& hi0, uint32_t& lo0, uint32_t& hi1, uint32_t& lo1) {
+    const uint64_t e0 = (uint64_t)m0 * c0, e1 = (uint64_t)m1 * c2;
+    hi0 = (uint32_t)(e0 >> 32); lo0 = (uint32_t)e0;
+    hi1 = (uint32_t)(e1 >> 32); lo1 = (uint32_t)e1;
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -27,8 +28,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
-        mul_wide_u32(0xD2511F53u, c0, hi0, lo0);
-        mul_wide_u32(0xCD9E8D57u, c2, hi1, lo1);
+        philox_round_products(0xD2511F53u, 0xCD9E8D57u, c0, c2, hi0, lo0, hi1, lo1);
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -263,7 +263,7 @@ struct LogisticT {
             }
             const double t = det_exp_v(-__builtin_fabs(eta));
             const double sig = eta >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-            const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg_t<dm_vector>(t);
+            const double l1pe = (eta > 0 ? eta : 0.0) + det_log1p_nonneg_t<dm_v>(t);
             const bool valid = n < N;
             const double yn = y[n];
             const double r = valid ? yn - sig : 0.0;

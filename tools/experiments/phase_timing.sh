@@ -12,7 +12,7 @@ if [ "${1:-run}" = build ]; then
     FL="-O3 -std=c++17 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wno-unused-result"
     /opt/rocm/bin/hipcc $FL -DDHMC_PHASE_TIMING -DDHMC_FAMILY=StdNormalT -c -o $ROOT/tools/experiments/_phase/family_StdNormalT.o family.hip
     OBJS=$(ls ../lib/obj/*.o | grep -v family_StdNormalT)
-    /opt/rocm/bin/hipcc $FL -shared -o $ROOT/tools/experiments/_phase/libdhmc_amd.so $OBJS $ROOT/tools/experiments/_phase/family_StdNormalT.o
+    /opt/rocm/bin/hipcc $FL -shared -o $ROOT/tools/experiments/_phase/libdhmc_amd.so $OBJS $ROOT/tools/experiments/_phase/family_StdNormalT.o -lhiprtc
     rm $ROOT/tools/experiments/_phase/family_StdNormalT.o
     exit 0
 fi

@@ -71,6 +71,12 @@ while time.time() - t0 < budget:
             n = int(rng.integers(1, 25 if D < 500 or not dense else 4)); adapt = rng.random() < 0.6
             x = dev.run(n, da={} if adapt else None, allow_failure=True); y_ = ora.run(n, da={} if adapt else None, allow_failure=True)
             for k in x:
+                if not np.array_equal(x[k], y_[k], equal_nan=True) and os.environ.get("FUZZ_VERBOSE"):   # where and by how much
+                    bad = np.argwhere(~((x[k] == y_[k]) | (np.isnan(x[k].astype(float)) & np.isnan(y_[k].astype(float)))))
+                    i = tuple(bad[0]); c_, t_ = int(i[0]), int(i[1])
+                    print(f"  first difference in {k} at {i} of {x[k].shape} ({len(bad)} entries differ): device {x[k][i]!r} oracle {y_[k][i]!r}", file=sys.stderr)
+                    for f_ in ("depth", "steps", "term_left", "term_right", "acceptance_rate", "pi", "logdensities", "eps"):
+                        if f_ in x: print(f"    chain {c_}: {f_} device {x[f_][c_][max(t_ - 1, 0):t_ + 2]!r} oracle {y_[f_][c_][max(t_ - 1, 0):t_ + 2]!r}", file=sys.stderr)
                 assert np.array_equal(x[k], y_[k], equal_nan=True), f"field {k}"
             nrun += 1; ntrans += n * C; nleap += int(x["steps"].sum())
             assert np.array_equal(dev.stepsize(), ora.stepsize(), equal_nan=True), "eps"
