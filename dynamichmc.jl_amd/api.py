@@ -747,7 +747,11 @@ def mcmc_next_step(steps, Q=None):
     # A Q that is the context's own last state (the object this function returned, or equal arrays) costs no copy; a Q of
     # the caller's own is evaluated on the device — strictly, as dhmc_init does, where the reference would trust its ℓq and
     # ∇ℓq (mcmc.jl:348-351): a stated deviation, the position is what defines the step.
+    # The cached state counts only while nobody else moved the chains (two MCMCSteps over one context, a run or set_position in
+    # between): the context's position epoch says so.
     last = getattr(steps, "_last_Q", None)
+    if last is not None and getattr(steps, "_last_epoch", None) != ctx.position_epoch:
+        last = None
     if Q is not None and Q is not last and not (last is not None and np.array_equal(last.q, np.asarray(Q.q))):
         if last is not None or not np.array_equal(ctx.position()[0], np.asarray(Q.q)):
             ctx.set_position(Q.q)
@@ -756,6 +760,7 @@ def mcmc_next_step(steps, Q=None):
     out = EvaluatedLogDensity(q, lq, g)
     try:
         steps._last_Q = out
+        steps._last_epoch = ctx.position_epoch
     except AttributeError:
         pass
     return out, ts

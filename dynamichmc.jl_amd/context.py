@@ -95,6 +95,7 @@ class DeviceContext:
                  max_depth=10, min_delta=-1000.0, chain_offset=0, metric=abi.METRIC_DIAG, device=0,
                  stream=None, dense_per_chain=False):
         self.D, self.C = int(dim), int(chains)
+        self.position_epoch = 0      # bumped by every call that can move the chains: whoever caches a position checks it (api.mcmc_next_step)
         cfg = abi.Config()
         cfg.device, cfg.dim, cfg.chains, cfg.chain_offset = device, self.D, self.C, chain_offset
         cfg.metric, cfg.target, cfg.max_depth, cfg.min_delta, cfg.seed = metric, target, max_depth, min_delta, seed
@@ -153,12 +154,14 @@ class DeviceContext:
         """initialize_warmup_state (mcmc.jl:129-132)."""
         if q0 is not None and isinstance(q0, np.ndarray):
             q0 = np.ascontiguousarray(np.broadcast_to(q0, (self.C, self.D)), np.float64)
+        self.position_epoch += 1
         return self._chk(abi.lib().dhmc_init(self.h, _ptr(q0), int(q0 is not None and _is_device(q0))), "dhmc_init", allow_failure)
 
     def set_position(self, q, allow_failure=False):
         """Q := evaluate_ℓ(ℓ, q) at the caller's positions; κ, ϵ, adaptation state and random streams are kept."""
         if isinstance(q, np.ndarray) or not _is_device(q):
             q = np.ascontiguousarray(np.broadcast_to(np.asarray(q, np.float64), (self.C, self.D)), np.float64)
+        self.position_epoch += 1
         return self._chk(abi.lib().dhmc_set_position(self.h, _ptr(q), int(_is_device(q))), "dhmc_set_position", allow_failure)
 
     def position(self):
@@ -241,6 +244,7 @@ class DeviceContext:
             d = dict(delta=0.8, gamma=0.05, kappa=0.75, t0=10, init=1, finalize=1)
             d.update(da)
             dap = abi.DualAveragingABI(d["delta"], d["gamma"], d["kappa"], d["t0"], d["init"], d["finalize"], 0)
+        self.position_epoch += 1
         rc = abi.lib().dhmc_run(self.h, C.c_int64(N), C.byref(dap) if dap is not None else None, C.byref(o))
         return self._chk(rc, "dhmc_run", allow_failure)
 
@@ -354,6 +358,7 @@ class DeviceContext:
 
     def import_state(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)
+        self.position_epoch += 1
         self._chk(abi.lib().dhmc_import_state(self.h, _ptr(blob), C.c_uint64(blob.size)), "dhmc_import_state")
 
     # ---- measurement -----------------------------------------------------------------------

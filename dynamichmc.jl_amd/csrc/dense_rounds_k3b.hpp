@@ -104,7 +104,9 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
     ldv<NT>(cp_row, lane, p);
     double* const cps_row = R.cps + row + off;
     double* const cu_row = R.cu + row + off;
-    constexpr bool CAN_FUSE = BlockEval<T>::value;
+    // … and whose finite ℓ implies a finite gradient: the fused step applies evaluate_ℓ's rules without the gradient scan
+    // (a functor of the caller's with kElementwise but without kFiniteLqImpliesFiniteGrad keeps the separate K2 kernel)
+    constexpr bool CAN_FUSE = BlockEval<T>::value && T::kFiniteLqImpliesFiniteGrad;
     const bool fuse = CAN_FUSE && P.fuse_k2 && P.one_product;
     // ∇ℓ of a stored point (proposal slot, parked edge) is not kept next to its q but re-evaluated from it, a block per wave
     // (same functor, same bits), for the families where that is cheap: two row copies less per suspended leaf

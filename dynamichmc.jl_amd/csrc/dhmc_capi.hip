@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <hipcub/hipcub.hpp>
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +59,11 @@ const char* rtc_prelude() {
 }
 // the kernels a functor needs, as name expressions: the wave-per-chain set of the diagonal metric, or the dense metric's
 // (round engine K0/K2/K3, wave-per-chain run and search, the two probes)
+uint64_t rtc_checksum(const char* p, uint64_t n) {      // FNV-1a over the code object
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
 std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
     const std::string T = "dhmc::" + name, N = std::to_string(npl);
     if (!dense)
@@ -94,7 +101,7 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
             char magic[8];
             uint32_t n = 0;
             std::vector<std::string> names;
-            if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DHMCRTC1", 8) == 0 && std::fread(&n, 4, 1, f) == 1 && n == exprs.size()) {
+            if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DHMCRTC2", 8) == 0 && std::fread(&n, 4, 1, f) == 1 && n == exprs.size()) {
                 ok = true;
                 for (uint32_t i = 0; i < n && ok; ++i) {
                     uint32_t len = 0;
@@ -103,9 +110,10 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
                     ok = ok && (len == 0 || std::fread(&t[0], 1, len, f) == len);
                     names.push_back(t);
                 }
-                uint64_t cs = 0;
+                uint64_t cs = 0, sum = 0;
                 ok = ok && std::fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 31);
                 if (ok) { code->resize(cs); ok = std::fread(code->data(), 1, cs, f) == cs; }
+                ok = ok && std::fread(&sum, 8, 1, f) == 1 && sum == rtc_checksum(code->data(), cs);      // a damaged payload is not trusted
             }
             std::fclose(f);
             if (ok) { *lowered = names; g_rtc_log = "(loaded from " + cache_file + ")"; return DHMC_OK; }
@@ -115,7 +123,16 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
     for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"};
+    // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
+    // whatever device it will run beside them on)
+    std::string arch = "--offload-arch=gfx950";
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0])
+            arch = std::string("--offload-arch=") + prop.gcnArchName;
+    }
+    const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"};
     const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
     size_t ls = 0;
     (void)hiprtcGetProgramLogSize(prog, &ls);
@@ -139,16 +156,17 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     }
     (void)hiprtcDestroyProgram(&prog);
     if (rc == DHMC_OK && !cache_file.empty()) {           // written under another name first: a concurrent reader never sees half a file
-        const std::string tmp = cache_file + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&rc);
+        static std::atomic<unsigned> serial{0};              // unique per process (pid) and per call: concurrent ranks never share a tmp file
+        const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
             const uint32_t n = (uint32_t)lowered->size();
-            bool ok = std::fwrite("DHMCRTC1", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
+            bool ok = std::fwrite("DHMCRTC2", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
             for (const auto& t : *lowered) {
                 const uint32_t len = (uint32_t)t.size();
                 ok = ok && std::fwrite(&len, 4, 1, f) == 1 && std::fwrite(t.data(), 1, len, f) == len;
             }
-            const uint64_t cs = code->size();
-            ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code->data(), 1, cs, f) == cs;
+            const uint64_t cs = code->size(), sum = rtc_checksum(code->data(), cs);
+            ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code->data(), 1, cs, f) == cs && std::fwrite(&sum, 8, 1, f) == 1;
             ok = (std::fclose(f) == 0) && ok;
             if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) (void)std::remove(tmp.c_str());
         }
@@ -156,11 +174,24 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     return rc;
 }
 // load a compiled module and look its kernels up in the order of rtc_kernel_names
+// (the module handle and the functions are published only when every kernel resolved; otherwise the module is unloaded and
+// *mod stays null, so that a later context compiles again instead of finding a module without kernels)
 int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low, hipModule_t* mod, std::initializer_list<hipFunction_t*> fns) {
-    if (hipModuleLoadData(mod, code.data()) != hipSuccess) return DHMC_ERR_HIP;
+    hipModule_t m = nullptr;
+    if (hipModuleLoadData(&m, code.data()) != hipSuccess) return DHMC_ERR_HIP;
+    std::vector<hipFunction_t> got;
     size_t i = 0;
-    for (hipFunction_t* f : fns)
-        if (i >= low.size() || hipModuleGetFunction(f, *mod, low[i++].c_str()) != hipSuccess) return DHMC_ERR_HIP;
+    for (size_t k = 0; k < fns.size(); ++k) {
+        hipFunction_t f = nullptr;
+        if (i >= low.size() || hipModuleGetFunction(&f, m, low[i++].c_str()) != hipSuccess || !f) {
+            (void)hipModuleUnload(m);
+            return DHMC_ERR_HIP;
+        }
+        got.push_back(f);
+    }
+    i = 0;
+    for (hipFunction_t* f : fns) *f = got[i++];
+    *mod = m;
     return DHMC_OK;
 }
 int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : 0; }
@@ -215,10 +246,9 @@ struct dhmc_ctx {
     unsigned long long last_rounds = 0;
     uint64_t ws_bytes = 0;
     // host outputs of dhmc_run: persistent device staging (two buffers per field, grown on demand — no hipMalloc per call),
-    // a copy stream, and pinned bounce buffers for destinations that are not page-locked
+    // and a copy stream
     struct StageBuf { void* p = nullptr; size_t cap = 0; };
     StageBuf stage[2][10];
-    StageBuf bounce[2];
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_k0[2] = {}, ev_k1[2] = {}, ev_copy[2] = {};
     int* h_done = nullptr;     // page-locked [2][8]: the dense round engine's done-counters, read without draining the streams
@@ -302,24 +332,30 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
     if (c->user) {     // the caller's functor: the same kernels, from the run-time compiled modules
         const UserKernels& U = *c->user;
+        // the grid is the op's own chain count: the dense round engine runs half-batches (RoundArgs::P.C chains from P.chain_base)
+        // on two streams, and the kernels index chain_base + blockIdx.x without a bounds guard
+        unsigned grid = (unsigned)c->cfg.chains;
         auto launch = [&](hipFunction_t f, unsigned block, unsigned lds, void** args) {
-            return f && hipModuleLaunchKernel(f, (unsigned)c->cfg.chains, 1, 1, block, 1, 1, lds, cs, args, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
+            return f && grid > 0 && hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, cs, args, nullptr) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
         };
         DenseMetric dm = M ? *M : DenseMetric{};
         switch (op) {
         case Op::Run: {
             const RunParams& R = *(const RunParams*)P;
+            grid = (unsigned)R.C;
             void* args[] = {const_cast<void*>(P), &dm};
             if (M) return launch(U.run_dense, WAVE, (unsigned)lds_bytes_dense(), args);
             return launch(R.l1_in_lds ? U.run_lds : U.run, WAVE,
                           (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0)), args);
         }
-        case Op::Init: { void* args[] = {const_cast<void*>(P)}; return launch(U.init, WAVE, 0, args); }
+        case Op::Init: { grid = (unsigned)((const InitParams*)P)->C; void* args[] = {const_cast<void*>(P)}; return launch(U.init, WAVE, 0, args); }
         case Op::Search: {
+            grid = (unsigned)((const SearchParams*)P)->C;
             void* args[] = {const_cast<void*>(P), &dm};
             return M ? launch(U.search_dense, WAVE, 0, args) : launch(U.search, WAVE, (unsigned)(sizeof(double) * c->Dpad), args);
         }
         case Op::ProbeTrajectory: case Op::ProbeRatios: {     // Diagnostics.leapfrog_trajectory / explore_log_acceptance_ratios
+            grid = (unsigned)((const ProbeParams*)P)->C;
             void* args[] = {const_cast<void*>(P), &dm};
             const bool traj = op == Op::ProbeTrajectory;
             if (M) return launch(traj ? U.probe_traj_dense : U.probe_ratio_dense, WAVE, 0, args);
@@ -328,6 +364,7 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
         case Op::RoundStart: return dispatch_family<StdNormalT>(c->NPL, op, P, cs, M);      // no density in this kernel
         case Op::RoundK0: case Op::RoundK2: case Op::RoundK3: {
             RoundArgs a = *(const RoundArgs*)P;
+            grid = (unsigned)a.P.C;
             void* args[] = {&a.P, &a.R};
             if (op == Op::RoundK0) return launch(U.k0, WAVE, 0, args);
             if (op == Op::RoundK2) return launch(U.k2, WAVE, 0, args);
@@ -795,7 +832,6 @@ int dhmc_destroy(dhmc_ctx* c) {
     for (int b = 0; b < 2; ++b) if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
     for (int b = 0; b < 2; ++b) {
         for (auto& sb : c->stage[b]) if (sb.p) (void)hipFree(sb.p);
-        if (c->bounce[b].p) (void)hipHostFree(c->bounce[b].p);
         if (c->ev_k0[b]) (void)hipEventDestroy(c->ev_k0[b]);
         if (c->ev_k1[b]) (void)hipEventDestroy(c->ev_k1[b]);
         if (c->ev_copy[b]) (void)hipEventDestroy(c->ev_copy[b]);
@@ -1589,31 +1625,39 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     unsigned long long leapfrogs = 0, rounds = 0;
     int rc = DHMC_OK;
     bool used[2] = {false, false};
-    for (int64_t k = 0; k < nchunks; ++k) {
-        const int b = (int)(k & 1);
-        const int64_t n0 = k * L, len = std::min(L, N - n0);
-        if (used[b]) HIP_TRY(c, hipEventSynchronize(c->ev_copy[b]));            // staging buffer b is free again
-        dhmc_outputs dev{};
-        dev.on_device = 1;
-        void** slots[10] = {(void**)&dev.draws, (void**)&dev.logdensities, (void**)&dev.eps, (void**)&dev.pi, (void**)&dev.acceptance_rate,
-                            (void**)&dev.steps, (void**)&dev.term_left, (void**)&dev.term_right, (void**)&dev.depth, (void**)&dev.directions};
-        for (const F& f : fields)
-            if (f.host) *slots[f.idx] = c->stage[b][f.idx].p;
-        dhmc_dual_averaging dk{};
-        if (da) { dk = *da; dk.init = (k == 0) ? da->init : 0; dk.finalize = (k == nchunks - 1) ? da->finalize : 0; }
-        const int r = run_call(c, len, da ? &dk : nullptr, &dev);              // returns with the stream drained
-        ms += c->last_ms; leapfrogs += c->last_leapfrogs; rounds += c->last_rounds;
-        if (r != DHMC_OK && r != DHMC_ERR_CHAIN_FAILURE) { (void)hipStreamSynchronize(c->copy_stream); return r; }
-        if (r != DHMC_OK) rc = r;                                              // (a failed chain: the call goes on, as one call would)
-        for (const F& f : fields) {
-            if (!f.host) continue;
-            HIP_TRY(c, hipMemcpy2DAsync((char*)f.host + (size_t)n0 * f.elem, (size_t)N * f.elem, c->stage[b][f.idx].p, (size_t)len * f.elem,
-                                        (size_t)len * f.elem, C, hipMemcpyDeviceToHost, c->copy_stream));
+    // Every exit drains the copy stream: asynchronous copies into the caller's arrays must not outlive the call (the caller —
+    // numpy, Julia's GC — may free them the moment it sees an error code).
+    auto chunks = [&]() -> int {
+        for (int64_t k = 0; k < nchunks; ++k) {
+            const int b = (int)(k & 1);
+            const int64_t n0 = k * L, len = std::min(L, N - n0);
+            if (used[b]) HIP_TRY(c, hipEventSynchronize(c->ev_copy[b]));            // staging buffer b is free again
+            dhmc_outputs dev{};
+            dev.on_device = 1;
+            void** slots[10] = {(void**)&dev.draws, (void**)&dev.logdensities, (void**)&dev.eps, (void**)&dev.pi, (void**)&dev.acceptance_rate,
+                                (void**)&dev.steps, (void**)&dev.term_left, (void**)&dev.term_right, (void**)&dev.depth, (void**)&dev.directions};
+            for (const F& f : fields)
+                if (f.host) *slots[f.idx] = c->stage[b][f.idx].p;
+            dhmc_dual_averaging dk{};
+            if (da) { dk = *da; dk.init = (k == 0) ? da->init : 0; dk.finalize = (k == nchunks - 1) ? da->finalize : 0; }
+            const int r = run_call(c, len, da ? &dk : nullptr, &dev);              // returns with the stream drained
+            ms += c->last_ms; leapfrogs += c->last_leapfrogs; rounds += c->last_rounds;
+            if (r != DHMC_OK && r != DHMC_ERR_CHAIN_FAILURE) return r;
+            if (r != DHMC_OK) rc = r;                                              // (a failed chain: the call goes on, as one call would)
+            for (const F& f : fields) {
+                if (!f.host) continue;
+                HIP_TRY(c, hipMemcpy2DAsync((char*)f.host + (size_t)n0 * f.elem, (size_t)N * f.elem, c->stage[b][f.idx].p, (size_t)len * f.elem,
+                                            (size_t)len * f.elem, C, hipMemcpyDeviceToHost, c->copy_stream));
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_copy[b], c->copy_stream));
+            used[b] = true;
         }
-        HIP_TRY(c, hipEventRecord(c->ev_copy[b], c->copy_stream));
-        used[b] = true;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        return DHMC_OK;
+    };
+    const int lr = chunks();
+    const hipError_t se = hipStreamSynchronize(c->copy_stream);
+    if (lr != DHMC_OK) return lr;
+    HIP_TRY(c, se);
     c->last_ms = ms; c->last_leapfrogs = leapfrogs; c->last_rounds = rounds;
     return rc;
 }

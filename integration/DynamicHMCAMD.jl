@@ -282,12 +282,24 @@ function DynamicHMC.mcmc_steps(sl::SamplingLogDensityAMD, warmup_state)
     warmup_state.ϵ ≡ nothing && throw(ArgumentError("ϵ ≢ nothing"))
     ctx = sl.ctx
     warmup_state.ϵ == stepsize(ctx) || set_stepsize!(ctx, warmup_state.ϵ)
-    # κ of the warmup state, if it is not the context's own (mcmc.jl:337-339 builds the Hamiltonian from warmup_state.κ)
-    if warmup_state.κ isa DynamicHMC.GaussianKineticEnergy                      # one dense κ shared by the chains
-        set_metric_dense!(ctx, Matrix(warmup_state.κ.M⁻¹))
-    elseif !(warmup_state.κ ≡ kinetic_energy(ctx))
-        m = reduce(hcat, [Vector(k.M⁻¹.diag) for k in warmup_state.κ])           # D×C
-        check(ctx, ccall((:dhmc_set_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, m, 1, 0), "dhmc_set_metric_diag")
+    # κ of the warmup state, if it is not the context's own (mcmc.jl:337-339 builds the Hamiltonian from warmup_state.κ).
+    # Compared by VALUE with what the context holds (current_warmup_state builds fresh objects every time, so identity says
+    # nothing), dispatched on the context's metric layout, uploaded only when it differs.
+    κ, own = warmup_state.κ, kinetic_energy(ctx)
+    same(a, b) = a.M⁻¹ == b.M⁻¹
+    if ctx.metric == 0                                                            # per-chain Diagonal κ: a Vector, or one κ for all chains
+        κs = κ isa DynamicHMC.GaussianKineticEnergy ? fill(κ, ctx.chains) : κ
+        all(k -> k.M⁻¹ isa Diagonal, κs) || throw(ArgumentError("a Diagonal-metric context takes Diagonal kinetic energies"))
+        if !all(same.(κs, own))
+            m = reduce(hcat, [Vector(k.M⁻¹.diag) for k in κs])                     # D×C
+            check(ctx, ccall((:dhmc_set_metric_diag, libdhmc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint), ctx.h, m, 1, 0), "dhmc_set_metric_diag")
+        end
+    elseif ctx.dense_per_chain                                                    # one Symmetric κ per chain, adapted on the device
+        all(same.(κ, own)) || throw(ArgumentError("per-chain dense kinetic energies live in the context (dhmc_update_metric_dense); " *
+                                                  "a warmup state with other matrices cannot be uploaded chain by chain"))
+    else                                                                          # one Symmetric κ shared by the chains
+        κ isa DynamicHMC.GaussianKineticEnergy || throw(ArgumentError("a shared-dense-metric context takes one GaussianKineticEnergy"))
+        same(κ, own) || set_metric_dense!(ctx, Matrix(κ.M⁻¹))
     end
     warmup_state.Q.q == position(ctx).q || set_position!(ctx, warmup_state.Q.q)
     MCMCStepsAMD(sl)

@@ -2,8 +2,13 @@
 
 These functions replace Julia's exp/log/log1p/randn/randexp on the hot path (call sites in the
 header).  Bar: within 2 ulp of numpy/libm over the ranges the sampler uses, so the substitution
-stays inside the reference's own tolerance class.
+stays inside the reference's own tolerance class.  (ABI v2, round 4: table-driven; the tables are
+what tools/gen_detmath_tables.py produces from 200-bit arithmetic.)
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import oracle_lib as ol
 
@@ -115,3 +120,31 @@ def test_wave_dot_matches_plain_dot():
         a = RNG.normal(size=n); b = RNG.normal(size=n)
         assert abs(ol.wave_dot(a, b) - float(np.dot(a, b))) <= 1e-13 * np.abs(a * b).sum()
     assert ol.wave_dot(np.array([np.nan]), np.array([1.0])) != ol.wave_dot(np.array([np.nan]), np.array([1.0]))  # NaN
+
+
+def test_tables_are_what_the_generator_produces():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_detmath_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_softplus_table_against_high_precision():
+    import mpmath as mp
+    mp.mp.prec = 120
+    d = np.concatenate([RNG.uniform(0, 16, 4000), RNG.uniform(16, 745, 1000), (np.arange(257) / 16.0)[:-1], np.nextafter(np.arange(1, 257) / 16.0, 0)])
+    got = ol.detmath(8, np.zeros_like(d), -d)          # logaddexp(0, -d) = softplus(-d)
+    ref = np.array([float(mp.log1p(mp.exp(-mp.mpf(float(v))))) for v in d])
+    assert ulp_err(got, ref).max() <= 2.0
+
+
+def test_exp_log_special_paths():
+    # results in the subnormal range take the two-multiplication path; 709.78... is the last finite argument
+    x = np.array([-708.4, -710.0, -730.0, -744.9, -745.13, 709.782712893383])
+    ref = np.exp(x)
+    got = ol.detmath(0, x)
+    assert (np.abs(got - ref) <= np.maximum(np.spacing(ref), 5e-324)).all()
+    assert np.isfinite(got[-1]) and ol.detmath(0, [709.7827128933841])[0] == np.inf
+    # every cell border of the log table, from both sides
+    cells = 1 + (np.arange(129) - 0.5) / 128
+    xs = np.concatenate([cells, np.nextafter(cells, 0), np.nextafter(cells, 4), cells / 2, cells * 4])
+    assert ulp_err(ol.detmath(1, xs), np.log(xs)).max() <= 2.0

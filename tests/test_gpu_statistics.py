@@ -60,6 +60,23 @@ def test_stepwise_api_and_keep_warmup(pkg):
     assert np.abs(qs.mean((0, 1)) - 1).max() < 0.15
 
 
+def test_two_step_objects_over_one_context_do_not_trust_a_stale_position(pkg):
+    """mcmc.jl:348-351: the step starts from the Q it is GIVEN.  Two MCMCSteps over one context: after B moved the chains, A's
+    remembered last state is stale — a Q equal to it must be pushed back into the context, not assumed to be there."""
+    l = pkg.DiagNormal(np.zeros(4), 1.0)
+    res = pkg.mcmc_keep_warmup(5, l, 0, chains=3, reporter=pkg.NoProgressReport())
+    sl, ws = res["sampling_logdensity"], res["final_warmup_state"]
+    a = pkg.mcmc_steps(sl, ws)
+    qa, _ = pkg.mcmc_next_step(a, ws.Q)                 # A remembers qa
+    b = pkg.mcmc_steps(sl)
+    for _ in range(3):
+        pkg.mcmc_next_step(b)                           # B moves the chains elsewhere
+    assert not np.array_equal(sl.ctx.position()[0], qa.q)
+    before = sl.ctx.position_epoch
+    pkg.mcmc_next_step(a, qa)                           # from qa again: the context must be put back there first
+    assert sl.ctx.position_epoch >= before + 2          # set_position + run, not run alone
+
+
 def test_200dim_never_reaches_depth_12(pkg):
     """test_mcmc.jl:60-72 (issue #115): 200-dim standard normal, max_depth = 12, 20×1000 draws."""
     r = pkg.mcmc_with_warmup(4, pkg.StandardNormal(200), 1000, chains=20, algorithm=pkg.NUTS(max_depth=12),

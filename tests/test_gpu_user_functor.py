@@ -82,11 +82,13 @@ def test_diagnostics_probes_of_a_user_functor_equal_the_builtin_family(pkg):
     assert np.array_equal(ra, rb)
 
 
-@pytest.mark.parametrize("D,C", [(40, 6), (200, 160), (1000, 136)])
+@pytest.mark.parametrize("D,C", [(40, 6), (200, 160), (1000, 136), (520, 256)])
 def test_user_functor_with_the_dense_metric_is_bit_equal_to_the_builtin_family(pkg, D, C):
     """DHMC_METRIC_DENSE for the caller's functor: 6 chains run the wave-per-chain dense kernels, 136+ the GEMM round engine
     (K0 / K2 / K3 compiled around the functor; at D = 1000 the workgroup-per-chain K3b with the fused position update) — the same
-    kernels as the built-in family's, so the same bits; the small case also against the oracle."""
+    kernels as the built-in family's, so the same bits; the small case also against the oracle.  256 chains (an even count from
+    256 up) run as two half-batches on two streams: every launch must cover its own half only (round 3 launched the functor's
+    kernels over all chains of the context for each half)."""
     rng = np.random.default_rng(D)
     mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
     A = rng.normal(size=(D, D)) / np.sqrt(D)
