@@ -17,6 +17,12 @@ roofline: the chain state is register/LDS-resident, so the bound that applies is
 unit (≈30·D useful flops per leapfrog against 78.6 TFLOP/s); the 48·D-byte streaming
 model and the measured HBM traffic are kept as secondary keys inside `roofline`.
 
+After the headline's timed region and the CPU baseline, the default single-GPU run also takes short measurements of
+BASELINE.json configs[2..4] (dense metric / funnel share / logistic share: `other_configs` in the same JSON line, so that they
+are under the driver's clock too; --no-other-configs skips them) and, when rocprofv3 is on PATH, measures the per-draw kernel's
+HBM traffic afresh in two counter passes of a small probe run (`roofline.traffic`, `traffic_source: "live"`; --traffic profile
+falls back to the committed profiles/*traffic.json and names the commit it was taken at).
+
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -50,13 +56,71 @@ def _run(ctx, n, arrays, **kw):
 
 def measured_traffic_per_leapfrog():
     """HBM bytes per leapfrog from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, separate runs; tools/profile.sh -> profiles/*traffic.json), or None."""
+    WRITE_SIZE, separate runs; tools/profile.sh -> profiles/*traffic.json), with the commit the file was
+    last touched at (a kernel changed since then makes the figure stale), or None."""
     import glob
+    import subprocess
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
     if not files:
         return None, None
     with open(files[-1]) as fh:
-        return json.load(fh).get("hbm_bytes_per_leapfrog"), os.path.basename(files[-1])
+        val = json.load(fh).get("hbm_bytes_per_leapfrog")
+    src = os.path.basename(files[-1])
+    try:
+        c = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", files[-1]], capture_output=True, text=True, timeout=10).stdout.strip()
+        if c:
+            src += f" (committed {c})"
+    except Exception:
+        pass
+    return val, src
+
+
+def live_traffic_per_leapfrog(seed):
+    """HBM bytes per leapfrog of the per-draw kernel measured NOW: two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass; counters only — no trace domains beside them) over a small probe run of this file
+    (--traffic-probe: the same workload with the short setup and one 100-transition step), summed over its nuts_run_kernel
+    dispatches and divided by the leapfrogs the probe reports.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+    gfx950.  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tot, leapfrogs = {}, None
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-probe", "--seed", str(seed)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=env)
+            except Exception as e:      # noqa
+                return None, f"rocprofv3 pass failed: {e!r}"
+            try:
+                leapfrogs = json.loads(r.stdout.strip().splitlines()[-1])["probe_leapfrogs"]
+            except Exception:
+                return None, "probe run printed no leapfrog count: " + (r.stderr or r.stdout)[-200:]
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "nuts_run_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            tot[counter] = tot.get(counter, 0.0) + float(row["Counter_Value"])
+    if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot or not leapfrogs:
+        return None, "counter rows missing"
+    return (tot["FETCH_SIZE"] * 1024 * 2 + tot["WRITE_SIZE"] * 1024) / leapfrogs, "live"
+
+
+def traffic_probe(pkg, torch, seed):
+    """The run the counter passes wrap: short adaptive setup, then one step of 100 transitions; prints the leapfrogs of ALL its
+    dhmc_run calls (the counters are summed over all dispatches of the kernel too)."""
+    ctx, _ = setup_context(pkg, torch, 0, CHAINS_PER_GPU, seed, True)
+    out = {"draws": torch.empty((CHAINS_PER_GPU, 100, D), dtype=torch.float64, device="cuda")}
+    _run(ctx, 100, out)
+    torch.cuda.synchronize()
+    print(json.dumps({"probe_leapfrogs": ALL_RUN_LEAPFROGS[0]}))
 
 
 def setup_context(pkg, torch, rank, chains, seed, short):
@@ -163,7 +227,7 @@ def bench_config3(args, pkg, torch):
     peak = 78.6                                           # MI355X fp64 matrix peak, TFLOP/s
     ach = flops / (sum(kms) * 1e-3) / 1e12
     q = out["draws"]
-    print(json.dumps({
+    return ({
         "metric": "leapfrog-steps/sec (all chains), 1000-dim correlated MVN, dense M^-1, @4096 chains",
         "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -180,7 +244,7 @@ def bench_config3(args, pkg, torch):
                      "note": f"flops of the {nprod} M^-1 contraction(s) per leapfrog round (2·Dpad² each; one-product recurrence: "
                              "include/dhmc.h dhmc_set_dense_products) / total kernel time of the rounds "
                              "(tree-logic kernels included); the GEMM launches alone reach ~50 TFLOP/s (profiles/)",
-                     "rounds": rounds}}))
+                     "rounds": rounds}})
 
 
 def bench_config45(args, pkg, torch):
@@ -230,13 +294,35 @@ def bench_config45(args, pkg, torch):
         ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                 "kernel": "nuts_run_kernel<FunnelT,1>", "note": "48·D algorithmic bytes per leapfrog; a 30-dim chain is latency-, not bandwidth-bound"}
-    print(json.dumps({
+    return ({
         "metric": "leapfrog-steps/sec (all chains)", "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "config": {"workload": name, "transitions_per_step": T, "chains_per_gpu": C},
         "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
                  "mean_acceptance": float(out["acceptance_rate"].mean())},
-        "roofline": roof}))
+        "roofline": roof})
+
+
+def other_configs(args, pkg, torch):
+    """Short measurements of BASELINE.json configs[2], [3] (one GPU's share) and [4] (one GPU's share) for the default line:
+    the same code paths as --config 3 / 4 / 5, two timed steps of 20 transitions after one warm-up step each."""
+    import copy
+    res = {}
+    for cfg, key, fn in ((3, "c3", bench_config3), (4, "c4", bench_config45), (5, "c5", bench_config45)):
+        a = copy.copy(args)
+        a.config, a.transitions, a.steps, a.warmup, a.chains = cfg, 20, 2, 1, CHAINS_PER_GPU
+        t0 = time.perf_counter()
+        try:
+            line = fn(a, pkg, torch)
+            res[key] = {"workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                        "steps": line["steps"], "transitions_per_step": 20, "tree": line["tree"], "roofline": line["roofline"],
+                        "seconds_with_setup": None}
+        except Exception as e:      # noqa: the headline line is what must come out
+            res[key] = {"error": repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        res[key]["seconds_with_setup"] = time.perf_counter() - t0
+    return res
 
 
 def spawn_ranks(n):
@@ -268,6 +354,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-transitions", type=int, default=150)
     ap.add_argument("--seed", type=int, default=0x23EF614D)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2..4] measurements attached to the default line")
+    ap.add_argument("--traffic", choices=["live", "profile", "none"], default="live",
+                    help="roofline.traffic: measured now with rocprofv3 counter passes (default, single GPU), from profiles/*traffic.json, or left out")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
@@ -312,12 +402,14 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    if args.traffic_probe:
+        return traffic_probe(pkg, torch, args.seed)
     if args.transitions is None:
         args.transitions = 1000 if args.config == 2 else 20
     if args.config == 3:
-        return bench_config3(args, pkg, torch)
+        return print(json.dumps(bench_config3(args, pkg, torch)))
     if args.config in (4, 5):
-        return bench_config45(args, pkg, torch)
+        return print(json.dumps(bench_config45(args, pkg, torch)))
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
     ctx, warm = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
     out = {
@@ -383,7 +475,15 @@ def main():
         achieved = per_launch * ALGO_BYTES_PER_LEAPFROG / (k_ms * 1e-3) / 1e9
         valu_ach = per_launch * ALGO_FLOPS_PER_LEAPFROG / (k_ms * 1e-3) / 1e12
         kernel_name = "nuts_run_kernel<StdNormalT,16,true>"
-        tpl, tsrc = measured_traffic_per_leapfrog()
+        tpl, tsrc = None, None
+        if args.traffic == "live" and dist is None:
+            tpl, tsrc = live_traffic_per_leapfrog(args.seed)
+            if tpl is None:
+                why = tsrc
+                tpl, tsrc = measured_traffic_per_leapfrog()
+                tsrc = f"{tsrc}; live measurement unavailable ({why})"
+        elif args.traffic != "none":
+            tpl, tsrc = measured_traffic_per_leapfrog()
         line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, 1000-dim MVN @4096 chains",
             "value": total_leapfrogs / t_max,
@@ -421,6 +521,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_transitions, os.cpu_count() or 1)
+        if dist is None and not args.no_other_configs:
+            del out, q, ctx
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(args, pkg, torch)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

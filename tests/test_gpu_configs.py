@@ -257,3 +257,26 @@ def test_bench_collectives_run_over_rccl():
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl"
     assert d["value"] > 1e7
+
+
+def test_bench_default_line_carries_the_other_configs_and_a_live_traffic_figure():
+    """the default single-GPU invocation puts configs 3 / 4 / 5 under the same clock as the headline
+    (`other_configs` in the one JSON line) and measures roofline.traffic afresh (two rocprofv3 counter passes of a probe run) instead
+    of quoting a committed profile.  Short sizes here; the line's shape is what is checked."""
+    import json, os, shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--transitions", "50", "--short-warmup",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1e7
+    oc = d["other_configs"]
+    assert set(oc) == {"c3", "c4", "c5"}
+    for k, floor in (("c3", 1e6), ("c4", 1e7), ("c5", 1e4)):
+        assert "error" not in oc[k], oc[k]
+        assert oc[k]["value"] > floor and oc[k]["steps"] == 2 and 0 < oc[k]["roofline"]["frac"] < 1.5
+    if shutil.which("rocprofv3"):
+        assert d["roofline"]["traffic_source"] == "live", d["roofline"]["traffic_source"]
+        per_leapfrog = d["roofline"]["traffic"] / d["roofline"]["leapfrogs_per_launch"]
+        assert 2e3 < per_leapfrog < 1e5                 # ≈ 11 KB per leapfrog in rounds 1-3

@@ -3,7 +3,7 @@
 # Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2..4: PMC counters, each in its own run
 # (never combined with other trace domains; FETCH_SIZE and WRITE_SIZE cannot share a pass).
 TAG=${1:-r01}; shift
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --transitions 100 $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --traffic none --transitions 100 $@"
 KEEP=$PWD/gpurun_out/prof_$TAG
 OUT=/tmp/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $KEEP
