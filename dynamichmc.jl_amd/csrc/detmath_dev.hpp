@@ -94,6 +94,26 @@ __device__ __forceinline__ double det_exp_u(double x) { return det_exp_t<dm_u>(x
 __device__ __forceinline__ double det_log_u(double x) { return det_log_t<dm_u>(x); }
 __device__ __forceinline__ double det_logaddexp_u(double x, double y) { return det_logaddexp_t<dm_u>(x, y); }
 __device__ __forceinline__ double det_pow_pos_u(double x, double y) { return det_pow_pos_t<dm_u>(x, y); }
+// The two logaddexp's of a tree merge (visited statistic and ω) together: when both |x - y| < 16 — the common case — the two
+// softplus cells are requested back to back and the two Horner chains run interleaved (one basic block); each value is
+// computed by exactly the operations of det_logaddexp_t, so the bits are those of two separate calls.
+__device__ __forceinline__ void det_logaddexp_pair_u(double x1, double y1, double x2, double y2, double& r1, double& r2) {
+    const double d1 = __builtin_fabs(x1 - y1), d2 = __builtin_fabs(x2 - y2);
+    if (__builtin_expect((d1 < 16.0) & (d2 < 16.0), 1)) {
+        const int i1 = dm_u::idx((int)(d1 * 16.0)), i2 = dm_u::idx((int)(d2 * 16.0));
+        double c1[8], c2[8];
+        dm_u::row8(DM_SOFTPLUS_TBL[i1], c1);
+        dm_u::row8(DM_SOFTPLUS_TBL[i2], c2);
+        const double t1 = d1 - (double)(2 * i1 + 1) * 0.03125, t2 = d2 - (double)(2 * i2 + 1) * 0.03125;
+        const double m1 = dm_u::max_nonnan(x1, y1), m2 = dm_u::max_nonnan(x2, y2);
+        const double s1 = dm_u::template horner_row<8>(t1, c1), s2 = dm_u::template horner_row<8>(t2, c2);
+        r1 = m1 + s1;
+        r2 = m2 + s2;
+    } else {
+        r1 = det_logaddexp_t<dm_u>(x1, y1);
+        r2 = det_logaddexp_t<dm_u>(x2, y2);
+    }
+}
 // per-lane arguments
 __device__ __forceinline__ double det_exp_v(double x) { return det_exp_t<dm_v>(x); }
 __device__ __forceinline__ double det_log_v(double x) { return det_log_t<dm_v>(x); }

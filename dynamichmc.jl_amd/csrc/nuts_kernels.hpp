@@ -268,8 +268,10 @@ __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
 // lanes — was 177.
 __device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, double b2, int,
                                                double& r1, double& r2) {
-    r1 = uni_f64(det_logaddexp_u(a1, b1));
-    r2 = uni_f64(det_logaddexp_u(a2, b2));
+    double v1, v2;
+    det_logaddexp_pair_u(a1, b1, a2, b2, v1, v2);
+    r1 = uni_f64(v1);
+    r2 = uni_f64(v2);
 }
 
 // p = W .* randn (hamiltonian.jl:124) from the chain's stream.  The Box–Muller pairs are taken in batches of four: Philox and the

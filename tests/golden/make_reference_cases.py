@@ -1,5 +1,6 @@
 """Extracts the NUMERIC test inputs (μ, d, C / Σ literals) of the reference's statistical tests
-(/root/reference/test/sample-correctness_tests.jl:27-87) into tests/golden/reference_mvn_cases.json.
+(/root/reference/test/sample-correctness_tests.jl:27-98) into tests/golden/reference_mvn_cases.json and
+reference_mixture_case.json.
 Only data is kept — each case becomes {name, mu, L} with x = μ + L z, z ~ N(0, I) (the reference's
 multivariate_normal(μ, L), test/utilities.jl:64-67); no source text is copied.  Run in the build container
 (the reference is not present on the GPU box)."""
@@ -46,6 +47,18 @@ def main():
         cases.append(dict(name=f"kept {len(mu)} dim", mu=mu.tolist(), L=np.linalg.cholesky(S).tolist(), metric="Diagonal"))
     with open(os.path.join(HERE, "reference_mvn_cases.json"), "w") as fh:
         json.dump(cases, fh, indent=0)
+    # --- mixture of two normals (:89-98): α, the second component's mean and L = D2 * C2, and the alert levels of the call ----
+    sec = src[src.index('@testset "NUTS tests with mixtures"'):src.index('@testset "NUTS tests with heavier tails and skewness"')]
+    C2 = parse_matrix(re.search(r"C2 = \[([^\]]+)\]", sec).group(1))
+    d2 = float(re.search(r"D2 = I \* ([0-9.]+)", sec).group(1))
+    alpha = float(re.search(r"mix\(([0-9.]+),", sec).group(1))
+    tau_alert = float(re.search(r"τ_alert = ([0-9.]+)", sec).group(1))
+    p_alert = float(re.search(r"p_alert = ([0-9.]+)", sec).group(1))
+    mix = dict(name="mixture of two normals", alpha=alpha, mu1=[0.0] * 3, L1=np.eye(3).tolist(), mu2=[1.0] * 3, L2=(d2 * C2).tolist(),
+               tau_alert=tau_alert, p_alert=p_alert, N=1000)
+    with open(os.path.join(HERE, "reference_mixture_case.json"), "w") as fh:
+        json.dump(mix, fh, indent=0)
+    print(mix["name"], "alpha", alpha, "tau_alert", tau_alert, "p_alert", p_alert)
     for c in cases:
         print(c["name"], len(c["mu"]))
 

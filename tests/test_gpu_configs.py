@@ -280,3 +280,88 @@ def test_bench_default_line_carries_the_other_configs_and_a_live_traffic_figure(
         assert d["roofline"]["traffic_source"] == "live", d["roofline"]["traffic_source"]
         per_leapfrog = d["roofline"]["traffic"] / d["roofline"]["leapfrogs_per_launch"]
         assert 2e3 < per_leapfrog < 1e5                 # ≈ 11 KB per leapfrog in rounds 1-3
+
+
+def _tree_properties(out):
+    """Size-independent invariants of every transition (trees.jl:283-319, NUTS.jl:59-89): a tree of depth d visited between
+    2^d - 1 and 2^(d+1) - 1 leaves; a trajectory that ended by turning at the top level spans exactly its 2^d - 1 new points;
+    acceptance rates are probabilities; π = ℓ - K <= ℓ."""
+    steps, depth = out["steps"], out["depth"].long()
+    assert (steps >= 1).all() and (steps <= 2 ** (depth + 1) - 1).all() and (steps >= 2 ** depth - 1).all()
+    l, r = out["term_left"], out["term_right"]
+    top_turn = (l <= 0) & (r >= 0) & (l < r)
+    assert (steps[top_turn] == (2 ** depth[top_turn] - 1)).all()
+    assert (r[top_turn] - l[top_turn] == steps[top_turn]).all()
+    a = out["acceptance_rate"]
+    assert (a >= 0).all() and (a <= 1).all()
+    assert (out["pi"] <= out["logdensities"]).all()
+
+
+def test_config3_full_size_properties(pkg):
+    """BASELINE.json configs[2] at FULL size — D = 1000 correlated normal, dense M⁻¹ = Σ, 4096 chains through the two-stream GEMM
+    round engine: the stored log density is ℓ of the stored draw (tridiagonal precision, recomputed in torch), the tree
+    invariants hold for every transition, the whitened draws have unit variance, and chains 2048..2051 — the first chains of the
+    SECOND half-batch — equal a 4-chain oracle at that chain offset bit for bit."""
+    import torch
+    D, C, N = 1000, 4096, 12
+    params, Sigma = _config3_problem(D)
+    sig = np.sqrt(np.diag(Sigma))
+    dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=77)
+    q0 = np.random.default_rng(6).normal(size=(C, D)) * sig
+    dev.set_metric_dense(Sigma); dev.init(q0); dev.find_initial_stepsize()
+    eps0 = dev.stepsize()
+    dev.run(6, da={}, fields=[])
+    out = {k: torch.empty((C, N, D) if k == "draws" else (C, N), dtype=dt, device="cuda")
+           for k, dt in (("draws", torch.float64), ("logdensities", torch.float64), ("pi", torch.float64), ("acceptance_rate", torch.float64),
+                         ("steps", torch.int64), ("depth", torch.int32), ("term_left", torch.int64), ("term_right", torch.int64))}
+    dev.run_into(N, out)
+    assert dev.last_run_rounds() > 0
+    q = out["draws"]
+    diag = torch.tensor(params[:D], device="cuda"); off = torch.tensor(params[D:2 * D - 1], device="cuda")
+    quad = (diag * q * q).sum(-1) + 2 * (off * q[..., :-1] * q[..., 1:]).sum(-1)
+    assert torch.allclose(out["logdensities"], -0.5 * quad, rtol=1e-11, atol=1e-8)
+    _tree_properties(out)
+    assert 0.6 < float(out["acceptance_rate"].mean()) < 0.97
+    w = q / torch.tensor(sig, device="cuda")
+    assert abs(float(w.var()) - 1) < 0.02 and abs(float(w.mean())) < 5e-3
+    off0 = 2048
+    ora = ol.Oracle(D, 4, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=77, chain_offset=off0, threads=4)
+    ora.set_metric_dense(Sigma); ora.init(q0[off0:off0 + 4]); ora.find_initial_stepsize()
+    assert np.array_equal(eps0[off0:off0 + 4], ora.stepsize())
+    ora.run(6, da={}, fields=[])
+    b = ora.run(N, fields=["draws", "steps", "acceptance_rate"])
+    assert np.array_equal(b["draws"], q[off0:off0 + 4].cpu().numpy())
+    assert np.array_equal(b["steps"], out["steps"][off0:off0 + 4].cpu().numpy())
+    assert np.array_equal(b["acceptance_rate"], out["acceptance_rate"][off0:off0 + 4].cpu().numpy())
+
+
+def test_config5_full_size_properties(pkg):
+    """BASELINE.json configs[4], one GPU's share at FULL size — N = 10⁵ observations, p = 256, 1024 chains through the
+    GEMM-gradient round engine: the stored log density is ℓ of the stored draw (recomputed in torch as one fp64 matmul), the tree
+    invariants hold, the position the context ends on is the last draw, and its gradient is Xᵀ(y - σ(Xβ)) - β."""
+    import torch
+    rng = np.random.default_rng(0)
+    Nobs, D, C, N = 100000, 256, 1024, 3
+    X = rng.normal(size=(Nobs, D)) / 16
+    y = (rng.random(Nobs) < 1 / (1 + np.exp(-X @ rng.normal(size=D)))).astype(float)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_LOGISTIC, target_params=ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y), seed=5)
+    dev.init(); dev.set_stepsize(0.02)
+    dev.run(3, da={}, fields=[])
+    out = {k: torch.empty((C, N, D) if k == "draws" else (C, N), dtype=dt, device="cuda")
+           for k, dt in (("draws", torch.float64), ("logdensities", torch.float64), ("pi", torch.float64), ("acceptance_rate", torch.float64),
+                         ("steps", torch.int64), ("depth", torch.int32), ("term_left", torch.int64), ("term_right", torch.int64))}
+    dev.run_into(N, out)
+    assert dev.last_run_rounds() > 0
+    Xt = torch.tensor(X, device="cuda"); yt = torch.tensor(y, device="cuda")
+    q = out["draws"].reshape(-1, D)
+    eta = q @ Xt.T
+    lq = (yt * eta - torch.nn.functional.softplus(eta)).sum(1) - 0.5 * (q * q).sum(1)
+    assert torch.allclose(out["logdensities"].reshape(-1), lq, rtol=1e-11)
+    _tree_properties(out)
+    assert (out["steps"] >= 3).all()
+    qf, lqf, gf = dev.position()
+    assert np.array_equal(qf, out["draws"][:, -1].cpu().numpy()) and np.array_equal(lqf, out["logdensities"][:, -1].cpu().numpy())
+    ql = out["draws"][:, -1]
+    el = ql @ Xt.T
+    g = (yt - torch.sigmoid(el)) @ Xt - ql
+    assert np.allclose(gf, g.cpu().numpy(), rtol=1e-9, atol=1e-9)

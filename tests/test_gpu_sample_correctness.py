@@ -82,6 +82,44 @@ def test_reference_literal_cases(pkg, case):
     nuts_tests(pkg, l, samp, 1000, seed=100 + len(mu), warmup_stages=stages)
 
 
+def test_reference_mixture_of_two_normals_through_a_device_functor(pkg):
+    """sample-correctness_tests.jl:89-98: mix(0.2, N(0, I₃), N(1, (0.4 C₂)(0.4 C₂)ᵀ)), 1000 draws × 5 chains, with the call's own
+    alert levels (τ_alert = 0.15 → τ_fail = 0.075, p_alert = 0.005 → p_fail = 0.0005; R̂ ≤ 1.02, E-BFMI ≥ 0.25 by default).  Not a
+    built-in family: the log-sum-exp of the two components is a caller's device functor (tests/user_functors.py MIXTURE3),
+    compiled into the per-draw kernels — the reference's LogDensityTestSuite.mix on the device.  Literals:
+    tests/golden/reference_mixture_case.json (make_reference_cases.py)."""
+    import json, os
+    import user_functors as uf
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_mixture_case.json")) as fh:
+        c = json.load(fh)
+    a = c["alpha"]; mu2 = np.array(c["mu2"]); L2 = np.array(c["L2"])
+    S2 = L2 @ L2.T
+    P2 = np.linalg.inv(S2); P2 = (P2 + P2.T) / 2
+    params = np.concatenate([[a, -np.log(abs(np.linalg.det(L2)))], mu2, P2.ravel()])
+    l = pkg.DeviceFunctorLogDensity(3, uf.MIXTURE3, "Mixture3", params=params)
+
+    def exact(n):
+        first = RNG.random(n) < a
+        z = RNG.normal(size=(n, 3))
+        return np.where(first[:, None], z, mu2 + z @ L2.T)
+    r = nuts_tests(pkg, l, exact, c["N"], seed=41, tau_fail=c["tau_alert"] * 0.5, p_fail=c["p_alert"] * 0.1)
+    x = r["posterior_matrix"].reshape(-1, 3)
+    mean = (1 - a) * mu2
+    assert np.abs(x.mean(0) - mean).max() < 0.1                 # E x = (1 - α) μ₂
+    # the density itself at a few points, against numpy (the functor's ℓ up to the shared -3/2 log 2π)
+    ctx = pkg.DeviceContext(3, 4, target=l.family, target_params=l.params(), seed=2)
+    q0 = RNG.normal(size=(4, 3)) * 1.5 + 0.5
+    ctx.init(q0)
+    q, lq, g = ctx.position()
+    n1 = np.log(a) - 0.5 * (q0 ** 2).sum(1)
+    d = q0 - mu2
+    n2 = np.log(1 - a) - np.log(abs(np.linalg.det(L2))) - 0.5 * np.einsum("ci,ij,cj->c", d, P2, d)
+    want = np.logaddexp(n1, n2)
+    assert np.allclose(lq, want, rtol=1e-13, atol=1e-13)
+    w1 = np.exp(n1 - want)[:, None]
+    assert np.allclose(g, -w1 * q0 - (1 - w1) * (d @ P2), rtol=1e-12, atol=1e-12)
+
+
 def test_dense_normal_target_parity(pkg):
     """The dense-precision target itself: HIP == oracle, bit for bit."""
     K = 7

@@ -25,6 +25,15 @@ def test_user_functors_compile_into_the_dense_metric_kernels(pkg, dim):
     assert ok, log
 
 
+def test_the_references_mixture_case_compiles_as_a_functor(pkg):
+    """mix(0.2, N(0, I₃), N(1, L₂L₂ᵀ)) of test/sample-correctness_tests.jl:89-98 as a device functor (log-sum-exp of two quadratic
+    forms with the ABI's scalar math); the run and the reference's bars: tests/test_gpu_sample_correctness.py."""
+    ok, log = pkg.DeviceFunctorLogDensity.check(3, uf.MIXTURE3, "Mixture3")
+    assert ok, log
+    ok, log = pkg.DeviceFunctorLogDensity.check(3, uf.MIXTURE3, "Mixture3", metric=pkg.abi.METRIC_DENSE)
+    assert ok, log
+
+
 def test_compile_errors_come_back_with_the_log(pkg):
     ok, log = pkg.DeviceFunctorLogDensity.check(10, uf.BROKEN, "Broken")
     assert not ok

@@ -82,3 +82,49 @@ struct Broken {
 };
 }
 """
+
+
+# The reference's "mixture of two normals" (test/sample-correctness_tests.jl:89-98): ℓ = log(α N(q; 0, I) + (1-α) N(q; μ₂, L₂L₂ᵀ)) in
+# three dimensions, as LogDensityTestSuite's mix(α, ℓ₁, ℓ₂) of two NORMALISED densities.  Parameters: [α, c₂ = -log|det L₂|,
+# μ₂ (3), P₂ = (L₂L₂ᵀ)⁻¹ row-major (9)].  Every lane computes the two quadratic forms from the three coordinates (lanes 0..2
+# of slot 0); the scalar math is the ABI's (logaddexp, exp, log of dhmc_detmath.h).
+MIXTURE3 = r"""
+namespace dhmc {
+struct Mixture3 {
+    static constexpr bool kDeferred = false;                 // eval returns ℓ itself
+    static constexpr bool kElementwise = false;
+    static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kBigDims = false;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = true;
+    double la1, la2, c2, mu[3], P[9];
+    __device__ explicit Mixture3(const TargetParams& p) {
+        la1 = det_log(p.a[0]); la2 = det_log(1.0 - p.a[0]); c2 = p.a[1];
+        for (int i = 0; i < 3; ++i) mu[i] = p.a[2 + i];
+        for (int i = 0; i < 9; ++i) P[i] = p.a[5 + i];
+    }
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        double x[3], d[3], Pd[3];
+        for (int i = 0; i < 3; ++i) { x[i] = readlane_f64(q[0], i); d[i] = x[i] - mu[i]; }
+        double q1 = 0.0, q2 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            Pd[i] = P[3 * i] * d[0] + P[3 * i + 1] * d[1] + P[3 * i + 2] * d[2];
+            q1 += x[i] * x[i];
+            q2 += d[i] * Pd[i];
+        }
+        const double l1 = la1 - 0.5 * q1, l2 = (la2 + c2) - 0.5 * q2;
+        const double l = det_logaddexp(l1, l2);
+        const double w1 = det_exp(l1 - l), w2 = det_exp(l2 - l);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] = 0.0;
+        double gl = 0.0;
+        for (int i = 0; i < 3; ++i) gl = (lane == i) ? -(w1 * x[i]) - w2 * Pd[i] : gl;
+        g[0] = gl;
+        return l;
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+}
+"""
