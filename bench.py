@@ -358,6 +358,8 @@ def main():
     ap.add_argument("--traffic", choices=["live", "profile", "none"], default="live",
                     help="roofline.traffic: measured now with rocprofv3 counter passes (default, single GPU), from profiles/*traffic.json, or left out")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let several ranks share one physical GPU (collectives over gloo): a readiness run of the multi-process path, not a measurement of N GPUs")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
@@ -395,6 +397,15 @@ def main():
         idents = [None] * world
         dist.all_gather_object(idents, ident)
         if len(set(idents)) < world:
+            # fewer distinct devices than ranks: a line with n_gpus = N measured on fewer GPUs would be a lie about the hardware.
+            # Only a readiness run of the multi-process path on a small box asks for it explicitly.
+            if not args.allow_shared_gpu:
+                if rank == 0:
+                    print(f"bench.py: --gpus {world} but only {len(set(idents))} distinct device(s) among the ranks ({sorted(set(idents))}); "
+                          "refusing to print an n_gpus line for GPUs that are not there (--allow-shared-gpu runs the ranks on shared "
+                          "devices over gloo, for testing the multi-process path)", file=sys.stderr)
+                dist.destroy_process_group()
+                raise SystemExit(3)
             backend, coll_dev = "gloo", "cpu"
         else:
             backend = "nccl"
@@ -497,7 +508,7 @@ def main():
                        "dim": D, "chains_per_gpu": C, "transitions_per_step": T,
                        "phase": "sampling (fixed adapted eps and M^-1 per chain)", "max_depth": 10,
                        "parallelism": f"chains sharded x{world}, no data-path collective",
-                       "collective_backend": backend},
+                       "collective_backend": backend, "shared_gpu": bool(args.allow_shared_gpu and backend == "gloo")},
             "ess_per_sec": ess_rate,
             "ess_note": f"min rank-normalised split-chain bulk ESS (Vehtari et al. 2021; dhmc_ess_bulk) over 16 coordinates, "
                         f"the last {ess_T} draws x all chains of the last timed step, over that share of the step's time",

@@ -55,6 +55,7 @@ class TreeStatisticsSummaryABI(C.Structure):
 
 
 # int fn(void* user, const double* q, int64 chains, int64 ld, int64 dim, double* lq, double* grad, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 LOGDENSITY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
 
 OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np.float64),
@@ -72,7 +73,7 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
            "dhmc_set_logdensity_callback", "dhmc_ess_bulk", "dhmc_ess_tail", "dhmc_summarize_tree_statistics",
            "dhmc_set_dense_products", "dhmc_get_dense_products", "dhmc_host_alloc", "dhmc_host_free",
-           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log", "dhmc_detmath_selftest"]
+           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log", "dhmc_detmath_selftest", "dhmc_set_metric_allreduce"]
 
 _lib = None
 

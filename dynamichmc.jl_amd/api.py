@@ -669,13 +669,16 @@ def mcmc(slogd, N, warmup_state):
 
 
 def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False, per_chain_metric=False, _keep_warmup=True):
+                     reporter=None, device=0, on_device=False, per_chain_metric=False, metric_allreduce=None, _keep_warmup=True):
     """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU.  `on_device=True` returns the
     posterior matrices and statistics as torch CUDA tensors (no PCIe copy of the draws).
     `per_chain_metric` concerns Symmetric (dense) metrics only — a Diagonal κ is always per chain: False (default) adapts ONE
     M⁻¹ from the pooled draws of all chains, which is what lets the leapfrog's products run as one GEMM over the batch;
     True gives every chain its own M⁻¹ adapted from its own draws, exactly what C separate calls of the reference do
-    (mcmc.jl:281-284) — the wave-per-chain dense kernels, 2·C·D² doubles of HBM; κ.M⁻¹ then comes back as [C][D][D]."""
+    (mcmc.jl:281-284) — the wave-per-chain dense kernels, 2·C·D² doubles of HBM; κ.M⁻¹ then comes back as [C][D][D].
+    `metric_allreduce` (a job sharded over several GPUs, one process each, `rng.chain_offset` = the block's first chain): an
+    in-place SUM over the ranks (sharding.TorchAllReduce(torch.distributed)) — the shared Symmetric M⁻¹ is then adapted from the
+    draws of ALL ranks, so every rank samples with the matrix one GPU holding all chains would have adapted (to rounding)."""
     warmup_stages = default_warmup_stages() if warmup_stages is None else warmup_stages
     reporter = default_reporter() if reporter is None else reporter
     rng = _as_rng(rng)
@@ -690,6 +693,9 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
                         dense_per_chain=bool(per_chain_metric) and metric == abi.METRIC_DENSE)
     if l.family == abi.TARGET_EXTERNAL:
         ctx.set_logdensity_callback(l.callback())
+    if metric_allreduce is not None:
+        _argcheck(metric == abi.METRIC_DENSE and not per_chain_metric, "metric_allreduce pools a shared Symmetric metric")
+        ctx.set_metric_allreduce(metric_allreduce)
     slogd = SamplingLogDensity(rng, l, algorithm, reporter, ctx, on_device=on_device, keep_warmup=_keep_warmup)
     initial = initialize_warmup_state(slogd, **dict(initialization))
     wu, final = _warmup(slogd, warmup_stages, initial)
@@ -699,12 +705,12 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
 
 
 def mcmc_with_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False, per_chain_metric=False):
+                     reporter=None, device=0, on_device=False, per_chain_metric=False, metric_allreduce=None):
     """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C].
     The warmup stages' draws never leave the GPU (the reference discards them too, mcmc.jl:579-583)."""
     r = mcmc_keep_warmup(rng, l, N, chains=chains, initialization=initialization, warmup_stages=warmup_stages,
                          algorithm=algorithm, reporter=reporter, device=device, on_device=on_device,
-                         per_chain_metric=per_chain_metric, _keep_warmup=False)
+                         per_chain_metric=per_chain_metric, metric_allreduce=metric_allreduce, _keep_warmup=False)
     out = dict(r["inference"])
     out["kappa"] = r["final_warmup_state"].kappa
     out["eps"] = r["final_warmup_state"].eps

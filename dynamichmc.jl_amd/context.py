@@ -275,6 +275,33 @@ class DeviceContext:
         self._chk(abi.lib().dhmc_update_metric_dense(self.h, _ptr(draws), C.c_int64(draws.shape[1]), C.c_double(lam), int(_is_device(draws))),
                   "dhmc_update_metric_dense")
 
+    def set_metric_allreduce(self, allreduce):
+        """The shared dense metric adapted from the draws of ALL ranks (include/dhmc.h dhmc_set_metric_allreduce): `allreduce(t)`
+        adds the CUDA float64 tensor `t` over the ranks in place (sharding.TorchAllReduce wraps torch.distributed); None: back
+        to pooling over this context's chains only."""
+        if allreduce is None:
+            self._ar = None
+            return self._chk(abi.lib().dhmc_set_metric_allreduce(self.h, abi.ALLREDUCE_FN(0), None), "dhmc_set_metric_allreduce")
+        import torch
+
+        class _Dev:
+            def __init__(s, ptr, n):
+                s.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(int(ptr), False), version=2, strides=(8,))
+        dev = torch.device("cuda", self.cfg.device)
+        self._cb_error = None
+
+        def trampoline(user, ptr, count, stream):
+            try:
+                ctxm = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev))
+                with ctxm:
+                    allreduce(torch.as_tensor(_Dev(ptr, int(count)), device=dev))
+                return 0
+            except Exception as e:          # no exception may cross the C ABI
+                self._cb_error = e
+                return 1
+        self._ar = abi.ALLREDUCE_FN(trampoline)
+        return self._chk(abi.lib().dhmc_set_metric_allreduce(self.h, self._ar, None), "dhmc_set_metric_allreduce")
+
     # ---- DHMC_TARGET_EXTERNAL: the user's own batched log density --------------------------------
     def set_logdensity_callback(self, fn):
         """`fn(q) -> (lq, grad)` with q a CUDA torch tensor [C][D] (a view of the library's buffer: do not keep it),

@@ -250,6 +250,8 @@ struct dhmc_ctx {
     struct StageBuf { void* p = nullptr; size_t cap = 0; };
     StageBuf stage[2][10];
     hipStream_t copy_stream = nullptr;
+    dhmc_allreduce_fn metric_allreduce = nullptr;   // dhmc_set_metric_allreduce: the shared dense metric adapted from the draws of all ranks
+    void* metric_allreduce_user = nullptr;
     hipEvent_t ev_k0[2] = {}, ev_k1[2] = {}, ev_copy[2] = {};
     int* h_done = nullptr;     // page-locked [2][8]: the dense round engine's done-counters, read without draining the streams
     hipEvent_t ev_done[2] = {};
@@ -1694,9 +1696,31 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
         double* const mean = (double*)bmean.p;
         double* const S = (double*)bS.p;
         const double* x = (const double*)s.dev;
-        hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0);
-        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
-        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, J, lambda, S, (size_t)0);
+        double Jtot = (double)J;
+        if (!c->metric_allreduce) {
+            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0, 0);
+            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
+        } else {
+            // job-wide estimate (include/dhmc.h dhmc_set_metric_allreduce): column sums + row count over the ranks, then the
+            // scatter about the job's mean over the ranks; `mean` has Dpad >= D + 1 slots except when D is a multiple of 64
+            DevBuf bsum;
+            HIP_TRY(c, hipMalloc(&bsum.p, sizeof(double) * (size_t)(D + 1)));
+            double* const sums = (double*)bsum.p;
+            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, sums, (size_t)0, (size_t)0, 1);
+            HIP_TRY(c, hipMemcpyAsync(sums + D, &Jtot, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if (c->metric_allreduce(c->metric_allreduce_user, sums, (int64_t)D + 1, (void*)c->stream) != 0) {
+                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (column sums)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
+            }
+            HIP_TRY(c, hipMemcpyAsync(&Jtot, sums + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            hipLaunchKernelGGL(pooled_mean_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, sums);
+            HIP_TRY(c, hipMemcpyAsync(mean, sums, sizeof(double) * (size_t)D, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
+            if (c->metric_allreduce(c->metric_allreduce_user, S, (int64_t)ld * ld, (void*)c->stream) != 0) {
+                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (scatter matrix)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));       // Jtot is on the host now
+            if (!(Jtot >= 2.0)) { stage_free(c, &s); return DHMC_ERR_INVALID_ARGUMENT; }
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }
         else rc = device_dense_metric(c, S, ld, -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
@@ -1722,7 +1746,7 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
             const unsigned Bz = (unsigned)B;
             const double* x = (const double*)s.dev + (size_t)k0 * J * D;
             HIP_TRY(c, hipMemsetAsync(flags, 0, sizeof(int) * 2 * (size_t)B, c->stream));
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256, 1, Bz), dim3(256), 0, c->stream, D, J, x, mean, (size_t)J * D, (size_t)ld);
+            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256, 1, Bz), dim3(256), 0, c->stream, D, J, x, mean, (size_t)J * D, (size_t)ld, 0);
             hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64, Bz), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)J * D, (size_t)ld, n);
             hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256), 1, Bz), dim3(256), 0, c->stream, D, ld, J, lambda, S, n);
             hipLaunchKernelGGL(df_symmetrize_kernel, dim3((unsigned)((n + 255) / 256), 1, Bz), dim3(256), 0, c->stream, (const double*)S, ld, D, Ssym, ld,
@@ -1746,6 +1770,13 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
         return DHMC_ERR_INVALID_ARGUMENT;
     }
     return rc;
+}
+
+int dhmc_set_metric_allreduce(dhmc_ctx* c, dhmc_allreduce_fn fn, void* user) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || c->per_chain_dense) return DHMC_ERR_INVALID_ARGUMENT;   // a shared dense metric is what is pooled
+    c->metric_allreduce = fn;
+    c->metric_allreduce_user = fn ? user : nullptr;
+    return DHMC_OK;
 }
 
 // ---- resume blob: header + raw images of the per-chain arrays -------------------------------

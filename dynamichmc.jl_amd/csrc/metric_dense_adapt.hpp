@@ -11,7 +11,9 @@
 namespace dhmc {
 
 // (blockIdx.z: batch element — one chain of a per-chain dense context — at strides x_bs / mean_bs / out_bs doubles)
-__global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ X, double* __restrict__ mean, size_t x_bs = 0, size_t mean_bs = 0) {
+// (sums_only: leave Σ_j x_ji in `mean` — the cross-rank estimate adds the ranks' sums before dividing by the job's row count)
+__global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ X, double* __restrict__ mean, size_t x_bs = 0, size_t mean_bs = 0,
+                                   int sums_only = 0) {
     X += blockIdx.z * x_bs; mean += blockIdx.z * mean_bs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
@@ -25,7 +27,12 @@ __global__ void pooled_mean_kernel(int D, int64_t J, const double* __restrict__ 
         for (int u = 0; u < 8; ++u) s = s + x[u];
     }
     for (; j < J; ++j) s = s + X[(size_t)j * D + i];
-    mean[i] = s / (double)J;
+    mean[i] = sums_only ? s : s / (double)J;
+}
+// the job-wide mean from the all-reduced sums: buf[0..D) = Σ over ranks of the column sums, buf[D] = Σ over ranks of the row counts
+__global__ void pooled_mean_finish_kernel(int D, double* __restrict__ buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) buf[i] = buf[i] / buf[D];
 }
 
 // OUT[i][k] (ld = ldo, i,k < Dpad) = Σ_j (X[j][i]-mean[i])·(X[j][k]-mean[k]); X is [J][D] unpadded; columns >= D give 0.

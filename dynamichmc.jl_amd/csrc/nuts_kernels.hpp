@@ -146,7 +146,7 @@ __device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool gra
 template <class T, int NPL, class MK>
 __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, int D,
                                                 double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
-                                                double eps, double& lq_out, double& pi_out, bool& pos_finite) {
+                                                double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl = 64) {
     const double h = eps / 2;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -169,12 +169,12 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
     double lq, K;
     if constexpr (T::kDeferred) {
         double r[2] = {lres, kacc.fold(0)};
-        wave_allreduce<2>(r);
+        wave_allreduce<2>(r, nl);
         lq = tgt.finish(r[0]);
         K = r[1] / 2.0;
     } else {
         lq = lres;
-        K = wave_allreduce1(kacc.fold(0)) / 2.0;
+        K = wave_allreduce1(kacc.fold(0), nl) / 2.0;
     }
     // evaluate_ℓ's checks (hamiltonian.jl:203-211).  Every shipped family has "ℓq finite =>
     // all q finite" (kFiniteLqImpliesFiniteQ), so the coordinate scan runs only on the rare
@@ -208,7 +208,7 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
 // On return cf = nf, cr = ρ of the merge.  Returns turning.
 template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, class NF, class MK>
 __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_, MK mk_,
-                                           double (&cf)[NPL], double (&cr)[NPL]) {
+                                           double (&cf)[NPL], double (&cr)[NPL], int nl = 64) {
     LaneAcc<6, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -234,7 +234,7 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
     }
     double acc[6];
     A.fold_all(acc);
-    wave_allreduce<6>(acc);
+    wave_allreduce<6>(acc, nl);
     return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
 }
 
@@ -245,7 +245,7 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
 // result is bit-identical to merge_core.  Half of all merges of a tree are of this kind.
 template <int NPL, class PA, class MK>
 __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
-                                                double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL]) {
+                                                double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL], int nl = 64) {
     LaneAcc<2, NPL> A;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -259,7 +259,7 @@ __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
     }
     double acc[2];
     A.fold_all(acc);
-    wave_allreduce<2>(acc);
+    wave_allreduce<2>(acc, nl);
     return acc[0] < 0 || acc[1] < 0;
 }
 
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     const int max_depth = P.max_depth;
     const int nslots = ws_nslots(max_depth);
+    const int nl = uni_i32(reduce_lanes(NPL, D));          // lanes that can hold nonzero partial sums (wave.hpp wave_allreduce)
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
     double tpm[TPL ? 1 : NPL], tpp[TPL ? 1 : NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             LaneAcc<1, NPL> kacc;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], mk(k) * p[k]);
-            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0)) / 2.0));
+            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0), nl) / 2.0));
         }
         // leaf τ of z₀ (NUTS.jl:120-123)
         if constexpr (TPL) {
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
                 PH(3)   // leaf
-                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite);
+                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl);
                 PH(4)   // leaf scalars
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
@@ -562,13 +563,13 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         PH(5)   // merge, vector part
                         if (sub) {
                             if (level == 0) {
-                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p);
+                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p, nl);
                             } else if (L1LDS && level == 1) {
                                 auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             } else if (NXL > 0 && level < 2 + NXL) {
                                 const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
                                 const double* Ll = Lf + Dpad;
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             } else {
                                 const double* Lf = wsv(ws_stack(level, 0));
                                 const double* Ll = wsv(ws_stack(level, 1));
@@ -585,8 +586,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
                                 auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             }
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
                             PH(6)   // merge, scalar part
@@ -618,10 +619,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             // time-ordered (tpm, tpp, trho) whatever the direction
                             auto a_tr = [&](int k) { return trho[k]; };
                             if (depth == 0) {
-                                turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p);
+                                turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p, nl);
                             } else {
-                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr);
+                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr, nl)
+                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr, nl);
                             }
                             double w;
                             PH(6)

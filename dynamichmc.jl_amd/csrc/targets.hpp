@@ -202,7 +202,7 @@ struct FunnelT {
             double x = (k == 0 && lane == 0) ? 0.0 : q[k];
             acc.add(0, k, x, x);
         }
-        double S = wave_allreduce1(acc.fold(0));
+        double S = wave_allreduce1(acc.fold(0), reduce_lanes(NPL, D));
         double hd = 0.5 * (double)(D - 1);
         double hes = (0.5 * ev) * S;
         double lq = (((v * v) * (-1.0 / 18.0)) - hes) - hd * v;

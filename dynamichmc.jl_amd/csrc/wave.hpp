@@ -56,8 +56,13 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 // which leave (r3 + r2) + (r1 + r0) in lane 63 — the same bits as (r0 + r1) + (r2 + r3) since
 // IEEE addition commutes — read back as a scalar.  (After row_bcast15 only rows 1 and 3 are meaningful, after
 // row_bcast31 only row 3: lane 63 = (v₃ + v₂) + lane 31, lane 31 = v₁ + v₀.)
+// `nl` (16, 32 or 64; wave-uniform): lanes nl .. 63 are known to hold ±0 in every value — a chain of at most nl coordinates at
+// one slot per lane, whose pad lanes contribute exact zeros to every partial sum.  Then whole rows of 16 lanes add nothing
+// (x + ±0 = x bit for bit), the last one or two butterfly steps are skipped and the total is read from lane nl - 1: the same
+// bits with 2 × 3 dependent instructions per value less on the critical path of a short chain (BASELINE config 4's 30-dim funnel).
+__host__ __device__ constexpr int reduce_lanes(int NPL, int D) { return NPL > 1 ? 64 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)); }
 template <int N>
-__device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
+__device__ __forceinline__ void wave_allreduce(double (&v)[N], int nl = 64) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
 #pragma unroll
@@ -66,16 +71,20 @@ __device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x141>(v[i]);  // row_half_mirror
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x140>(v[i]);  // row_mirror
+    if (nl > 16) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x142, 0xA>(v[i]);  // row_bcast15 -> rows 1,3
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x142, 0xA>(v[i]);  // row_bcast15 -> rows 1,3
+    }
+    if (nl > 32) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x143, 0xC>(v[i]);  // row_bcast31 -> rows 2,3
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_rows_f64<0x143, 0xC>(v[i]);  // row_bcast31 -> rows 2,3
+    }
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = readlane_f64(v[i], 63);  // (r3 + r2) + (r1 + r0), now scalar
+    for (int i = 0; i < N; ++i) v[i] = readlane_f64(v[i], nl - 1);  // (r3 + r2) + (r1 + r0), now scalar
 }
-__device__ __forceinline__ double wave_allreduce1(double x) {
+__device__ __forceinline__ double wave_allreduce1(double x, int nl = 64) {
     double v[1] = {x};
-    wave_allreduce<1>(v);
+    wave_allreduce<1>(v, nl);
     return v[0];
 }
 

@@ -38,3 +38,41 @@ def job_throughput(local_units, local_seconds, dist=None, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u[0]) / float(t[0])
+
+
+class TorchAllReduce:
+    """In-place SUM of a tensor over the ranks of a torch.distributed group — what DeviceContext.set_metric_allreduce wants.
+    backend "nccl" (= RCCL over xGMI) reduces the CUDA tensor where it lies; with "gloo" (the CPU tests, and several ranks
+    sharing one GPU) the tensor makes the round trip through host memory."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+
+    def __call__(self, t):
+        backend = self.dist.get_backend(self.group)
+        if t.is_cuda and backend != "nccl":
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def pooled_covariance(draws, allreduce=None):
+    """The job-wide estimate of the shared dense metric, spelled out on the host (numpy): what dhmc_update_metric_dense computes
+    on the device once an all-reduce is installed (include/dhmc.h) — column sums and row counts added over the ranks, the scatter
+    about the job's mean added over the ranks, Σ = S / (J_total - 1).  `draws`: this rank's [C_local][N][D] (or [J][D]);
+    `allreduce(array)` adds a float64 numpy array over the ranks in place (None: one rank).  The protocol's reference for the
+    tests; the device path uses the same two collectives."""
+    x = np.asarray(draws, np.float64).reshape(-1, np.shape(draws)[-1])
+    buf = np.concatenate([x.sum(0), [float(x.shape[0])]])
+    if allreduce is not None:
+        allreduce(buf)
+    J = buf[-1]
+    mean = buf[:-1] / J
+    d = x - mean
+    S = d.T @ d
+    if allreduce is not None:
+        allreduce(S)
+    return S / (J - 1), mean, int(J)

@@ -359,6 +359,21 @@ int dhmc_summarize_tree_statistics(int32_t device, void* stream, const double* p
                                    int64_t chains, int64_t n, int on_device, dhmc_tree_statistics_summary* summary,
                                    double* ebfmi);
 
+/* ---- a shared dense metric adapted from the draws of ALL ranks (mcmc.jl:210,218-222 pooled over the whole job) ----
+ * Without this, dhmc_update_metric_dense pools the draws of the chains of ONE context — one GPU's block — so a job sharded over
+ * 8 ranks adapts eight different matrices where one GPU holding all chains would adapt one.  With an all-reduce installed the
+ * estimate is job-wide: (1) every rank sums its rows per coordinate (sequentially in chain-major row order, as before) and the
+ * D sums plus the row count are added over the ranks; mean = sum / J_total; (2) every rank forms Σ_j (x_j - mean)(x_j - mean)ᵀ
+ * over ITS rows (the same k-ordered fp64-MFMA chain as before) and the Dpad² sums are added over the ranks; then regularisation
+ * with J_total and the factorisation as before — every rank ends with the same matrix.  The callback must add `count` doubles at
+ * `device_buf` (device memory) over all ranks IN PLACE, ordered on `hip_stream` (RCCL: ncclAllReduce on that stream; from Python
+ * torch.distributed.all_reduce — dynamichmc.jl_amd.sharding.TorchAllReduce), and return 0.  A collective's summation order is its
+ * own: the result of N ranks agrees with one rank holding all chains to rounding (tests: rtol 1e-12), and is bit-identical to
+ * dhmc_update_metric_dense without a callback when there is one rank.  Shared dense metric only (per-chain metrics need no
+ * pooling); fn == NULL removes it. */
+typedef int (*dhmc_allreduce_fn)(void* user, double* device_buf, int64_t count, void* hip_stream);
+int dhmc_set_metric_allreduce(dhmc_ctx* ctx, dhmc_allreduce_fn fn, void* user);
+
 /* ---- resume: flat POD image of every chain's (Q, κ, ϵ, adaptation state, counters) ---- */
 int dhmc_state_bytes(dhmc_ctx* ctx, uint64_t* nbytes);
 int dhmc_export_state(dhmc_ctx* ctx, void* host_blob, uint64_t nbytes);

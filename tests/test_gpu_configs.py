@@ -230,7 +230,7 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--chains", "2048", "--steps", "2", "--warmup", "1",
-                        "--transitions", "40", "--short-warmup", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                        "--transitions", "40", "--short-warmup", "--no-cpu-baseline", "--allow-shared-gpu"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # ONE line, from rank 0
@@ -239,6 +239,14 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["collective_backend"] in ("gloo", "nccl")
     assert "2048 chains" in d["config"]["workload"]
     assert d["value"] > 1e7 and d["scaling"] == "weak"
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["shared_gpu"] is True
+        # without the explicit flag a run that finds fewer devices than ranks REFUSES: no n_gpus line for GPUs that are not there
+        q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--chains", "512", "--steps", "1", "--warmup", "0",
+                            "--transitions", "10", "--short-warmup", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+        assert q.returncode != 0 and not [l for l in q.stdout.splitlines() if l.startswith("{")]
+        assert "distinct device" in q.stderr
 
 
 def test_bench_collectives_run_over_rccl():

@@ -321,3 +321,68 @@ def test_per_chain_dense_update_lets_every_chain_stand_for_itself(pkg):
         assert not np.array_equal(after[c], before[c])        # the others did adapt
         assert np.allclose(after[c], np.cov(draws[c].T), rtol=1e-10)
     dev.run(5)                                                # and the context goes on
+
+
+def test_metric_pooled_over_ranks_with_one_rank_is_the_plain_update(pkg):
+    """include/dhmc.h dhmc_set_metric_allreduce: with ONE rank the job-wide estimate (column sums / row count and the scatter
+    matrix passed through the all-reduce callback) is bit-identical to dhmc_update_metric_dense without a callback, and close to
+    the host statement of the protocol (sharding.pooled_covariance); the callback really ran (two collectives per update)."""
+    D, C, N = 37, 6, 30
+    rng = np.random.default_rng(8)
+    draws = rng.normal(size=(C, N, D)) * np.linspace(0.5, 2, D) + 1.0
+    calls = []
+    a = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, seed=1)
+    b = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, seed=1)
+    b.set_metric_allreduce(lambda t: calls.append(int(t.numel())))          # one rank: the sum over ranks is the tensor itself
+    for ctx in (a, b):
+        ctx.init()
+        ctx.update_metric_dense(draws, 0.05)
+    Ma, Wa = a.metric_dense(); Mb, Wb = b.metric_dense()
+    assert np.array_equal(Ma, Mb) and np.array_equal(Wa, Wb)
+    assert calls == [D + 1, 64 * 64]                                       # column sums + count, then the padded scatter matrix
+    S, _, J = pkg.sharding.pooled_covariance(draws)
+    want = 0.95 * S + 0.05 * np.diag(np.diag(S))
+    assert J == C * N and np.allclose(Mb, want, rtol=1e-11, atol=1e-13)
+    b.set_metric_allreduce(None)
+    b.update_metric_dense(draws, 0.05)
+    assert len(calls) == 2 and np.array_equal(b.metric_dense()[0], Ma)
+
+
+def _pooled_worker(rank, world, port, total, D, N, outdir):
+    import os, sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import oracle_lib as ol2
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks on this box's one GPU: RCCL wants one device per rank
+    off, cnt = pkg.sharding.shard_chains(total, world, rank)
+    draws = np.random.default_rng(4).normal(size=(total, N, D)) * np.linspace(0.5, 2, D)
+    ctx = pkg.DeviceContext(D, cnt, metric=ol2.METRIC_DENSE, seed=2, chain_offset=off)
+    ctx.init()
+    ctx.set_metric_allreduce(pkg.sharding.TorchAllReduce(dist))
+    ctx.update_metric_dense(draws[off:off + cnt], 0.1)
+    M, W = ctx.metric_dense()
+    np.savez(os.path.join(outdir, f"metric{rank}.npz"), M=M, W=W)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_adapt_one_shared_dense_metric(pkg, tmp_path):
+    """Two PROCESSES, each a context over its block of chains (ragged: 4 and 3), adapt the shared dense metric from the draws of
+    both (all-reduce over gloo: they share this box's GPU): the two ranks end with the same M⁻¹ and W bit for bit, and that matrix
+    agrees with one context holding all seven chains to rounding (a collective's summation order is its own: rtol 1e-12)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    total, D, N, world = 7, 70, 25, 2
+    mp.spawn(_pooled_worker, args=(world, port, total, D, N, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "metric0.npz"), np.load(tmp_path / "metric1.npz")
+    assert np.array_equal(a["M"], b["M"]) and np.array_equal(a["W"], b["W"])
+    draws = np.random.default_rng(4).normal(size=(total, N, D)) * np.linspace(0.5, 2, D)
+    one = pkg.DeviceContext(D, total, metric=ol.METRIC_DENSE, seed=2)
+    one.init(); one.update_metric_dense(draws, 0.1)
+    M1, W1 = one.metric_dense()
+    assert np.allclose(a["M"], M1, rtol=1e-12, atol=1e-15) and np.allclose(a["W"], W1, rtol=1e-10, atol=1e-13)

@@ -9,8 +9,13 @@ pkg = load_package()
 lib = pkg.abi.lib()
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-ctx = pkg.DeviceContext(1000, C, seed=1)
-ctx.init(); ctx.set_stepsize(0.3)          # unit metric, eps 0.3: depth-4 trees as after adaptation
+PH_D = int(os.environ.get("PH_D", 1000))
+if os.environ.get("PH_TARGET") == "funnel":   # Neal's funnel (config 4's model), FAM=FunnelT build: a short adaptation first
+    ctx = pkg.DeviceContext(PH_D, C, target=pkg.abi.TARGET_FUNNEL, seed=1)
+    ctx.init(); ctx.find_initial_stepsize(); ctx.run(100, da={}, fields=[])
+else:
+    ctx = pkg.DeviceContext(PH_D, C, seed=1)
+    ctx.init(); ctx.set_stepsize(0.3)          # unit metric, eps 0.3: depth-4 trees as after adaptation
 ctx.run(20, fields=[])
 lib.dhmc_debug_phase.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.dhmc_debug_phase(None, 1)
