@@ -1721,6 +1721,7 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
             HIP_TRY(c, hipStreamSynchronize(c->stream));       // Jtot is on the host now
             if (!(Jtot >= 2.0)) { stage_free(c, &s); return DHMC_ERR_INVALID_ARGUMENT; }
         }
+        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, (int64_t)Jtot, lambda, S, (size_t)0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }
         else rc = device_dense_metric(c, S, ld, -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite

@@ -143,10 +143,16 @@ __device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool gra
 
 // One leapfrog step in registers (hamiltonian.jl:273-282) followed by the leaf's joint log
 // density.  eps is signed (backward motion = negative ϵ, NUTS.jl:30).
-template <class T, int NPL, class MK>
+// `merge0` (wave-uniform; `pa0_` = slot k of the suspended level-0 leaf's momentum): the leaf that completes a pair also takes
+// the pair's leaf·leaf turn check — merge_leaf_leaf's two dots — and their partial sums ride in the SAME butterfly as ℓ and K
+// (four values instead of two, one reduction latency instead of two; the suspended row's LDS round trip runs under the
+// leapfrog's arithmetic).  Same operations on the same operands, value by value, so the same bits as the separate merge; if the
+// leaf turns out divergent the merge's result is simply not looked at (cf / cr are dead then).
+template <class T, int NPL, class MK, class PA0>
 __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, int D,
                                                 double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
-                                                double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl = 64) {
+                                                double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl,
+                                                bool merge0, PA0 pa0_, double (&cf)[NPL], double (&cr)[NPL], bool& turning0) {
     const double h = eps / 2;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -167,7 +173,33 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
         kacc.add(0, k, p[k], ps);
     }
     double lq, K;
-    if constexpr (T::kDeferred) {
+    turning0 = false;
+    if (merge0) {
+        LaneAcc<2, NPL> A;                           // merge_leaf_leaf, word for word
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const double pa = pa0_(k);
+            const double mk = mk_(k);
+            const double r = pa + p[k];
+            A.add(0, k, mk * pa, r);
+            A.add(1, k, mk * p[k], r);
+            cf[k] = pa;
+            cr[k] = r;
+        }
+        if constexpr (T::kDeferred) {
+            double r[4] = {lres, kacc.fold(0), A.fold(0), A.fold(1)};
+            wave_allreduce<4>(r, nl);
+            lq = tgt.finish(r[0]);
+            K = r[1] / 2.0;
+            turning0 = r[2] < 0 || r[3] < 0;
+        } else {
+            double r[3] = {kacc.fold(0), A.fold(0), A.fold(1)};
+            wave_allreduce<3>(r, nl);
+            lq = lres;
+            K = r[0] / 2.0;
+            turning0 = r[1] < 0 || r[2] < 0;
+        }
+    } else if constexpr (T::kDeferred) {
         double r[2] = {lres, kacc.fold(0)};
         wave_allreduce<2>(r, nl);
         lq = tgt.finish(r[0]);
@@ -192,6 +224,23 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
     lq = demote_lq(lq, pos_finite, gfin);
     lq_out = lq;
     pi_out = uni_f64(joint_logdensity(lq, K));
+}
+// Measured (round 4, D = 1000 × 4096 chains, same box): 3.19e8 leapfrog-steps/s without the fusion, 3.01e8 with it — the merge's
+// rows live through the density evaluation and the allocator pays in AGPR moves (the leaf region +650 clocks per leapfrog, the
+// merges −315): bit-exact, slower, off.  -DDHMC_FUSE_LEAF_MERGE0 builds it.
+#ifdef DHMC_FUSE_LEAF_MERGE0
+constexpr bool kFuseLeafMerge0 = true;
+#else
+constexpr bool kFuseLeafMerge0 = false;
+#endif
+// the leaf alone
+template <class T, int NPL, class MK>
+__device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, int D,
+                                                double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
+                                                double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl = 64) {
+    double cf_[NPL], cr_[NPL];
+    bool t0;
+    leapfrog_leaf_m<T, NPL>(tgt, mk_, lane, D, q, p, g, eps, lq_out, pi_out, pos_finite, nl, false, [](int) { return 0.0; }, cf_, cr_, t0);
 }
 
 // M⁻¹ staged in LDS (or any lane-strided row)
@@ -356,7 +405,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     double* tpp_lds = lds + 4 * Dpad;                      // [Dpad]   trajectory p₊   (TPL only)
     constexpr int NXL = L1LDS ? lds_extra_levels(NPL) : 0; // levels 2 .. 1+NXL in LDS too (short chains)
     double* xl_lds = lds + 4 * Dpad;                       // [NXL][3][Dpad]  first, last, ρ
-    LaneArrF64 lv_omega, lv_vlsa, lv_vsteps;               // per suspended level (lane = level): ω, visited statistic
+    LaneArrF64 lv_omega, lv_vlsa;                          // per suspended level (lane = level): ω, visited statistic
+    LaneArrI64 lv_vsteps;
     LaneArrI32 lv_zeta;                                    //   … and the proposal slot
     LaneArrF64 sl_lq, sl_pi;                               // per proposal slot (lane = slot): ℓq and π of the point stored there
 
@@ -426,6 +476,16 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         sl_lq.set(s, lq_leaf, lane);
         sl_pi.set(s, pi_leaf, lane);
         return s;
+    };
+
+    // draw n of this call := the chain's position after transition n (mcmc.jl:275,376)
+    auto store_draw = [&](int64_t n_) {
+        if (P.out.draws) {
+            double* drow = P.out.draws + ((size_t)chain * (P.out_stride ? P.out_stride : P.N) + n_) * D;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
+        }
     };
 
     PH_DECL
@@ -536,11 +596,12 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
                 PH(3)   // leaf
-                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl);
+                bool turning0;
+                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl, kFuseLeafMerge0 && (j & 1u) != 0,
+                                        [&](int k) { return l0_lds[lane + WAVE * k]; }, cf, cr, turning0);
                 PH(4)   // leaf scalars
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
-                total_steps += 1;
                 const double delta = pi_leaf - pi0;             // NUTS.jl:150
                 v_lsa = delta < 0.0 ? delta : 0.0;              // min(Δ, 0)   (NUTS.jl:79)
                 v_steps = 1;
@@ -563,7 +624,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         PH(5)   // merge, vector part
                         if (sub) {
                             if (level == 0) {
-                                turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p, nl);
+                                if constexpr (kFuseLeafMerge0) turning = turning0;      // taken with the leaf's own reduction (leapfrog_leaf_m)
+                                else turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p, nl);
                             } else if (L1LDS && level == 1) {
                                 auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
                                 auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
@@ -594,7 +656,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             const double wl = lv_omega.get(level);
                             double w;
                             logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
-                            v_steps += (int64_t)lv_vsteps.get(level);
+                            v_steps += lv_vsteps.get(level);
                             if (turning) {                       // trees.jl:255
                                 term_left = i - di * (((int64_t)2 << level) - 1);
                                 term_right = i;
@@ -683,7 +745,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         }
                         lv_omega.set(level, c_omega, lane);
                         lv_vlsa.set(level, v_lsa, lane);
-                        lv_vsteps.set(level, (double)v_steps, lane);
+                        lv_vsteps.set(level, v_steps, lane);
                         lv_zeta.set(level, c_zeta, lane);
                     }
                 }
@@ -693,7 +755,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                     for (int l2 = level; l2 < depth; ++l2) {
                         if ((j >> l2) & 1u) {
                             v_lsa = uni_f64(det_logaddexp_u(lv_vlsa.get(l2), v_lsa));
-                            v_steps += (int64_t)lv_vsteps.get(l2);
+                            v_steps += lv_vsteps.get(l2);
                         }
                     }
                     vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa)); // trees.jl:294
@@ -709,6 +771,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             double a = det_exp_u(vtop_lsa) / (double)vtop_steps;           // NUTS.jl:87
             return uni_f64(a < 1.0 ? a : 1.0);
         }();
+        total_steps += (unsigned long long)vtop_steps;
         init_slot = zeta_top;
         ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
         if constexpr (T::kPointwiseGrad) {}
@@ -718,12 +781,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         const double pi_stat = sl_pi.get(init_slot);
 
         const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + n;
-        if (P.out.draws) {
-            double* drow = P.out.draws + o * D;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k)
-                if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];     // mcmc.jl:275,376
-        }
+        // (tried in round 4: the draw stored after the NEXT transition's momentum refresh, so that the proposal slot's round trip
+        // runs under it — 3.10e8 against 3.16e8 leapfrog-steps/s on one box, the loads kept in flight across the loop's back edge
+        // cost more in waits at the loop head than the round trip they hide)
+        store_draw(n);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
             if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273

@@ -164,6 +164,16 @@ struct LaneArrF64 {
     __device__ __forceinline__ double get(int i) const { return readlane_f64(v, i); }
     __device__ __forceinline__ void set(int i, double x, int lane) { v = (lane == i) ? x : v; }
 };
+struct LaneArrI64 {      // exact for any count (a float64 lane array would cost two conversions per access)
+    uint32_t lo = 0, hi = 0;
+    __device__ __forceinline__ int64_t get(int i) const {
+        return (int64_t)(((uint64_t)__builtin_amdgcn_readlane(hi, i) << 32) | __builtin_amdgcn_readlane(lo, i));
+    }
+    __device__ __forceinline__ void set(int i, int64_t x, int lane) {
+        lo = (lane == i) ? (uint32_t)(uint64_t)x : lo;
+        hi = (lane == i) ? (uint32_t)((uint64_t)x >> 32) : hi;
+    }
+};
 struct LaneArrI32 {
     int v = 0;
     __device__ __forceinline__ int get(int i) const { return (int)__builtin_amdgcn_readlane((uint32_t)v, i); }
