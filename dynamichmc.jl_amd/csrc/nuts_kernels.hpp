@@ -33,6 +33,14 @@
 
 namespace dhmc {
 
+// Scheduling fence between 256-coordinate blocks of a per-slot loop (experiment switch -DDHMC_SCHED_BLOCKS): keeps the compiler
+// from hoisting the loads of all 16 slots to the top of a loop, which is what decides the kernel's register budget.
+#ifdef DHMC_SCHED_BLOCKS
+#define DHMC_BLOCK_FENCE(k) do { if (((k) & 3) == 3) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DHMC_BLOCK_FENCE(k) do { } while (0)
+#endif
+
 // DualAveragingState (stepsize.jl:121-127)
 struct DAState {
     double mu;
@@ -163,6 +171,7 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
         double t = mk_(k) * pm;                      // ∇kinetic_energy(κ, pₘ) = M⁻¹ pₘ
         q[k] = q[k] + eps * t;                       // :278
         p[k] = pm;
+        DHMC_BLOCK_FENCE(k);
     }
     const double lres = tgt.eval(q, g, lane, D);     // :279 -> hamiltonian.jl:204
     LaneAcc<1, NPL> kacc;
@@ -171,6 +180,7 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
         p[k] = p[k] + h * g[k];                      // :280
         double ps = mk_(k) * p[k];                   // p♯ = M⁻¹ p'
         kacc.add(0, k, p[k], ps);
+        DHMC_BLOCK_FENCE(k);
     }
     double lq, K;
     turning0 = false;
@@ -280,6 +290,7 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
         A.add(5, k, d, r);
         cf[k] = nf;
         cr[k] = r;
+        DHMC_BLOCK_FENCE(k);
     }
     double acc[6];
     A.fold_all(acc);
@@ -305,6 +316,7 @@ __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
         A.add(1, k, mk * pb[k], r);
         cf[k] = pa;
         cr[k] = r;
+        DHMC_BLOCK_FENCE(k);
     }
     double acc[2];
     A.fold_all(acc);
@@ -434,13 +446,24 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     const int nl = uni_i32(reduce_lanes(NPL, D));          // lanes that can hold nonzero partial sums (wave.hpp wave_allreduce)
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
-    double tpm[TPL ? 1 : NPL], tpp[TPL ? 1 : NPL], trho[NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+    // TWS (the two-waves-per-SIMD layout of a wide chain, L1LDS = false at 16 slots per lane): the trajectory's turn statistic
+    // (p₋, p₊, ρ — touched once per doubling) lives in workspace rows like the level >= 1 summaries, M⁻¹ and the level-0 leaf in
+    // 16 KB of LDS, and only the phase point and the running summary (q, p, cf, cr: 128 VGPRs) in registers — half the
+    // registers and less than half the LDS of the one-wave-per-SIMD layout, so that a second chain shares the SIMD and each
+    // chain's memory and dependency latencies run under the other's instructions.
+    constexpr bool TWS = NPL == 16 && !L1LDS;
+    double* const tpm_ws = ws + (size_t)ws_edge(0, 1) * Dpad;
+    double* const tpp_ws = ws + (size_t)ws_edge(1, 1) * Dpad;
+    double* const trho_ws = ws + (size_t)ws_rho_top() * Dpad;
+    double tpm[(TPL || TWS) ? 1 : NPL], tpp[(TPL || TWS) ? 1 : NPL], trho[TWS ? 1 : NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
     auto a_tm = [&](int k) -> double {
         if constexpr (TPL) return tpm_lds[lane + WAVE * k];
+        else if constexpr (TWS) return tpm_ws[lane + WAVE * k];
         else return tpm[k];
     };
     auto a_tp = [&](int k) -> double {
         if constexpr (TPL) return tpp_lds[lane + WAVE * k];
+        else if constexpr (TWS) return tpp_ws[lane + WAVE * k];
         else return tpp[k];
     };
     ldv<NPL>(P.st.q + row, lane, q);
@@ -514,12 +537,18 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         if constexpr (TPL) {
             stv<NPL>(tpm_lds, lane, p);
             stv<NPL>(tpp_lds, lane, p);
+        } else if constexpr (TWS) {
+            stv<NPL>(tpm_ws, lane, p);
+            stv<NPL>(tpp_ws, lane, p);
+            stv<NPL>(trho_ws, lane, p);
         } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; }
         }
+        if constexpr (!TWS) {
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) trho[k] = p[k];
+            for (int k = 0; k < NPL; ++k) trho[k] = p[k];
+        }
         sl_lq.set(init_slot, lq_cur, lane);
         sl_pi.set(init_slot, pi0, lane);
 
@@ -679,7 +708,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         } else {
                             // top level (trees.jl:294-316): merge with τ of the whole trajectory, which is
                             // time-ordered (tpm, tpp, trho) whatever the direction
-                            auto a_tr = [&](int k) { return trho[k]; };
+                            auto a_tr = [&](int k) -> double {
+                                if constexpr (TWS) return trho_ws[lane + WAVE * k];
+                                else return trho[k];
+                            };
                             if (depth == 0) {
                                 turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p, nl);
                             } else {
@@ -710,6 +742,9 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                                 // τ of the doubled trajectory: the new edge momentum and Σp
                                 if constexpr (TPL) {
                                     stv<NPL>(fwd ? tpp_lds : tpm_lds, lane, p);
+                                } else if constexpr (TWS) {
+                                    stv<NPL>(fwd ? tpp_ws : tpm_ws, lane, p);
+                                    stv<NPL>(trho_ws, lane, cr);
                                 } else if (fwd) {
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) tpp[k] = p[k];
@@ -717,8 +752,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) tpm[k] = p[k];
                                 }
+                                if constexpr (!TWS) {
 #pragma unroll
-                                for (int k = 0; k < NPL; ++k) trho[k] = cr[k];
+                                    for (int k = 0; k < NPL; ++k) trho[k] = cr[k];
+                                }
                             }
                             level = -1;  // handled
                             break;

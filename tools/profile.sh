@@ -20,6 +20,6 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- python $R
 cd $REPO
 find $OUT -name "*.csv" > $KEEP/files.txt; python tools/summarize_prof.py $OUT > $KEEP/summary.txt 2>&1
 cp $OUT/bench_trace.json $OUT/traffic.json $KEEP/ 2>/dev/null
-for f in $(find $OUT -name '*kernel_stats.csv' -o -name '*agent_info.csv' | head -4); do cp $f $KEEP/; done
+for f in $(find $OUT -name '*kernel_stats.csv' | head -2) $(find $OUT -name '*agent_info.csv' | head -2); do cp $f $KEEP/; done
 for e in $OUT/*.err; do echo "--- $e"; tail -3 $e; done
 cat $KEEP/summary.txt
