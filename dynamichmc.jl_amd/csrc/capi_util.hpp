@@ -1,0 +1,49 @@
+// Shared by every translation unit of the C ABI (not part of the ABI: include/dhmc.h is): the standard headers, a device
+// temporary with scope lifetime, and the interface of capi_rtc.hip (the caller's device functor compiled at run time).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+
+#include "../../include/dhmc.h"
+
+// a device temporary that is released on every return path
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// ---- the caller's device functor, compiled at run time (capi_rtc.hip) ----------------------------------------------------
+struct UserKernels {
+    hipModule_t mod = nullptr;
+    hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr, probe_traj = nullptr, probe_ratio = nullptr;
+    // DHMC_METRIC_DENSE: a second module, compiled when the first dense context of this functor is created
+    hipModule_t dense_mod = nullptr;
+    hipFunction_t k0 = nullptr, k2 = nullptr, k3 = nullptr, run_dense = nullptr, search_dense = nullptr, probe_traj_dense = nullptr,
+                  probe_ratio_dense = nullptr;
+};
+struct UserTarget {
+    std::string source, name;
+    std::map<std::pair<int, int>, UserKernels> built;   // (device, slots per lane) -> module
+};
+extern std::vector<UserTarget> g_user_targets;
+extern std::mutex g_user_mutex;
+extern std::string g_rtc_log;
+int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered);
+int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low, hipModule_t* mod, std::initializer_list<hipFunction_t*> fns);
+int npl_for_user_dim(int D);
+

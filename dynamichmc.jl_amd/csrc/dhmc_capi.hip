@@ -4,293 +4,13 @@
 // the reference uses @argcheck, launches the HIP kernels of nuts_kernels.hpp on the caller's
 // stream, and maps per-chain failure words onto return codes.  There is NO CPU path in this
 // library: without a HIP device every entry point that computes returns DHMC_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-#include <hip/hiprtc.h>
-#include <hipcub/hipcub.hpp>
-#include <unistd.h>
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
+#include "capi_internal.hpp"
 
-#include "../../include/dhmc.h"
-#include "dense_factor.hpp"
-#include "dense_rounds_k3b.hpp"
-#include "external_rounds.hpp"
-#include "ess_kernels.hpp"
-#include "logistic_rounds.hpp"
-#include "metric_dense_adapt.hpp"
-#include "treestat_kernels.hpp"
-#include "launch.hpp"
-#include "util_kernels.hpp"
+using namespace capi;
 
-using namespace dhmc;
 
-// ---- the caller's device functor, compiled at run time (include/dhmc.h dhmc_register_target_source) -----------------------
-#include "gen/rtc_headers.inc"     // const char dhmc_rtc_headers[]: the kernel headers as one string (make_rtc_source.py)
-namespace {
-struct UserKernels {
-    hipModule_t mod = nullptr;
-    hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr, probe_traj = nullptr, probe_ratio = nullptr;
-    // DHMC_METRIC_DENSE: a second module, compiled when the first dense context of this functor is created
-    hipModule_t dense_mod = nullptr;
-    hipFunction_t k0 = nullptr, k2 = nullptr, k3 = nullptr, run_dense = nullptr, search_dense = nullptr, probe_traj_dense = nullptr,
-                  probe_ratio_dense = nullptr;
-};
-struct UserTarget {
-    std::string source, name;
-    std::map<std::pair<int, int>, UserKernels> built;   // (device, slots per lane) -> module
-};
-std::vector<UserTarget> g_user_targets;
-std::mutex g_user_mutex;
-std::string g_rtc_log;
 
-// hiprtc has the HIP device runtime built in but no system headers: the fixed-width integer names the headers use
-const char* rtc_prelude() {
-    return "typedef unsigned char uint8_t; typedef unsigned int uint32_t; typedef int int32_t;\n"
-           "typedef unsigned long long uint64_t; typedef long long int64_t;\n";
-}
-// the kernels a functor needs, as name expressions: the wave-per-chain set of the diagonal metric, or the dense metric's
-// (round engine K0/K2/K3, wave-per-chain run and search, the two probes)
-uint64_t rtc_checksum(const char* p, uint64_t n) {      // FNV-1a over the code object
-    uint64_t h = 1469598103934665603ull;
-    for (uint64_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
-    return h;
-}
-std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
-    const std::string T = "dhmc::" + name, N = std::to_string(npl);
-    if (!dense)
-        return {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
-                "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
-                "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
-    return {"dhmc::rounds_k0_kernel<" + T + ", " + N + ">", "dhmc::rounds_k2_kernel<" + T + ", " + N + ">",
-            (npl >= 8 ? "dhmc::rounds_k3b_kernel<" : "dhmc::rounds_k3_kernel<") + T + ", " + N + ">",
-            "dhmc::nuts_run_dense_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_dense_kernel<" + T + ", " + N + ">",
-            "dhmc::probe_kernel<" + T + ", " + N + ", true, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", true, 1>"};
-}
-// compile `source` (which defines dhmc::`name`) with the kernel templates for one chain width; *code receives the code object
-int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered) {
-    std::string src = rtc_prelude();
-    src += dhmc_rtc_headers;
-    src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
-    src += source;
-    src += "\n";
-    const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
-    // DHMC_RTC_CACHE=<directory>: code objects are kept there, keyed by everything that went into them, so that the next
-    // process (a new Julia session) loads instead of compiling (≈ 2 s diagonal, ≈ 15 s dense per functor and chain width)
-    std::string cache_file;
-    if (const char* dir = std::getenv("DHMC_RTC_CACHE"); dir && *dir && code && lowered) {
-        uint64_t h = 1469598103934665603ull;
-        auto mix = [&](const std::string& t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
-        int major = 0, minor = 0;
-        (void)hiprtcVersion(&major, &minor);
-        mix(src); mix(dhmc_version()); mix(std::to_string(major) + "." + std::to_string(minor));
-        for (const auto& e : exprs) mix(e);
-        char hex[17];
-        std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
-        cache_file = std::string(dir) + "/dhmc_rtc_" + hex + ".co";
-        if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
-            bool ok = false;
-            char magic[8];
-            uint32_t n = 0;
-            std::vector<std::string> names;
-            if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DHMCRTC2", 8) == 0 && std::fread(&n, 4, 1, f) == 1 && n == exprs.size()) {
-                ok = true;
-                for (uint32_t i = 0; i < n && ok; ++i) {
-                    uint32_t len = 0;
-                    ok = std::fread(&len, 4, 1, f) == 1 && len < 4096;
-                    std::string t(ok ? len : 0, '\0');
-                    ok = ok && (len == 0 || std::fread(&t[0], 1, len, f) == len);
-                    names.push_back(t);
-                }
-                uint64_t cs = 0, sum = 0;
-                ok = ok && std::fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 31);
-                if (ok) { code->resize(cs); ok = std::fread(code->data(), 1, cs, f) == cs; }
-                ok = ok && std::fread(&sum, 8, 1, f) == 1 && sum == rtc_checksum(code->data(), cs);      // a damaged payload is not trusted
-            }
-            std::fclose(f);
-            if (ok) { *lowered = names; g_rtc_log = "(loaded from " + cache_file + ")"; return DHMC_OK; }
-            code->clear();
-        }
-    }
-    hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
-    for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
-    // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
-    // whatever device it will run beside them on)
-    std::string arch = "--offload-arch=gfx950";
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0])
-            arch = std::string("--offload-arch=") + prop.gcnArchName;
-    }
-    const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
-    size_t ls = 0;
-    (void)hiprtcGetProgramLogSize(prog, &ls);
-    g_rtc_log.assign(ls, '\0');
-    if (ls) (void)hiprtcGetProgramLog(prog, &g_rtc_log[0]);
-    int rc = DHMC_OK;
-    if (r != HIPRTC_SUCCESS) {
-        rc = DHMC_ERR_INVALID_ARGUMENT;
-    } else {
-        if (lowered)
-            for (const auto& e : exprs) {
-                const char* low = nullptr;
-                if (hiprtcGetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) { rc = DHMC_ERR_HIP; break; }
-                lowered->push_back(low);
-            }
-        if (rc == DHMC_OK && code) {
-            size_t cs = 0;
-            if (hiprtcGetCodeSize(prog, &cs) != HIPRTC_SUCCESS) rc = DHMC_ERR_HIP;
-            else { code->resize(cs); if (hiprtcGetCode(prog, code->data()) != HIPRTC_SUCCESS) rc = DHMC_ERR_HIP; }
-        }
-    }
-    (void)hiprtcDestroyProgram(&prog);
-    if (rc == DHMC_OK && !cache_file.empty()) {           // written under another name first: a concurrent reader never sees half a file
-        static std::atomic<unsigned> serial{0};              // unique per process (pid) and per call: concurrent ranks never share a tmp file
-        const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
-        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-            const uint32_t n = (uint32_t)lowered->size();
-            bool ok = std::fwrite("DHMCRTC2", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
-            for (const auto& t : *lowered) {
-                const uint32_t len = (uint32_t)t.size();
-                ok = ok && std::fwrite(&len, 4, 1, f) == 1 && std::fwrite(t.data(), 1, len, f) == len;
-            }
-            const uint64_t cs = code->size(), sum = rtc_checksum(code->data(), cs);
-            ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code->data(), 1, cs, f) == cs && std::fwrite(&sum, 8, 1, f) == 1;
-            ok = (std::fclose(f) == 0) && ok;
-            if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) (void)std::remove(tmp.c_str());
-        }
-    }
-    return rc;
-}
-// load a compiled module and look its kernels up in the order of rtc_kernel_names
-// (the module handle and the functions are published only when every kernel resolved; otherwise the module is unloaded and
-// *mod stays null, so that a later context compiles again instead of finding a module without kernels)
-int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low, hipModule_t* mod, std::initializer_list<hipFunction_t*> fns) {
-    hipModule_t m = nullptr;
-    if (hipModuleLoadData(&m, code.data()) != hipSuccess) return DHMC_ERR_HIP;
-    std::vector<hipFunction_t> got;
-    size_t i = 0;
-    for (size_t k = 0; k < fns.size(); ++k) {
-        hipFunction_t f = nullptr;
-        if (i >= low.size() || hipModuleGetFunction(&f, m, low[i++].c_str()) != hipSuccess || !f) {
-            (void)hipModuleUnload(m);
-            return DHMC_ERR_HIP;
-        }
-        got.push_back(f);
-    }
-    i = 0;
-    for (hipFunction_t* f : fns) *f = got[i++];
-    *mod = m;
-    return DHMC_OK;
-}
-int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : 0; }
-}  // namespace
-
-struct dhmc_ctx {
-    dhmc_config cfg{};
-    int Dpad = 0, NPL = 0, nvec = 0;
-    hipStream_t stream = nullptr;
-    ChainArrays st{};
-    TargetParams tp{};
-    void* d_tp_a = nullptr;
-    void* d_tp_b = nullptr;
-    unsigned long long* d_counter = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_ms = 0.0;
-    unsigned long long last_leapfrogs = 0;
-    int l1_in_lds = 1;
-    int k3_block = 1;
-    DenseMetric dm{};          // DHMC_METRIC_DENSE only
-    double* d_Minv = nullptr;
-    double* d_WT = nullptr;
-    double* d_fwork = nullptr;   // 4 × Dpad² doubles: work space of the device factorisation (dense_factor.hpp)
-    int* d_fflags = nullptr;     // [2]: non-finite input, not positive definite
-    RoundBuffers rb{};         // round-based dense engine (dense_rounds.hpp)
-    RoundBuffers rbp[4]{};     // dense round engine: the batch is run as up to 4 parts on as many streams; every part has its own
-                               // list and counters, the vectors are shared
-    hipStream_t streams[4] = {};
-    int dense_parts = 2;       // DHMC_DENSE_PARTS
-    int dense_row_lists = 1;   // DHMC_DENSE_ROW_LISTS: products over the running chains only once some have finished
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_joins[4] = {};
-    int dense_rounds = 1;
-    int fuse_k2 = 1;           // DHMC_FUSE_K2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
-    int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (either dense engine)
-    int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
-    int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
-    int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
-    int logistic_batched = 0;  // … and with it (or beyond 1024 coefficients) ℓ, ∇ℓ of all chains by the same GEMMs wherever they are needed
-                               // outside a round: initialisation, step-size search, the Diagnostics probes (external_eval)
-    LogisticRound lr{};
-    int external = 0;          // DHMC_TARGET_EXTERNAL: density from the host's callback, round engine always
-    int builtin_big = 0;       // a built-in family whose density the LIBRARY evaluates for all chains between kernels, where an external model's
-                               // callback stands (more than 1024 coordinates; the logistic regression with a dense metric): the same engine
-    int* d_all_rows = nullptr; // logistic_batched: the row list 0..C-1 and its length, for the GEMMs of the batched gradient
-    double* d_big[2] = {};     // DHMC_TARGET_DENSE_NORMAL beyond 1024 coordinates: q − μ and P(q − μ) of all chains ([C][Dpad] each)
-    dhmc_logdensity_fn ext_fn = nullptr;
-    void* ext_user = nullptr;
-    ExtSearchState* d_ss = nullptr;
-    uint32_t* d_sflags = nullptr;   // [C][4]: ℓ(q′) (a double) and the position flag between two search kernels (dense)
-    unsigned long long last_rounds = 0;
-    uint64_t ws_bytes = 0;
-    // host outputs of dhmc_run: persistent device staging (two buffers per field, grown on demand — no hipMalloc per call),
-    // and a copy stream
-    struct StageBuf { void* p = nullptr; size_t cap = 0; };
-    StageBuf stage[2][10];
-    hipStream_t copy_stream = nullptr;
-    dhmc_allreduce_fn metric_allreduce = nullptr;   // dhmc_set_metric_allreduce: the shared dense metric adapted from the draws of all ranks
-    void* metric_allreduce_user = nullptr;
-    hipEvent_t ev_k0[2] = {}, ev_k1[2] = {}, ev_copy[2] = {};
-    int* h_done = nullptr;     // page-locked [2][8]: the dense round engine's done-counters, read without draining the streams
-    hipEvent_t ev_done[2] = {};
-    int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
-    const UserKernels* user = nullptr;   // target >= DHMC_TARGET_USER_BASE: the run-time compiled kernels of the caller's functor
-    void* d_user_params = nullptr;
-    bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state
-    std::string err;
-    std::vector<void*> allocs;
-};
-
-namespace {
-
-#define HIP_TRY(ctx, expr)                                                                  \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
-            return DHMC_ERR_HIP;                                                            \
-        }                                                                                   \
-    } while (0)
-
-#define DHMC_CHECK_USABLE(ctx)                                                                                     \
-    do {                                                                                                          \
-        if ((ctx)->poisoned) {                                                                                    \
-            (ctx)->err = "the context's chain state is inconsistent after a failed log-density callback: call dhmc_init or dhmc_import_state"; \
-            return DHMC_ERR_CALLBACK;                                                                             \
-        }                                                                                                         \
-    } while (0)
-
-template <class Tp>
-int dev_alloc(dhmc_ctx* c, Tp** p, size_t count) {
-    void* v = nullptr;
-    HIP_TRY(c, hipMalloc(&v, count * sizeof(Tp)));
-    c->allocs.push_back(v);
-    c->ws_bytes += count * sizeof(Tp);
-    *p = (Tp*)v;
-    return DHMC_OK;
-}
+namespace capi {
 
 // slots per lane: the register/LDS-resident kernels go up to 16 (D <= 1024); the streaming round-engine kernels
 // of an external model up to 64 (D <= 4096)
@@ -329,7 +49,7 @@ void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRo
 #undef DHMC_NPL_SWITCH
 }
 
-int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false) {
+int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override, bool use_override) {
     hipStream_t cs = use_override ? stream_override : c->stream;
     const DenseMetric* M = c->cfg.metric == DHMC_METRIC_DENSE ? &c->dm : nullptr;
     if (c->user) {     // the caller's functor: the same kernels, from the run-time compiled modules
@@ -389,77 +109,7 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
     }
 }
 
-// upload S (symmetric M⁻¹) and Wᵀ padded to [Dpad][Dpad]
-int upload_dense_metric(dhmc_ctx* c, const std::vector<double>& S, const std::vector<double>& W) {
-    const int D = c->cfg.dim;
-    const size_t Dp = c->Dpad;
-    std::vector<double> a(Dp * Dp, 0.0), b(Dp * Dp, 0.0);
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) {
-            a[(size_t)i * Dp + j] = S[(size_t)i * D + j];
-            b[(size_t)j * Dp + i] = W[(size_t)i * D + j];   // transpose: WT[k][i] = W[i][k]
-        }
-    const size_t nmat = c->per_chain_dense ? (size_t)c->cfg.chains : 1;
-    for (size_t m = 0; m < nmat; ++m) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_Minv + m * Dp * Dp, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_WT + m * Dp * Dp, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return DHMC_OK;
-}
-// κ := GaussianKineticEnergy(Symmetric(src)) (hamiltonian.jl:73) entirely on the device (dense_factor.hpp): src is a
-// device matrix with row stride lsrc whose upper triangle is read.  The context's metric is replaced only if src is
-// finite and positive definite; otherwise DHMC_ERR_INVALID_ARGUMENT (the reference's cholesky throws).
-int device_dense_metric(dhmc_ctx* c, const double* src, int lsrc, int slot = -1) {   // slot: a chain of a per-chain dense context, -1: all
-    const int D = c->cfg.dim, ld = c->Dpad;
-    const size_t n = (size_t)ld * ld;
-    double* Stmp = c->d_fwork + 3 * n;
-    double* WTtmp = c->d_fwork + n;              // the X buffer: free again once M = XᵀX exists
-    int flags[2] = {0, 0};
-    HIP_TRY(c, hipMemsetAsync(c->d_fflags, 0, 2 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(df_symmetrize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, lsrc, D, Stmp, ld, c->d_fflags);
-    df_dense_metric(Stmp, Stmp, WTtmp, D, ld, c->d_fwork, c->d_fflags, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(flags, c->d_fflags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (flags[0] || flags[1]) return DHMC_ERR_INVALID_ARGUMENT;
-    const size_t nmat = c->per_chain_dense ? (size_t)c->cfg.chains : 1;
-    for (size_t m = 0; m < nmat; ++m) {
-        if (slot >= 0 && (size_t)slot != m) continue;
-        HIP_TRY(c, hipMemcpyAsync(c->d_Minv + m * n, Stmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_WT + m * n, WTtmp, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return DHMC_OK;
-}
-void launch_metric(const dhmc_ctx* c, const double* draws, int64_t N) {
-    int D = c->cfg.dim, Dp = c->Dpad, C = c->cfg.chains;
-    switch (c->NPL) {
-    case 1: hipLaunchKernelGGL((metric_diag_kernel<1>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    case 2: hipLaunchKernelGGL((metric_diag_kernel<2>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    case 4: hipLaunchKernelGGL((metric_diag_kernel<4>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    case 8: hipLaunchKernelGGL((metric_diag_kernel<8>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    case 16: hipLaunchKernelGGL((metric_diag_kernel<16>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    case 32: hipLaunchKernelGGL((metric_diag_kernel<32>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    default: hipLaunchKernelGGL((metric_diag_kernel<64>), dim3(C), dim3(WAVE), 0, c->stream, D, Dp, N, draws, c->st.minv, c->st.W); break;
-    }
-}
-
-// a device temporary that is released on every return path
-struct DevBuf {
-    void* p = nullptr;
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
 // Stage a host array onto the device (returns a temp the caller frees), or pass through.
-struct Staged {
-    const void* dev = nullptr;
-    void* temp = nullptr;
-    ~Staged() { if (temp) { (void)hipDeviceSynchronize(); (void)hipFree(temp); } }   // error paths; stage_free is the normal one
-};
 int stage_in(dhmc_ctx* c, const void* p, size_t bytes, int on_device, Staged* s) {
     if (on_device) { s->dev = p; return DHMC_OK; }
     HIP_TRY(c, hipMalloc(&s->temp, bytes));
@@ -509,7 +159,7 @@ int copy_out_scalar(dhmc_ctx* c, const void* src, void* dst, size_t bytes, int o
     return DHMC_OK;
 }
 
-}  // namespace
+}  // namespace capi
 
 extern "C" {
 
@@ -786,28 +436,6 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     return DHMC_OK;
 }
 
-int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle) {
-    if (!hip_source || !functor_name || !*functor_name || !target_handle) return DHMC_ERR_INVALID_ARGUMENT;
-    std::lock_guard<std::mutex> lock(g_user_mutex);
-    g_user_targets.push_back(UserTarget{hip_source, functor_name, {}});
-    *target_handle = (int32_t)g_user_targets.size() - 1;
-    return DHMC_OK;
-}
-int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, int32_t metric, char* log, uint64_t log_bytes) {
-    if (!hip_source || !functor_name || (metric != DHMC_METRIC_DIAG && metric != DHMC_METRIC_DENSE)) return DHMC_ERR_INVALID_ARGUMENT;
-    const int npl = npl_for_user_dim(dim);
-    if (npl == 0) return DHMC_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lock(g_user_mutex);
-    const int rc = rtc_compile(hip_source, functor_name, npl, metric == DHMC_METRIC_DENSE, nullptr, nullptr);
-    if (log && log_bytes) {
-        const size_t n = std::min<size_t>(g_rtc_log.size(), (size_t)log_bytes - 1);
-        std::memcpy(log, g_rtc_log.data(), n);
-        log[n] = '\0';
-    }
-    return rc;
-}
-const char* dhmc_target_source_log(void) { return g_rtc_log.c_str(); }
-
 int dhmc_host_alloc(void** out, uint64_t nbytes) {
     if (!out) return DHMC_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -843,7 +471,8 @@ int dhmc_destroy(dhmc_ctx* c) {
 }
 
 // ---- DHMC_TARGET_EXTERNAL (external_rounds.hpp) -------------------------------------------------
-namespace {
+}  // extern "C"
+namespace capi {
 #define DHMC_EXT_NPL_FWD(KERNEL, GRID, ...)                                                                    \
     switch (c->NPL) {                                                                                          \
     case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
@@ -857,7 +486,7 @@ namespace {
 // ℓ and ∇ℓ of `q` ([C][Dpad], device) for all chains through the host's callback: lq -> c->lr.S1, grad -> c->rb.tbuf
 // `active` (the logistic family's GEMM evaluation only): the rows of the chains in a leaf phase, listed in c->lr.act by the caller —
 // the round loops pass it, so that chains which have finished their transitions are not multiplied
-int external_eval(dhmc_ctx* c, const double* q, bool active = false) {
+int external_eval(dhmc_ctx* c, const double* q, bool active) {
     if (c->logistic_batched) {
         // the GEMM gradient of the logistic round engine over all chains (logistic_rounds.hpp), folded by builtin_logistic_fold_kernel
         const int C = c->cfg.chains, ld = c->Dpad, npad = (int)c->tp.npad;
@@ -898,17 +527,8 @@ int external_eval(dhmc_ctx* c, const double* q, bool active = false) {
     if (rc != 0) { c->err = "DHMC_TARGET_EXTERNAL: the callback returned " + std::to_string(rc); return DHMC_ERR_CALLBACK; }
     return DHMC_OK;
 }
-#define DHMC_EXT_NPL(KERNEL, GRID, ...)                                                                        \
-    switch (c->NPL) {                                                                                          \
-    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;               \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
-    default: hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(WAVE), 0, c->stream, __VA_ARGS__); break;             \
-    }
-}  // namespace
+}  // namespace capi
+extern "C" {
 
 int dhmc_set_logdensity_callback(dhmc_ctx* c, dhmc_logdensity_fn fn, void* user) {
     if (!c || !c->external || c->builtin_big) return DHMC_ERR_INVALID_ARGUMENT;
@@ -982,80 +602,6 @@ int dhmc_get_position(dhmc_ctx* c, double* q, double* lq, double* grad, int on_d
     if (lq && (rc = copy_out_scalar(c, c->st.lq, lq, sizeof(double) * c->cfg.chains, on_device))) return rc;
     return DHMC_OK;
 }
-
-int dhmc_set_metric_diag(dhmc_ctx* c, const double* minv, int per_chain, int on_device) {
-    if (!c || !minv || c->cfg.metric != DHMC_METRIC_DIAG) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int D = c->cfg.dim, C = c->cfg.chains;
-    const size_t n = per_chain ? (size_t)C * D : (size_t)D;
-    if (!on_device) {
-        for (size_t i = 0; i < n; ++i)
-            if (!(minv[i] > 0) || !std::isfinite(minv[i])) return DHMC_ERR_INVALID_ARGUMENT;
-    } else {                                   // the same @argcheck (hamiltonian.jl:63) for a device array
-        DevBuf flag;
-        int bad = 0;
-        HIP_TRY(c, hipMalloc(&flag.p, sizeof(int)));
-        HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(check_positive_finite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, minv, n, (int*)flag.p);
-        HIP_TRY(c, hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (bad) return DHMC_ERR_INVALID_ARGUMENT;
-    }
-    Staged s;
-    int rc = stage_in(c, minv, n * sizeof(double), on_device, &s);
-    if (rc) return rc;
-    size_t tot = (size_t)C * c->Dpad;
-    hipLaunchKernelGGL(set_metric_diag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, D, c->Dpad, C,
-                       (const double*)s.dev, per_chain, c->st.minv, c->st.W);
-    HIP_TRY(c, hipGetLastError());
-    stage_free(c, &s);
-    return DHMC_OK;
-}
-
-int dhmc_get_metric_diag(dhmc_ctx* c, double* minv, int on_device) {
-    if (!c || !minv) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return copy_out_padded(c, c->st.minv, minv, on_device);
-}
-
-int dhmc_set_metric_dense(dhmc_ctx* c, const double* minv, int on_device) {
-    if (!c || !minv || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int D = c->cfg.dim;
-    Staged s;
-    int rc = stage_in(c, minv, sizeof(double) * (size_t)D * D, on_device, &s);
-    if (rc) return rc;
-    rc = device_dense_metric(c, (const double*)s.dev, D);      // symmetrise, check, factorise: all on the device
-    stage_free(c, &s);
-    return rc;
-}
-
-int dhmc_set_dense_products(dhmc_ctx* c, int32_t products) {
-    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || (products != 1 && products != 2)) return DHMC_ERR_INVALID_ARGUMENT;
-    c->dense_products = products;
-    return DHMC_OK;
-}
-int dhmc_get_dense_products(const dhmc_ctx* c) { return (c && c->cfg.metric == DHMC_METRIC_DENSE) ? c->dense_products : 0; }
-
-int dhmc_get_metric_dense_chain(dhmc_ctx* c, int32_t chain, double* minv, double* W) {
-    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || chain < 0 || chain >= c->cfg.chains) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int D = c->cfg.dim;
-    const size_t Dp = c->Dpad;
-    const size_t off = c->per_chain_dense ? (size_t)chain * Dp * Dp : 0;
-    std::vector<double> a(Dp * Dp), b(Dp * Dp);
-    HIP_TRY(c, hipMemcpyAsync(a.data(), c->d_Minv + off, a.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b.data(), c->d_WT + off, b.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) {
-            if (minv) minv[(size_t)i * D + j] = a[(size_t)i * Dp + j];
-            if (W) W[(size_t)i * D + j] = b[(size_t)j * Dp + i];
-        }
-    return DHMC_OK;
-}
-
-int dhmc_get_metric_dense(dhmc_ctx* c, double* minv, double* W) { return dhmc_get_metric_dense_chain(c, 0, minv, W); }
 
 int dhmc_set_stepsize(dhmc_ctx* c, const double* eps, int per_chain, int on_device) {
     if (!c || !eps) return DHMC_ERR_INVALID_ARGUMENT;
@@ -1661,580 +1207,6 @@ int dhmc_run(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     if (lr != DHMC_OK) return lr;
     HIP_TRY(c, se);
     c->last_ms = ms; c->last_leapfrogs = leapfrogs; c->last_rounds = rounds;
-    return rc;
-}
-
-int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
-    if (!c || !draws || c->cfg.metric != DHMC_METRIC_DIAG) return DHMC_ERR_INVALID_ARGUMENT;
-    if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192 (N >= 20 is the host wrapper's check)
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    Staged s;
-    int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * c->cfg.dim, on_device, &s);
-    if (rc) return rc;
-    launch_metric(c, (const double*)s.dev, n);
-    HIP_TRY(c, hipGetLastError());
-    stage_free(c, &s);
-    return DHMC_OK;
-}
-
-int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
-    if (!c || !draws || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
-    if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int D = c->cfg.dim, ld = c->Dpad;
-    // shared M⁻¹: one estimate from the pooled draws of all chains; per-chain: every chain from its own n draws (mcmc.jl:281-285)
-    const int nest = c->per_chain_dense ? c->cfg.chains : 1;
-    const int64_t J = c->per_chain_dense ? n : (int64_t)c->cfg.chains * n;
-    Staged s;
-    int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s);
-    if (rc) return rc;
-    int refused = 0, first_refused = -1;
-    if (!c->per_chain_dense) {
-        DevBuf bmean, bS;
-        HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
-        HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld));
-        double* const mean = (double*)bmean.p;
-        double* const S = (double*)bS.p;
-        const double* x = (const double*)s.dev;
-        double Jtot = (double)J;
-        if (!c->metric_allreduce) {
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0, 0);
-            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
-        } else {
-            // job-wide estimate (include/dhmc.h dhmc_set_metric_allreduce): column sums + row count over the ranks, then the
-            // scatter about the job's mean over the ranks; `mean` has Dpad >= D + 1 slots except when D is a multiple of 64
-            DevBuf bsum;
-            HIP_TRY(c, hipMalloc(&bsum.p, sizeof(double) * (size_t)(D + 1)));
-            double* const sums = (double*)bsum.p;
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, sums, (size_t)0, (size_t)0, 1);
-            HIP_TRY(c, hipMemcpyAsync(sums + D, &Jtot, sizeof(double), hipMemcpyHostToDevice, c->stream));
-            if (c->metric_allreduce(c->metric_allreduce_user, sums, (int64_t)D + 1, (void*)c->stream) != 0) {
-                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (column sums)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
-            }
-            HIP_TRY(c, hipMemcpyAsync(&Jtot, sums + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            hipLaunchKernelGGL(pooled_mean_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, sums);
-            HIP_TRY(c, hipMemcpyAsync(mean, sums, sizeof(double) * (size_t)D, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
-            if (c->metric_allreduce(c->metric_allreduce_user, S, (int64_t)ld * ld, (void*)c->stream) != 0) {
-                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (scatter matrix)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
-            }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));       // Jtot is on the host now
-            if (!(Jtot >= 2.0)) { stage_free(c, &s); return DHMC_ERR_INVALID_ARGUMENT; }
-        }
-        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, (int64_t)Jtot, lambda, S, (size_t)0);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }
-        else rc = device_dense_metric(c, S, ld, -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
-    } else {
-        // per-chain metrics (mcmc.jl:281-285 runs per chain): estimate, regularise and factorise a BATCH of chains per launch
-        // (blockIdx.z = chain; the same kernels, so the same bits as chain by chain), ≈ 1 GiB of work space at a time.  Every chain
-        // stands for itself: one whose estimate is refused keeps its metric, the others are updated all the same.
-        const size_t n = (size_t)ld * ld;
-        const int Bmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)nest, ((size_t)1 << 30) / (5 * n * sizeof(double))));
-        DevBuf bmean, bS, bwork, bflags;
-        HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * (size_t)Bmax * ld));
-        HIP_TRY(c, hipMalloc(&bS.p, sizeof(double) * (size_t)Bmax * n * 2));          // the estimates, and Symmetric(estimate)
-        HIP_TRY(c, hipMalloc(&bwork.p, sizeof(double) * (size_t)Bmax * n * 3));
-        HIP_TRY(c, hipMalloc(&bflags.p, sizeof(int) * 2 * (size_t)Bmax));
-        double* const mean = (double*)bmean.p;
-        double* const S = (double*)bS.p;
-        double* const Ssym = S + (size_t)Bmax * n;
-        double* const work = (double*)bwork.p;
-        int* const flags = (int*)bflags.p;
-        std::vector<int> hflags(2 * (size_t)Bmax);
-        for (int k0 = 0; k0 < nest && rc == DHMC_OK; k0 += Bmax) {
-            const int B = std::min(Bmax, nest - k0);
-            const unsigned Bz = (unsigned)B;
-            const double* x = (const double*)s.dev + (size_t)k0 * J * D;
-            HIP_TRY(c, hipMemsetAsync(flags, 0, sizeof(int) * 2 * (size_t)B, c->stream));
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256, 1, Bz), dim3(256), 0, c->stream, D, J, x, mean, (size_t)J * D, (size_t)ld, 0);
-            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64, Bz), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)J * D, (size_t)ld, n);
-            hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256), 1, Bz), dim3(256), 0, c->stream, D, ld, J, lambda, S, n);
-            hipLaunchKernelGGL(df_symmetrize_kernel, dim3((unsigned)((n + 255) / 256), 1, Bz), dim3(256), 0, c->stream, (const double*)S, ld, D, Ssym, ld,
-                               flags, n, n);
-            double* const WTb = work + (size_t)B * n;                                  // the X buffers: free again once M = XᵀX exists
-            df_dense_metric(Ssym, Ssym, WTb, D, ld, work, flags, c->stream, B);
-            hipLaunchKernelGGL(df_commit_kernel, dim3((unsigned)((n + 255) / 256), 1, Bz), dim3(256), 0, c->stream, (const double*)Ssym, (const double*)WTb,
-                               (const int*)flags, c->d_Minv + (size_t)k0 * n, c->d_WT + (size_t)k0 * n, n);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; break; }
-            HIP_TRY(c, hipMemcpyAsync(hflags.data(), flags, sizeof(int) * 2 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            for (int b2 = 0; b2 < B; ++b2)
-                if (hflags[2 * b2] || hflags[2 * b2 + 1]) { if (refused++ == 0) first_refused = k0 + b2; }
-        }
-    }
-    stage_free(c, &s);
-    if (rc == DHMC_OK && refused) {
-        c->err = "dhmc_update_metric_dense: the covariance estimate of " + std::to_string(refused) + " chain(s) (first: chain " +
-                 std::to_string(first_refused) + ") is not finite / positive definite; those chains keep their metric";
-        return DHMC_ERR_INVALID_ARGUMENT;
-    }
-    return rc;
-}
-
-int dhmc_set_metric_allreduce(dhmc_ctx* c, dhmc_allreduce_fn fn, void* user) {
-    if (!c || c->cfg.metric != DHMC_METRIC_DENSE || c->per_chain_dense) return DHMC_ERR_INVALID_ARGUMENT;   // a shared dense metric is what is pooled
-    c->metric_allreduce = fn;
-    c->metric_allreduce_user = fn ? user : nullptr;
-    return DHMC_OK;
-}
-
-// ---- resume blob: header + raw images of the per-chain arrays -------------------------------
-struct BlobHeader {
-    uint64_t magic;
-    int32_t dim, chains, Dpad, reserved;
-};
-static const uint64_t BLOB_MAGIC = 0x31434d4844ull;  // "DHMC1"
-
-// ---- Diagnostics probes (probe_kernels.hpp) ---------------------------------------------------
-namespace {
-int probe_finish(dhmc_ctx* c, const DevBuf& dst, uint32_t* status) {
-    const int C = c->cfg.chains;
-    std::vector<uint32_t> st(C);
-    HIP_TRY(c, hipMemcpyAsync(st.data(), dst.p, sizeof(uint32_t) * C, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = DHMC_OK;
-    for (int i = 0; i < C; ++i) {
-        if (status) status[i] = st[i];
-        if (st[i]) rc = DHMC_ERR_CHAIN_FAILURE;
-    }
-    return rc;
-}
-
-// the same two probes for a model evaluated by the host's callback (external_rounds.hpp): lock-step leapfrogs of all chains
-struct ExtProbe {
-    DevBuf rows[8], pi0, lq, alive;
-    ExtProbeParams E{};
-    dhmc_ctx* c = nullptr;
-    int init(dhmc_ctx* ctx, uint32_t* d_status) {
-        c = ctx;
-        const size_t C = c->cfg.chains, n = C * c->Dpad;
-        for (DevBuf& b : rows) {
-            HIP_TRY(c, hipMalloc(&b.p, sizeof(double) * n));
-            HIP_TRY(c, hipMemsetAsync(b.p, 0, sizeof(double) * n, c->stream));
-        }
-        HIP_TRY(c, hipMalloc(&pi0.p, sizeof(double) * C));
-        HIP_TRY(c, hipMalloc(&lq.p, sizeof(double) * C));
-        HIP_TRY(c, hipMalloc(&alive.p, sizeof(int32_t) * C));
-        HIP_TRY(c, hipMemsetAsync(d_status, 0, sizeof(uint32_t) * C, c->stream));
-        E.D = c->cfg.dim; E.Dpad = c->Dpad; E.C = (int)C; E.chain_offset = c->cfg.chain_offset; E.seed = c->cfg.seed; E.st = c->st;
-        E.q = (double*)rows[0].p; E.p = (double*)rows[1].p; E.g = (double*)rows[2].p; E.pm = (double*)rows[3].p;
-        E.trial = (double*)rows[4].p; E.ps = (double*)rows[5].p; E.p0 = (double*)rows[6].p; E.ps0 = (double*)rows[7].p;
-        E.pi0 = (double*)pi0.p; E.lq_cur = (double*)lq.p; E.alive = (int32_t*)alive.p; E.status = d_status;
-        E.lq_in = c->lr.S1; E.grad_in = c->rb.tbuf; E.dense = c->cfg.metric == DHMC_METRIC_DENSE;
-        return DHMC_OK;
-    }
-    // p₀ (the caller's m-th momentum, or rand_p from the chains' streams), p₀♯, π₀
-    int momentum(const double* d_p_in, int n_mom, int m, uint32_t momentum_index, bool ratios) {
-        const int C = E.C, ld = E.Dpad;
-        if (E.dense && !d_p_in) {                      // z into pₘ's row (free here), p₀ = z·Wᵀ
-            ExtProbeParams Z = E;
-            Z.p0 = E.pm;
-            DHMC_EXT_NPL(ext_probe_momentum_kernel, dim3(C), Z, d_p_in, n_mom, m, momentum_index)
-            launch_gemm_rows(E.pm, c->d_WT, E.p0, ld, C, nullptr, nullptr, c->stream);
-        } else {
-            DHMC_EXT_NPL(ext_probe_momentum_kernel, dim3(C), E, d_p_in, n_mom, m, momentum_index)
-        }
-        if (E.dense) launch_gemm_rows(E.p0, c->d_Minv, E.ps0, ld, C, nullptr, nullptr, c->stream);
-        DHMC_EXT_NPL(ext_probe_start_kernel, dim3(C), E, (int)ratios)
-        return DHMC_OK;
-    }
-    void restart(bool ratios) { DHMC_EXT_NPL(ext_probe_restart_kernel, dim3(E.C), E, (int)ratios) }
-    int step(double eps) {                             // one leapfrog of every chain that still steps
-        const int C = E.C, ld = E.Dpad;
-        DHMC_EXT_NPL(ext_probe_half_kernel, dim3(C), E, eps)
-        if (E.dense) {
-            launch_gemm_rows(E.pm, c->d_Minv, E.ps, ld, C, nullptr, nullptr, c->stream);
-            DHMC_EXT_NPL(ext_probe_pos_kernel, dim3(C), E, eps)
-        }
-        if (int rc = external_eval(c, E.trial)) return rc;
-        DHMC_EXT_NPL(ext_probe_finish_kernel, dim3(C), E, eps)
-        if (E.dense) launch_gemm_rows(E.p, c->d_Minv, E.ps, ld, C, nullptr, nullptr, c->stream);
-        return DHMC_OK;
-    }
-    void record(int idx, int npos, int pos, bool start, double* od, double* ol, double* oq, double* op, int32_t* orange) {
-        DHMC_EXT_NPL(ext_probe_record_kernel, dim3(E.C), E, idx, npos, pos, (int)start, od, ol, oq, op, orange)
-    }
-};
-}  // namespace
-
-int dhmc_leapfrog_trajectory(dhmc_ctx* c, double eps, int32_t first, int32_t last, uint32_t momentum_index,
-                             const double* p, double* delta, double* logdensity, double* q_out, double* p_out,
-                             int32_t* range, uint32_t* status) {
-    if (!c || !delta || !logdensity) return DHMC_ERR_INVALID_ARGUMENT;
-    if (!(first <= 0 && 0 <= last)) return DHMC_ERR_INVALID_ARGUMENT;   // diagnostics.jl:218
-    if (c->external) DHMC_CHECK_USABLE(c);
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int C = c->cfg.chains, D = c->cfg.dim;
-    const size_t npos = (size_t)last - first + 1;
-    DevBuf dp, dd, dl, dq, dpo, dr, dst;
-    HIP_TRY(c, hipMalloc(&dd.p, sizeof(double) * C * npos));
-    HIP_TRY(c, hipMalloc(&dl.p, sizeof(double) * C * npos));
-    HIP_TRY(c, hipMalloc(&dr.p, sizeof(int32_t) * 2 * C));
-    HIP_TRY(c, hipMalloc(&dst.p, sizeof(uint32_t) * C));
-    // positions that are not visited stay NaN (all-ones bit pattern)
-    HIP_TRY(c, hipMemsetAsync(dd.p, 0xFF, sizeof(double) * C * npos, c->stream));
-    HIP_TRY(c, hipMemsetAsync(dl.p, 0xFF, sizeof(double) * C * npos, c->stream));
-    if (q_out) {
-        HIP_TRY(c, hipMalloc(&dq.p, sizeof(double) * C * npos * D));
-        HIP_TRY(c, hipMemsetAsync(dq.p, 0xFF, sizeof(double) * C * npos * D, c->stream));
-    }
-    if (p_out) {
-        HIP_TRY(c, hipMalloc(&dpo.p, sizeof(double) * C * npos * D));
-        HIP_TRY(c, hipMemsetAsync(dpo.p, 0xFF, sizeof(double) * C * npos * D, c->stream));
-    }
-    if (p) {
-        HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * D));
-        HIP_TRY(c, hipMemcpyAsync(dp.p, p, sizeof(double) * C * D, hipMemcpyHostToDevice, c->stream));
-    }
-    if (c->external || c->logistic_batched) {   // the density is evaluated for all chains between kernels: one batched evaluation per step
-        ExtProbe X;
-        int rc;
-        if ((rc = X.init(c, (uint32_t*)dst.p))) return rc;
-        HIP_TRY(c, hipMemsetAsync(dr.p, 0, sizeof(int32_t) * 2 * C, c->stream));
-        if ((rc = X.momentum((const double*)dp.p, 1, 0, momentum_index, false))) return rc;
-        X.restart(false);
-        X.record(-first, (int)npos, 0, true, (double*)dd.p, (double*)dl.p, (double*)dq.p, (double*)dpo.p, (int32_t*)dr.p);
-        for (int dir = 0; dir < 2; ++dir) {
-            const double e = dir == 0 ? eps : -eps;                          // diagnostics.jl:223,225
-            const int count = dir == 0 ? last : -first;
-            X.restart(false);
-            for (int i = 1; i <= count; ++i) {
-                if ((rc = X.step(e))) return rc;
-                const int pos = dir == 0 ? i : -i;
-                X.record(pos - first, (int)npos, pos, false, (double*)dd.p, (double*)dl.p, (double*)dq.p, (double*)dpo.p, (int32_t*)dr.p);
-            }
-        }
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(delta, dd.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(logdensity, dl.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
-        if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, dq.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
-        if (p_out) HIP_TRY(c, hipMemcpyAsync(p_out, dpo.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
-        if (range) HIP_TRY(c, hipMemcpyAsync(range, dr.p, sizeof(int32_t) * 2 * C, hipMemcpyDeviceToHost, c->stream));
-        return probe_finish(c, dst, status);
-    }
-    ProbeParams P{};
-    P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset; P.seed = c->cfg.seed;
-    P.st = c->st; P.tp = c->tp; P.momentum_index = momentum_index; P.p_in = (const double*)dp.p; P.n_mom = 1;
-    P.eps = eps; P.first = first; P.last = last;
-    P.out_delta = (double*)dd.p; P.out_lq = (double*)dl.p; P.out_q = (double*)dq.p; P.out_p = (double*)dpo.p;
-    P.out_range = (int32_t*)dr.p; P.out_status = (uint32_t*)dst.p;
-    int rc = dispatch(c, Op::ProbeTrajectory, &P);
-    if (rc) return rc;
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(delta, dd.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(logdensity, dl.p, sizeof(double) * C * npos, hipMemcpyDeviceToHost, c->stream));
-    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, dq.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
-    if (p_out) HIP_TRY(c, hipMemcpyAsync(p_out, dpo.p, sizeof(double) * C * npos * D, hipMemcpyDeviceToHost, c->stream));
-    if (range) HIP_TRY(c, hipMemcpyAsync(range, dr.p, sizeof(int32_t) * 2 * C, hipMemcpyDeviceToHost, c->stream));
-    return probe_finish(c, dst, status);
-}
-
-int dhmc_explore_log_acceptance_ratios(dhmc_ctx* c, const double* eps, int32_t n_eps, int32_t n_momenta,
-                                       uint32_t momentum_index, const double* ps, double* out, uint32_t* status) {
-    if (!c || !eps || !out || n_eps <= 0 || n_momenta <= 0) return DHMC_ERR_INVALID_ARGUMENT;
-    if (c->external) DHMC_CHECK_USABLE(c);
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int C = c->cfg.chains, D = c->cfg.dim;
-    const size_t nout = (size_t)C * n_momenta * n_eps;
-    DevBuf de, dp, dout, dst;
-    HIP_TRY(c, hipMalloc(&de.p, sizeof(double) * n_eps));
-    HIP_TRY(c, hipMalloc(&dout.p, sizeof(double) * nout));
-    HIP_TRY(c, hipMalloc(&dst.p, sizeof(uint32_t) * C));
-    HIP_TRY(c, hipMemcpyAsync(de.p, eps, sizeof(double) * n_eps, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(dout.p, 0xFF, sizeof(double) * nout, c->stream));
-    if (ps) {
-        HIP_TRY(c, hipMalloc(&dp.p, sizeof(double) * C * n_momenta * D));
-        HIP_TRY(c, hipMemcpyAsync(dp.p, ps, sizeof(double) * C * n_momenta * D, hipMemcpyHostToDevice, c->stream));
-    }
-    if (c->external || c->logistic_batched) {
-        ExtProbe X;
-        int rc;
-        if ((rc = X.init(c, (uint32_t*)dst.p))) return rc;
-        for (int m = 0; m < n_momenta; ++m) {
-            if ((rc = X.momentum((const double*)dp.p, n_momenta, m, momentum_index, true))) return rc;
-            for (int e = 0; e < n_eps; ++e) {
-                X.restart(true);
-                if ((rc = X.step(eps[e]))) return rc;
-                X.record(m * n_eps + e, n_momenta * n_eps, 0, false, (double*)dout.p, nullptr, nullptr, nullptr, nullptr);
-            }
-        }
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(out, dout.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
-        return probe_finish(c, dst, status);
-    }
-    ProbeParams P{};
-    P.D = D; P.Dpad = c->Dpad; P.C = C; P.chain_offset = c->cfg.chain_offset; P.seed = c->cfg.seed;
-    P.st = c->st; P.tp = c->tp; P.momentum_index = momentum_index; P.p_in = (const double*)dp.p; P.n_mom = n_momenta;
-    P.eps_list = (const double*)de.p; P.n_eps = n_eps; P.out_delta = (double*)dout.p; P.out_status = (uint32_t*)dst.p;
-    int rc = dispatch(c, Op::ProbeRatios, &P);
-    if (rc) return rc;
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(out, dout.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
-    return probe_finish(c, dst, status);
-}
-
-// ESS and R-hat of `ncoords` series sets laid out as draws[C][n][dim] (ess_kernels.hpp): n <= ESS_LDS_MAX_N with the whole series in LDS,
-// longer series from HBM a chunk of lags at a time.  de / dr: device [ncoords].  DHMC_ESS_LONG=1 forces the long path (tests).
-namespace {
-struct EssWork {
-    DevBuf da, dm, dx, dst;
-    bool long_series = false;
-    int prepare(int64_t chains, int64_t n, int ncoords) {
-        const char* e = std::getenv("DHMC_ESS_LONG");
-        const bool force_long = e && std::atoi(e) != 0;
-        long_series = n > ESS_LDS_MAX_N || force_long;
-        const size_t nseries = (size_t)ncoords * chains;
-        if (nseries > 0x7fffffffull) return DHMC_ERR_UNSUPPORTED;
-        if (hipMalloc(&dm.p, sizeof(double) * nseries) != hipSuccess) return DHMC_ERR_HIP;
-        if (!long_series) return hipMalloc(&da.p, sizeof(double) * nseries * n) == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
-        if (hipMalloc(&dx.p, sizeof(double) * nseries * n) != hipSuccess || hipMalloc(&da.p, sizeof(double) * nseries * ESS_LAG_CHUNK) != hipSuccess ||
-            hipMalloc(&dst.p, sizeof(EssState) * ncoords) != hipSuccess)
-            return DHMC_ERR_HIP;
-        return DHMC_OK;
-    }
-};
-// the short path only enqueues work on s; the long path returns with the stream drained
-int ess_estimate(EssWork& w, hipStream_t s, const double* draws, int64_t chains, int64_t n, int64_t dim, const int32_t* d_coords, int ncoords,
-                 double* de, double* dr) {
-    if (!w.long_series) {
-        hipLaunchKernelGGL(ess_acov_kernel, dim3(ncoords, (unsigned)chains), dim3(ESS_THREADS), sizeof(double) * n, s, draws, n, dim,
-                           d_coords, chains, (double*)w.da.p, (double*)w.dm.p);
-        hipLaunchKernelGGL(ess_finish_kernel, dim3(ncoords), dim3(ESS_THREADS), sizeof(double) * n, s, (const double*)w.da.p,
-                           (const double*)w.dm.p, n, chains, de, dr);
-        return hipGetLastError() == hipSuccess ? DHMC_OK : DHMC_ERR_HIP;
-    }
-    const size_t nseries = (size_t)ncoords * chains;
-    hipLaunchKernelGGL(ess_center_kernel, dim3(ncoords, (unsigned)chains), dim3(ESS_THREADS), 0, s, draws, n, dim, d_coords, chains,
-                       (double*)w.dx.p, (double*)w.dm.p);
-    std::vector<EssState> st(ncoords);
-    for (int64_t t0 = 0; t0 < n; t0 += ESS_LAG_CHUNK) {
-        hipLaunchKernelGGL(ess_acov_lags_kernel, dim3((unsigned)nseries, ESS_LAG_CHUNK / ESS_THREADS), dim3(ESS_THREADS), 0, s,
-                           (const double*)w.dx.p, n, t0, (double*)w.da.p);
-        hipLaunchKernelGGL(ess_finish_chunk_kernel, dim3(ncoords), dim3(ESS_THREADS), 0, s, (const double*)w.da.p, (const double*)w.dm.p, n,
-                           chains, t0, (EssState*)w.dst.p, de, dr);
-        if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
-        if (hipMemcpyAsync(st.data(), w.dst.p, sizeof(EssState) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-        if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
-        bool all = true;
-        for (const EssState& e : st) all = all && e.done;
-        if (all) break;
-    }
-    return DHMC_OK;
-}
-}  // namespace
-
-int dhmc_ess_rhat(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
-                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat) {
-    if (!draws || !coords || !ess || !rhat || chains < 1 || n < 4 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
-    for (int i = 0; i < ncoords; ++i)
-        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    DevBuf dc, de, dr;
-    EssWork work;
-    if (int rc = work.prepare(chains, n, ncoords)) return rc;
-    if (hipMalloc(&dc.p, sizeof(int32_t) * ncoords) != hipSuccess || hipMalloc(&de.p, sizeof(double) * ncoords) != hipSuccess ||
-        hipMalloc(&dr.p, sizeof(double) * ncoords) != hipSuccess)
-        return DHMC_ERR_HIP;
-    if (hipMemcpyAsync(dc.p, coords, sizeof(int32_t) * ncoords, hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (int rc = ess_estimate(work, s, draws, chains, n, dim, (const int32_t*)dc.p, ncoords, (double*)de.p, (double*)dr.p)) return rc;
-    if (hipMemcpyAsync(ess, de.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (hipMemcpyAsync(rhat, dr.p, sizeof(double) * ncoords, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
-    return DHMC_OK;
-}
-
-int dhmc_ess_bulk(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
-                  const int32_t* coords, int32_t ncoords, double* ess, double* rhat) {
-    if (!draws || !coords || !ess || !rhat || chains < 1 || n < 8 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
-    const int64_t half = n / 2, N2 = 2 * half, S = chains * N2, C2 = 2 * chains;
-    if (S > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
-    for (int i = 0; i < ncoords; ++i)
-        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    DevBuf dk, dk2, di, di2, dz, de, dr, dtmp, dc0;
-    EssWork work;
-    if (int rc = work.prepare(C2, half, 1)) return rc;
-    size_t tmp_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
-                                           (int32_t*)nullptr, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
-    const int32_t zero = 0;
-    if (hipMalloc(&dk.p, sizeof(double) * S) != hipSuccess || hipMalloc(&dk2.p, sizeof(double) * S) != hipSuccess ||
-        hipMalloc(&di.p, sizeof(int32_t) * S) != hipSuccess || hipMalloc(&di2.p, sizeof(int32_t) * S) != hipSuccess ||
-        hipMalloc(&dz.p, sizeof(double) * S) != hipSuccess || hipMalloc(&de.p, sizeof(double)) != hipSuccess ||
-        hipMalloc(&dr.p, sizeof(double)) != hipSuccess || hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess ||
-        hipMalloc(&dc0.p, sizeof(int32_t)) != hipSuccess)
-        return DHMC_ERR_HIP;
-    if (hipMemcpyAsync(dc0.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
-    const unsigned nb = (unsigned)((S + 255) / 256);
-    for (int j = 0; j < ncoords; ++j) {
-        hipLaunchKernelGGL(ess_gather_kernel, dim3(nb), dim3(256), 0, s, draws, n, dim, coords[j], chains, N2, (double*)dk.p, (int32_t*)di.p);
-        if (hipcub::DeviceRadixSort::SortPairs(dtmp.p, tmp_bytes, (const double*)dk.p, (double*)dk2.p, (const int32_t*)di.p,
-                                               (int32_t*)di2.p, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
-        hipLaunchKernelGGL(ess_rank_kernel, dim3(nb), dim3(256), 0, s, (const double*)dk2.p, (const int32_t*)di2.p, S, (double*)dz.p);
-        // z is [2C][N'][1]: the estimator of dhmc_ess_rhat on one "coordinate"
-        if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
-        if (int rc = ess_estimate(work, s, (const double*)dz.p, C2, half, 1, (const int32_t*)dc0.p, 1, (double*)de.p, (double*)dr.p)) return rc;
-        if (hipMemcpyAsync(ess + j, de.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-        if (hipMemcpyAsync(rhat + j, dr.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    }
-    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
-    return DHMC_OK;
-}
-
-int dhmc_ess_tail(int32_t device, void* stream, const double* draws, int64_t chains, int64_t n, int64_t dim,
-                  const int32_t* coords, int32_t ncoords, double* ess) {
-    if (!draws || !coords || !ess || chains < 1 || n < 8 || dim < 1 || ncoords < 1) return DHMC_ERR_INVALID_ARGUMENT;
-    const int64_t half = n / 2, N2 = 2 * half, S = chains * N2, C2 = 2 * chains;
-    if (S > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
-    for (int i = 0; i < ncoords; ++i)
-        if (coords[i] < 0 || coords[i] >= dim) return DHMC_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    DevBuf dk, dk2, di, di2, dz, de, dr, dtmp, dc0;
-    EssWork work;
-    if (int rc = work.prepare(C2, half, 1)) return rc;
-    size_t tmp_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
-                                           (int32_t*)nullptr, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
-    const int32_t zero = 0;
-    if (hipMalloc(&dk.p, sizeof(double) * S) != hipSuccess || hipMalloc(&dk2.p, sizeof(double) * S) != hipSuccess ||
-        hipMalloc(&di.p, sizeof(int32_t) * S) != hipSuccess || hipMalloc(&di2.p, sizeof(int32_t) * S) != hipSuccess ||
-        hipMalloc(&dz.p, sizeof(double) * S) != hipSuccess || hipMalloc(&de.p, sizeof(double) * 2) != hipSuccess ||
-        hipMalloc(&dr.p, sizeof(double)) != hipSuccess || hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess ||
-        hipMalloc(&dc0.p, sizeof(int32_t)) != hipSuccess)
-        return DHMC_ERR_HIP;
-    if (hipMemcpyAsync(dc0.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
-    const unsigned nb = (unsigned)((S + 255) / 256);
-    std::vector<double> both((size_t)ncoords * 2);
-    for (int j = 0; j < ncoords; ++j) {
-        hipLaunchKernelGGL(ess_gather_kernel, dim3(nb), dim3(256), 0, s, draws, n, dim, coords[j], chains, N2, (double*)dk.p, (int32_t*)di.p);
-        if (hipcub::DeviceRadixSort::SortPairs(dtmp.p, tmp_bytes, (const double*)dk.p, (double*)dk2.p, (const int32_t*)di.p,
-                                               (int32_t*)di2.p, (int)S, 0, 64, s) != hipSuccess) return DHMC_ERR_HIP;
-        for (int upper = 0; upper < 2; ++upper) {
-            hipLaunchKernelGGL(ess_tail_indicator_kernel, dim3(nb), dim3(256), 0, s, (const double*)dk2.p, (const int32_t*)di2.p, S, upper, (double*)dz.p);
-            if (int rc = ess_estimate(work, s, (const double*)dz.p, C2, half, 1, (const int32_t*)dc0.p, 1, (double*)de.p + upper, (double*)dr.p)) return rc;
-        }
-        if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
-        if (hipMemcpyAsync(both.data() + 2 * j, de.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-        if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;     // (de is reused by the next coordinate)
-    }
-    for (int j = 0; j < ncoords; ++j) ess[j] = std::min(both[2 * j], both[2 * j + 1]);
-    return DHMC_OK;
-}
-
-int dhmc_summarize_tree_statistics(int32_t device, void* stream, const double* pi, const double* acceptance_rate,
-                                   const int64_t* term_left, const int64_t* term_right, const int32_t* depth,
-                                   int64_t chains, int64_t n, int on_device, dhmc_tree_statistics_summary* summary,
-                                   double* ebfmi) {
-    if (!pi || !acceptance_rate || !term_left || !term_right || !depth || !summary || chains < 1 || n < 1) return DHMC_ERR_INVALID_ARGUMENT;
-    const int64_t total = chains * n;
-    if (total > 0x7fffffffll) return DHMC_ERR_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    DevBuf in[5], dsum, deb, dcnt, dsorted, dtmp, dout;
-    const void* src[5] = {pi, acceptance_rate, term_left, term_right, depth};
-    const size_t esz[5] = {8, 8, 8, 8, 4};
-    const void* dev[5];
-    for (int i = 0; i < 5; ++i) {
-        dev[i] = src[i];
-        if (!on_device) {
-            if (hipMalloc(&in[i].p, esz[i] * total) != hipSuccess) return DHMC_ERR_HIP;
-            if (hipMemcpyAsync(in[i].p, src[i], esz[i] * total, hipMemcpyHostToDevice, s) != hipSuccess) return DHMC_ERR_HIP;
-            dev[i] = in[i].p;
-        }
-    }
-    size_t tmp_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (int)total, 0, 64, s) != hipSuccess)
-        return DHMC_ERR_HIP;
-    const size_t ncnt = 3 + TS_DEPTH_BINS;
-    if (hipMalloc(&dsum.p, sizeof(double) * chains) != hipSuccess || hipMalloc(&deb.p, sizeof(double) * chains) != hipSuccess ||
-        hipMalloc(&dcnt.p, sizeof(unsigned long long) * ncnt) != hipSuccess || hipMalloc(&dsorted.p, sizeof(double) * total) != hipSuccess ||
-        hipMalloc(&dtmp.p, tmp_bytes ? tmp_bytes : 8) != hipSuccess || hipMalloc(&dout.p, sizeof(double) * 6) != hipSuccess)
-        return DHMC_ERR_HIP;
-    if (hipMemsetAsync(dcnt.p, 0, sizeof(unsigned long long) * ncnt, s) != hipSuccess) return DHMC_ERR_HIP;
-    hipLaunchKernelGGL(treestat_chain_kernel, dim3((unsigned)chains), dim3(WAVE), 0, s, (const double*)dev[0], (const double*)dev[1],
-                       (const int64_t*)dev[2], (const int64_t*)dev[3], (const int32_t*)dev[4], n, (double*)deb.p, (double*)dsum.p,
-                       (unsigned long long*)dcnt.p);
-    if (hipcub::DeviceRadixSort::SortKeys(dtmp.p, tmp_bytes, (const double*)dev[1], (double*)dsorted.p, (int)total, 0, 64, s) != hipSuccess)
-        return DHMC_ERR_HIP;
-    hipLaunchKernelGGL(treestat_finish_kernel, dim3(1), dim3(WAVE), 0, s, (const double*)dsum.p, chains, total, (const double*)dsorted.p,
-                       (double*)dout.p);
-    if (hipGetLastError() != hipSuccess) return DHMC_ERR_HIP;
-    double out6[6];
-    unsigned long long cnt[3 + TS_DEPTH_BINS];
-    if (hipMemcpyAsync(out6, dout.p, sizeof(out6), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (hipMemcpyAsync(cnt, dcnt.p, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (ebfmi && hipMemcpyAsync(ebfmi, deb.p, sizeof(double) * chains, hipMemcpyDeviceToHost, s) != hipSuccess) return DHMC_ERR_HIP;
-    if (hipStreamSynchronize(s) != hipSuccess) return DHMC_ERR_HIP;
-    summary->n = total;
-    summary->a_mean = out6[0];
-    for (int i = 0; i < 5; ++i) summary->a_quantiles[i] = out6[1 + i];
-    summary->max_depth = (int64_t)cnt[0];
-    summary->divergence = (int64_t)cnt[1];
-    summary->turning = (int64_t)cnt[2];
-    for (int d = 0; d < TS_DEPTH_BINS; ++d) summary->depth_counts[d] = (int64_t)cnt[3 + d];
-    return DHMC_OK;
-}
-
-int dhmc_state_bytes(dhmc_ctx* c, uint64_t* nbytes) {
-    if (!c || !nbytes) return DHMC_ERR_INVALID_ARGUMENT;
-    const uint64_t C = c->cfg.chains, Dp = c->Dpad;
-    *nbytes = sizeof(BlobHeader) + 4 * C * Dp * sizeof(double) + 2 * C * sizeof(double) + C * sizeof(DAState) + 2 * C * sizeof(uint32_t);
-    if (c->cfg.metric == DHMC_METRIC_DENSE) *nbytes += (c->per_chain_dense ? C : 1) * 2 * Dp * Dp * sizeof(double);   // dense M⁻¹ and Wᵀ (shared, or one pair per chain)
-    return DHMC_OK;
-}
-
-static int blob_io(dhmc_ctx* c, char* blob, bool exporting) {
-    const size_t C = c->cfg.chains, Dp = c->Dpad;
-    char* p = blob + sizeof(BlobHeader);
-    auto io = [&](void* dev, size_t bytes) -> hipError_t {
-        hipError_t e = exporting ? hipMemcpy(p, dev, bytes, hipMemcpyDeviceToHost) : hipMemcpy(dev, p, bytes, hipMemcpyHostToDevice);
-        p += bytes;
-        return e;
-    };
-    HIP_TRY(c, io(c->st.q, C * Dp * sizeof(double)));
-    HIP_TRY(c, io(c->st.g, C * Dp * sizeof(double)));
-    HIP_TRY(c, io(c->st.minv, C * Dp * sizeof(double)));
-    HIP_TRY(c, io(c->st.W, C * Dp * sizeof(double)));
-    HIP_TRY(c, io(c->st.lq, C * sizeof(double)));
-    HIP_TRY(c, io(c->st.eps, C * sizeof(double)));
-    HIP_TRY(c, io(c->st.da, C * sizeof(DAState)));
-    HIP_TRY(c, io(c->st.transition, C * sizeof(uint32_t)));
-    HIP_TRY(c, io(c->st.status, C * sizeof(uint32_t)));
-    if (c->cfg.metric == DHMC_METRIC_DENSE) {
-        const size_t nmat = c->per_chain_dense ? C : 1;
-        HIP_TRY(c, io(c->d_Minv, nmat * Dp * Dp * sizeof(double)));
-        HIP_TRY(c, io(c->d_WT, nmat * Dp * Dp * sizeof(double)));
-    }
-    return DHMC_OK;
-}
-
-int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
-    uint64_t need;
-    if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
-    DHMC_CHECK_USABLE(c);
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    BlobHeader h{BLOB_MAGIC, c->cfg.dim, c->cfg.chains, c->Dpad, 0};
-    std::memcpy(host_blob, &h, sizeof(h));
-    return blob_io(c, (char*)host_blob, true);
-}
-
-int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
-    uint64_t need;
-    if (!c || !host_blob || dhmc_state_bytes(c, &need) || nbytes < need) return DHMC_ERR_INVALID_ARGUMENT;
-    BlobHeader h;
-    std::memcpy(&h, host_blob, sizeof(h));
-    if (h.magic != BLOB_MAGIC || h.dim != c->cfg.dim || h.chains != c->cfg.chains || h.Dpad != c->Dpad) return DHMC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->poisoned = true;    // a partially copied blob is no state
-    const int rc = blob_io(c, const_cast<char*>((const char*)host_blob), false);
-    if (rc == DHMC_OK) c->poisoned = false;
     return rc;
 }
 

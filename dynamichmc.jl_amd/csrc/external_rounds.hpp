@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void builtin_logistic_fold_kernel(int C, int ld
     const double lq = s1 - 0.5 * wave_allreduce1(qq.fold(0));
     if (lane == 0) lq_out[chain] = lq;
 }
-__global__ void builtin_all_rows_kernel(int C, int* __restrict__ act, int* __restrict__ act_count) {
+static __global__ void builtin_all_rows_kernel(int C, int* __restrict__ act, int* __restrict__ act_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) act[i] = i;
     if (i == 0) *act_count = C;

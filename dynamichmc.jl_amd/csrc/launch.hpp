@@ -1,6 +1,6 @@
 // Kernel dispatch over (target family, slots per lane).  Every target family's kernels are instantiated in
 // their own translation unit (family.hip compiled once per family, see Makefile), so the library builds in
-// parallel; this header only declares the per-family entry point that dhmc_capi.hip calls.
+// parallel; this header only declares the per-family entry point that dhmc_capi.hip (capi_internal.hpp capi::dispatch) calls.
 #pragma once
 #include "../../include/dhmc.h"
 #include "dense_rounds.hpp"

@@ -35,7 +35,7 @@ struct LogisticRound {
 };
 
 // K_act: act <- the chains in PH_LEAF (any order: a row's result does not depend on its place in a tile)
-__global__ __launch_bounds__(256) void rounds_active_list_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+static __global__ __launch_bounds__(256) void rounds_active_list_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.C) return;
     const int chain = P.chain_base + i;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBu
 // K_r: link, residual and the block's share of the log-likelihood — one wave per (block of observations, listed chain).
 // H <- r (0 for the padding observations); S1P[z][chain] <- the block's Σ [y η − log(1+e^η)] in wave order (lane l adds
 // its observations n = l mod 64 in ascending order, then the butterfly: include/dhmc.h).
-__global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
+static __global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, RoundBuffers R, LogisticRound L) {
     if ((int)blockIdx.y >= *L.act_count) return;
     const int chain = L.act[blockIdx.y], lane = threadIdx.x, z = blockIdx.x;
     const int64_t N = P.tp.n, Npad = P.tp.npad;

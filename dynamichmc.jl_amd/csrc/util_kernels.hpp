@@ -1,11 +1,11 @@
-// Family-independent helper kernels of the C ABI (included by dhmc_capi.hip only).
+// Family-independent helper kernels of the C ABI (the capi_*.hip translation units: `static`, every unit has its own host stubs).
 #pragma once
 #include "nuts_kernels.hpp"
 
 namespace dhmc {
 
 // Set M⁻¹ from a user array (GaussianKineticEnergy(Diagonal), hamiltonian.jl:80)
-__global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __restrict__ src, int per_chain,
+static __global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __restrict__ src, int per_chain,
                                        double* __restrict__ minv, double* __restrict__ W) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)C * Dpad) return;
@@ -21,13 +21,13 @@ __global__ void set_metric_diag_kernel(int D, int Dpad, int C, const double* __r
 }
 
 // flag := 1 if any element is not a finite positive number (the @argcheck of GaussianKineticEnergy, hamiltonian.jl:63)
-__global__ void check_positive_finite_kernel(const double* __restrict__ v, size_t n, int* __restrict__ flag) {
+static __global__ void check_positive_finite_kernel(const double* __restrict__ v, size_t n, int* __restrict__ flag) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n && (!(v[idx] > 0) || !dm_isfinite(v[idx]))) *flag = 1;
 }
 
 // padded [C][Dpad] <-> unpadded [C][D]
-__global__ void unpad_kernel(int D, int Dpad, int C, const double* __restrict__ src, double* __restrict__ dst) {
+static __global__ void unpad_kernel(int D, int Dpad, int C, const double* __restrict__ src, double* __restrict__ dst) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)C * D) return;
     int c = (int)(idx / D), e = (int)(idx % D);
