@@ -123,7 +123,7 @@ def traffic_probe(pkg, torch, seed):
     print(json.dumps({"probe_leapfrogs": ALL_RUN_LEAPFROGS[0]}))
 
 
-def setup_context(pkg, torch, rank, chains, seed, short):
+def setup_context(pkg, torch, rank, chains, seed, short, keep_draws=False):
     stream = torch.cuda.current_stream().cuda_stream
     ctx = pkg.DeviceContext(D, chains, seed=seed, chain_offset=rank * chains, device=torch.cuda.current_device(),
                             stream=stream)
@@ -132,21 +132,26 @@ def setup_context(pkg, torch, rank, chains, seed, short):
     # default_warmup_stages (mcmc.jl:415-425): 75 stepsize-only, metric windows 25/50/100/200/400, 50 stepsize-only
     stages = [(20, False), (25, True), (20, False)] if short else \
         [(75, False), (25, True), (50, True), (100, True), (200, True), (400, True), (50, False)]
-    bufs = {n: torch.empty((chains, n, D), dtype=torch.float64, device="cuda") for n, metric in stages if metric}
     torch.cuda.synchronize()
     t0 = time.perf_counter(); lf0 = ALL_RUN_LEAPFROGS[0]; kms = 0.0
+    bufs = {n: torch.empty((chains, n, D), dtype=torch.float64, device="cuda") for n, metric in stages if metric and keep_draws}
     for n, metric in stages:
-        _run(ctx, n, {"draws": bufs[n]} if metric else {}, da={})
+        if metric and not keep_draws:
+            ctx.metric_window_begin()          # the stage's draws go into per-chain running moments, not into a [C][n][D] buffer
+        _run(ctx, n, {"draws": bufs[n]} if metric and keep_draws else {}, da={})
         kms += ctx.last_run_kernel_ms()
-        if metric:
+        if metric and keep_draws:              # --warmup-draws: round 3's path, the two-pass update of stored windows (25 GB at 8192 chains)
             ctx.update_metric_diag(bufs[n])
+        elif metric:
+            ctx.update_metric_diag_window()
+    del bufs
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lf = ALL_RUN_LEAPFROGS[0] - lf0
     warm = {"value": lf / dt, "unit": "leapfrog-steps/s", "seconds": dt, "leapfrogs": lf, "transitions": sum(n for n, _ in stages),
-            "kernel_ms": kms, "note": "TuningNUTS stages with dual averaging on, draws of the metric windows kept in HBM, "
-                                       "per-chain diagonal metric updates included; this rank"}
-    del bufs
+            "kernel_ms": kms, "note": "TuningNUTS stages with dual averaging on, the metric windows' draws accumulated into per-chain "
+                                       "running moments by the kernel (dhmc_metric_window_begin: no posterior matrix of a warmup "
+                                       "stage is stored), per-chain diagonal metric updates included; this rank"}
     return ctx, warm
 
 
@@ -165,8 +170,9 @@ def cpu_baseline(transitions, threads):
     o = ol.Oracle(D, chains, seed=1234, threads=threads)
     o.init(); o.find_initial_stepsize()
     o.run(20, da={}, fields=[])
-    r = o.run(25, da={}, fields=["draws"])
-    o.update_metric_diag(r["draws"])
+    o.metric_window_begin()
+    o.run(25, da={}, fields=[])
+    o.update_metric_diag_window()
     o.run(20, da={}, fields=[])
     t0 = time.perf_counter()
     r = o.run(transitions, fields=["steps"])
@@ -256,10 +262,11 @@ def bench_config45(args, pkg, torch):
         ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_FUNNEL, seed=args.seed, stream=_work_stream(torch))
         ctx.init(); ctx.find_initial_stepsize()
         for n, metric in ((75, False), (25, True), (50, True), (100, True), (200, True), (50, False)):
-            d = torch.empty((C, n, D), dtype=torch.float64, device="cuda")
-            ctx.run_into(n, {"draws": d}, da={})
             if metric:
-                ctx.update_metric_diag(d)
+                ctx.metric_window_begin()
+            ctx.run_into(n, {}, da={})
+            if metric:
+                ctx.update_metric_diag_window()
         name = f"Neal's funnel D=30, diagonal metric, {C} chains" + (" = one GPU's share of 32768" if C == 4096 else " (all of them on this GPU)" if C == 32768 else "") + " (BASELINE.json configs[3])"
         flops_per_leapfrog = None
     else:
@@ -270,8 +277,7 @@ def bench_config45(args, pkg, torch):
         ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_LOGISTIC, target_params=pkg.LogisticRegression(X, y).params(),
                                 seed=args.seed, stream=_work_stream(torch))
         ctx.init(); ctx.set_stepsize(0.02)
-        d = torch.empty((C, 20, D), dtype=torch.float64, device="cuda")
-        ctx.run_into(20, {"draws": d}, da={}); ctx.update_metric_diag(d); ctx.run_into(15, {}, da={})
+        ctx.metric_window_begin(); ctx.run_into(20, {}, da={}); ctx.update_metric_diag_window(); ctx.run_into(15, {}, da={})
         name = f"logistic regression N=1e5 p=256, diagonal metric, {C} chains" + (" = one GPU's share of 8192" if C == 1024 else " (all of them on this GPU)" if C == 8192 else "") + " (BASELINE.json configs[4])"
         flops_per_leapfrog = 4.0 * 100032 * 256      # two GEMM passes over X per gradient
     out = {"steps": torch.empty((C, T), dtype=torch.int64, device="cuda"), "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
@@ -350,6 +356,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--transitions", type=int, default=None, help="NUTS transitions per chain per step (default 1000 for config 2, 20 otherwise)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--warmup-draws", action="store_true", help="A/B: the metric windows' draws stored and re-read (dhmc_update_metric_diag) "
+                                                                 "instead of accumulated by the kernel (dhmc_metric_window_begin)")
     ap.add_argument("--short-warmup", action="store_true", help="65-transition adaptive setup instead of the reference's 900")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-transitions", type=int, default=150)
@@ -422,7 +430,7 @@ def main():
     if args.config in (4, 5):
         return print(json.dumps(bench_config45(args, pkg, torch)))
     C, T, K, Wn = args.chains, args.transitions, args.steps, args.warmup
-    ctx, warm = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup)
+    ctx, warm = setup_context(pkg, torch, rank, C, args.seed, args.short_warmup, args.warmup_draws)
     out = {
         "draws": torch.empty((C, T, D), dtype=torch.float64, device="cuda"),
         "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
@@ -457,6 +465,8 @@ def main():
     mean_depth = float(out["depth"].double().mean())
     mean_acc = float(out["acceptance_rate"].mean())
     mean_steps = float(out["steps"].double().mean())
+    per_chain = out["steps"].sum(1).double()         # the launch ends with its slowest chain: one wave walks a chain's T transitions
+    slowest = float(per_chain.max() / per_chain.mean())
     q = out["draws"]
     mom = (float(q[:, -20:].mean()), float(q[:, -20:].var()))
     ess_T = min(T, 1000)
@@ -513,7 +523,8 @@ def main():
             "ess_note": f"min rank-normalised split-chain bulk ESS (Vehtari et al. 2021; dhmc_ess_bulk) over 16 coordinates, "
                         f"the last {ess_T} draws x all chains of the last timed step, over that share of the step's time",
             "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
-                     "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1]},
+                     "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1],
+                     "slowest_chain_over_mean_leapfrogs": slowest},
             "warmup_phase": warm,
             "roofline": {"bound": "valu", "achieved": valu_ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": valu_ach / VALU_PEAK_TFLOPS,

@@ -73,7 +73,8 @@ SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", 
            "dhmc_leapfrog_trajectory", "dhmc_explore_log_acceptance_ratios", "dhmc_ess_rhat",
            "dhmc_set_logdensity_callback", "dhmc_ess_bulk", "dhmc_ess_tail", "dhmc_summarize_tree_statistics",
            "dhmc_set_dense_products", "dhmc_get_dense_products", "dhmc_host_alloc", "dhmc_host_free",
-           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log", "dhmc_detmath_selftest", "dhmc_set_metric_allreduce"]
+           "dhmc_register_target_source", "dhmc_check_target_source", "dhmc_target_source_log", "dhmc_detmath_selftest", "dhmc_set_metric_allreduce",
+           "dhmc_metric_window_begin", "dhmc_metric_window_count", "dhmc_update_metric_diag_window", "dhmc_metric_window_end"]
 
 _lib = None
 
@@ -121,9 +122,10 @@ def lib():
         L.dhmc_last_run_leapfrogs.restype = C.c_uint64
         L.dhmc_last_run_rounds.restype = C.c_uint64
         L.dhmc_workspace_bytes.restype = C.c_uint64
+        L.dhmc_metric_window_count.restype = C.c_int64
         for name in SYMBOLS:
             if name.startswith("dhmc_") and name not in ("dhmc_last_error", "dhmc_version", "dhmc_target_source_log", "dhmc_last_run_kernel_ms",
-                                                         "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes"):
+                                                         "dhmc_last_run_leapfrogs", "dhmc_last_run_rounds", "dhmc_workspace_bytes", "dhmc_metric_window_count"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib

@@ -534,6 +534,22 @@ def _host(arrs):
     return out
 
 
+def _run_discarding(slogd, N, da, mcmc_reporter):
+    """A stage whose draws nobody keeps (mcmc_with_warmup discards its warmup, mcmc.jl:579-583) and whose metric update — if any —
+    reads a metric window: dhmc_run without outputs.  Step reports as in _run."""
+    ctx = slogd.ctx
+    chunk = int(getattr(mcmc_reporter, "step_chunk", 0) or 0)
+    if chunk <= 0 or chunk >= N:
+        ctx.run_into(N, {}, da=da)
+        if mcmc_reporter is not None and N > 0 and chunk > 0:
+            mcmc_reporter.report(N, **({"ϵ": _sig(np.median(ctx.stepsize()))} if da is not None else {}))
+        return
+    for n0 in range(0, N, chunk):
+        L = min(chunk, N - n0)
+        ctx.run_into(L, {}, da=None if da is None else dict(da, init=int(n0 == 0), finalize=int(n0 + L >= N)))
+        mcmc_reporter.report(n0 + L, **({"ϵ": _sig(np.median(ctx.stepsize()))} if da is not None else {}))
+
+
 def _run(slogd, N, da=None, keep=True, mcmc_reporter=None):
     """The N transitions of a stage for all chains.  The outputs are written to HBM and only come to the host when the caller
     keeps them as numpy arrays (`keep` and not `on_device`); returns (arrays, draws usable for the metric update).
@@ -636,11 +652,24 @@ def warmup(slogd, stage, warmup_state):
         da = None if isinstance(ad, FixedStepsize) else dict(delta=ad.delta, gamma=ad.gamma, kappa=ad.kappa, t0=ad.t0)
         mcmc_reporter = make_mcmc_reporter(slogd.reporter, stage.N, currently_warmup=True,         # mcmc.jl:268-270
                                            tuning="stepsize" if stage.M is None else "stepsize and " + str(stage.M) + " metric")
-        arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup, mcmc_reporter=mcmc_reporter)
+        # A Diagonal stage's variance (mcmc.jl:281-284 with sample_M⁻¹(Diagonal, ·), :209) comes from running moments that the kernels
+        # update with every draw (include/dhmc.h dhmc_metric_window_begin) — whether the stage's posterior matrix is kept or not, so
+        # that mcmc_with_warmup and mcmc_keep_warmup sample the same chains bit for bit, as they do in the reference (mcmc.jl:579-583).
+        if stage.M == Diagonal:
+            ctx.metric_window_begin()
+        try:
+            if not slogd.keep_warmup and stage.M != Symmetric:
+                _run_discarding(slogd, stage.N, da, mcmc_reporter)     # nobody reads this posterior matrix: no [C][N][D] buffer at all
+                arrs = dev_draws = None
+            else:
+                arrs, dev_draws = _run(slogd, stage.N, da=da, keep=slogd.keep_warmup, mcmc_reporter=mcmc_reporter)
+            if stage.M == Diagonal:
+                ctx.update_metric_diag_window(stage.lam)
+        finally:
+            if stage.M == Diagonal and ctx.metric_window_count() >= 0:
+                ctx.metric_window_end()
         if stage.M == Symmetric:                               # mcmc.jl:281-284 with sample_M⁻¹(Symmetric, ·) (:210): pooled over the
             ctx.update_metric_dense(dev_draws, stage.lam)      # context's chains (shared M⁻¹), or chain by chain (per_chain_metric)
-        elif stage.M == Diagonal:
-            ctx.update_metric_diag(dev_draws, stage.lam)       # mcmc.jl:281-284, from the draws where they are (HBM)
         st = _state(ctx)
         if stage.M is not None:
             mcmc_reporter.report("adaptation finished", adapted_kinetic_energy=repr(st.kappa))        # mcmc.jl:283

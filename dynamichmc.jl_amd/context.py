@@ -268,6 +268,21 @@ class DeviceContext:
         self._chk(abi.lib().dhmc_update_metric_diag(self.h, _ptr(draws), C.c_int64(n), C.c_double(lam), int(_is_device(draws))),
                   "dhmc_update_metric_diag")
 
+    def metric_window_begin(self):
+        """Opens a metric window (include/dhmc.h dhmc_metric_window_begin): from now on every transition's draw joins per-chain running
+        moments on the device, so a tuning stage needs no [C][N][D] posterior matrix for its metric update."""
+        self._chk(abi.lib().dhmc_metric_window_begin(self.h), "dhmc_metric_window_begin")
+
+    def metric_window_count(self):
+        return int(abi.lib().dhmc_metric_window_count(self.h))
+
+    def metric_window_end(self):
+        self._chk(abi.lib().dhmc_metric_window_end(self.h), "dhmc_metric_window_end")
+
+    def update_metric_diag_window(self, lam=0.0):
+        """κ := GaussianKineticEnergy(Diagonal(window variance)) per chain from the open window's moments; closes the window."""
+        self._chk(abi.lib().dhmc_update_metric_diag_window(self.h, C.c_double(lam)), "dhmc_update_metric_diag_window")
+
     def update_metric_dense(self, draws, lam):
         """Pooled dense estimate: κ := GaussianKineticEnergy(regularize(Symmetric(cov(draws)), λ)) (mcmc.jl:210,218-222)."""
         if isinstance(draws, np.ndarray):

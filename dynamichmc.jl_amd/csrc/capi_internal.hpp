@@ -77,6 +77,16 @@ struct dhmc_ctx {
     int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
     const UserKernels* user = nullptr;   // target >= DHMC_TARGET_USER_BASE: the run-time compiled kernels of the caller's functor
     void* d_user_params = nullptr;
+    // the per-draw kernels' launch order (nuts_kernels.hpp RunParams::launch_order): chains sorted by the leapfrog steps of the previous
+    // launch, longest first, when one of them did more than a few percent above the mean (run_call)
+    unsigned* d_chain_work = nullptr;      // [C]
+    int* d_launch_order = nullptr;         // [C]
+    std::vector<unsigned> h_chain_work;
+    std::vector<int> h_launch_order;
+    bool launch_order_valid = false;
+    int launch_order_on = 1;               // DHMC_LAUNCH_ORDER=0: workgroup b takes chain b, always
+    double* d_win = nullptr;   // dhmc_metric_window_begin: [2][C][Dpad] running mean / sum of squared deviations of every chain's draws
+    int64_t win_n = -1;        // draws in the open metric window (-1: none open)
     bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state
     std::string err;
     std::vector<void*> allocs;

@@ -154,6 +154,41 @@ int dhmc_update_metric_diag(dhmc_ctx* c, const double* draws, int64_t n, double 
     return DHMC_OK;
 }
 
+// ---- the same estimate without the draws: running moments updated by the kernels at the end of every transition --------------
+int dhmc_metric_window_begin(dhmc_ctx* c) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DIAG) return DHMC_ERR_INVALID_ARGUMENT;
+    DHMC_CHECK_USABLE(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t n = 2 * (size_t)c->cfg.chains * c->Dpad;
+    if (!c->d_win) {
+        int rc = dev_alloc(c, &c->d_win, n);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_win, 0, n * sizeof(double), c->stream));
+    c->win_n = 0;
+    return DHMC_OK;
+}
+
+int64_t dhmc_metric_window_count(const dhmc_ctx* c) { return c ? c->win_n : -1; }
+
+int dhmc_metric_window_end(dhmc_ctx* c) {
+    if (!c) return DHMC_ERR_INVALID_ARGUMENT;
+    c->win_n = -1;
+    return DHMC_OK;
+}
+
+int dhmc_update_metric_diag_window(dhmc_ctx* c, double lambda) {
+    if (!c || c->cfg.metric != DHMC_METRIC_DIAG || c->win_n < 0) return DHMC_ERR_INVALID_ARGUMENT;
+    if (c->win_n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t n = (size_t)c->cfg.chains * c->Dpad;
+    hipLaunchKernelGGL(window_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->cfg.dim, c->Dpad, c->cfg.chains,
+                       (const double*)(c->d_win + n), c->win_n, c->st.minv, c->st.W);
+    HIP_TRY(c, hipGetLastError());
+    c->win_n = -1;
+    return DHMC_OK;
+}
+
 int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double lambda, int on_device) {
     if (!c || !draws || c->cfg.metric != DHMC_METRIC_DENSE) return DHMC_ERR_INVALID_ARGUMENT;
     if (n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;  // mcmc.jl:191-192

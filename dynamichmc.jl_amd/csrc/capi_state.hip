@@ -66,7 +66,7 @@ int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->poisoned = true;    // a partially copied blob is no state
     const int rc = blob_io(c, const_cast<char*>((const char*)host_blob), false);
-    if (rc == DHMC_OK) c->poisoned = false;
+    if (rc == DHMC_OK) { c->poisoned = false; c->win_n = -1; }   // (a blob carries no metric window)
     return rc;
 }
 

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(64) void rounds_k3_kernel(RunParams P, RoundBuffers
                 for (int k = 0; k < NPL; ++k)
                     if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
             }
+            window_accumulate<NPL>(P, row, lane, q, S.n);
             if constexpr (T::kRecomputeGrad) {
                 double g[NPL];
                 (void)tgt.eval(q, g, lane, D);

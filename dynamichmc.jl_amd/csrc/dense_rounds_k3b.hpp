@@ -359,6 +359,7 @@ __global__ __launch_bounds__(WAVE * k3b_waves(NPL)) void rounds_k3b_kernel(RunPa
                 for (int k = 0; k < NT; ++k)
                     if (off + lane + WAVE * k < D) drow[lane + WAVE * k] = qv[k];
             }
+            window_accumulate<NT>(P, row + off, lane, qv, n_done);
             if (regrad) {
                 double gv[NT];
                 (void)eval_blockwise(qv, gv);

@@ -244,6 +244,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_K3_BLOCK")) c->k3_block = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_HOST_CHUNK")) c->host_chunk = std::atoll(e);
+    if (const char* e = std::getenv("DHMC_LAUNCH_ORDER")) c->launch_order_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_FUSE_K2")) c->fuse_k2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
@@ -262,6 +263,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if ((rc = dev_alloc(c, &c->st.status, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.ws, C * (size_t)c->nvec * Dp))) return fail(rc);
     if ((rc = dev_alloc(c, &c->d_counter, 1))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->d_chain_work, (size_t)cfg->chains))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->d_launch_order, (size_t)cfg->chains))) return fail(rc);
     if (hipMemset(c->st.q, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
     if (hipMemset(c->st.g, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
     if (hipMemset(c->st.da, 0, C * sizeof(DAState)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -568,6 +571,8 @@ int dhmc_init(dhmc_ctx* c, const double* q0, int q0_on_device) {
         HIP_TRY(c, hipGetLastError());
     }
     c->poisoned = false;
+    c->win_n = -1;         // new chains: an open metric window is discarded
+    c->launch_order_valid = false;
     return status_code(c);
 }
 
@@ -737,6 +742,14 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     P.l1_in_lds = c->l1_in_lds;
     P.k3_block = c->k3_block;
     P.one_product = c->cfg.metric == DHMC_METRIC_DENSE && c->dense_products == 1;
+    const bool per_draw_kernel = !c->external && !c->logistic_rounds && !(c->cfg.metric == DHMC_METRIC_DENSE && c->dense_rounds);
+    if (per_draw_kernel && c->launch_order_on && c->d_chain_work) {
+        P.chain_work = c->d_chain_work;
+        P.launch_order = c->launch_order_valid ? c->d_launch_order : nullptr;
+    }
+    if (c->win_n >= 0) {       // an open metric window: every transition's draw joins the running moments (capi_metric.hip)
+        P.win_mean = c->d_win; P.win_m2 = c->d_win + (size_t)C * c->Dpad; P.win_n0 = c->win_n;
+    }
     if (da) {
         P.adapt = 1; P.da_init = da->init; P.da_finalize = da->finalize; P.t0 = da->t0;
         P.delta = da->delta; P.gamma = da->gamma; P.kappa = da->kappa;
@@ -1063,6 +1076,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             RunParams Q = P;
             Q.N = len;
             Q.out_stride = L;
+            Q.win_n0 = P.win_n0 + n0;
             if (da) { Q.da_init = (k == 0) ? da->init : 0; Q.da_finalize = (k == nchunks - 1) ? da->finalize : 0; }
             for (auto& f : staged) *f.dev = c->stage[b][f.idx].p;          // (the slots are fields of P.out: copy them again)
             Q.out = P.out;
@@ -1098,7 +1112,34 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
     if (e == hipSuccess && nbuf == 1 && !staged.empty()) e = d2h(0, 0, N, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    const bool reorder = P.chain_work && N >= 32;     // (a short call's counts say little about the chains, and sorting is not free)
+    if (e == hipSuccess && reorder) {
+        c->h_chain_work.resize(C);
+        e = hipMemcpyAsync(c->h_chain_work.data(), c->d_chain_work, sizeof(unsigned) * C, hipMemcpyDeviceToHost, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && reorder) {
+        // One wave walks a chain's N transitions, so the launch ends with its slowest chain: a chain whose trees are persistently
+        // deeper (a smaller adapted ϵ) and which starts in the last wave of workgroups holds the whole launch open — measured on
+        // BASELINE configs[1]: one chain of 4096 at 1.48 × the mean work, 189 ms instead of 171 ms per 1000 transitions.  The next
+        // launch therefore starts its chains in the order of this one's work, longest first (results do not depend on the order).
+        unsigned long long sum = 0;
+        unsigned mx = 0;
+        for (unsigned w : c->h_chain_work) { sum += w; mx = std::max(mx, w); }
+        c->launch_order_valid = false;
+        if ((double)mx * C > 1.03 * (double)sum) {
+            c->h_launch_order.resize(C);
+            for (int i = 0; i < C; ++i) c->h_launch_order[i] = i;
+            std::stable_sort(c->h_launch_order.begin(), c->h_launch_order.end(),
+                             [&](int a, int b) { return c->h_chain_work[a] > c->h_chain_work[b]; });
+            e = hipMemcpyAsync(c->d_launch_order, c->h_launch_order.data(), sizeof(int) * C, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            c->launch_order_valid = e == hipSuccess;
+        }
+        if (std::getenv("DHMC_DEBUG_ORDER"))
+            std::fprintf(stderr, "[dhmc] launch order: N=%lld max=%u mean=%.1f valid=%d first=%d used_this_call=%d\n", (long long)N, mx, (double)sum / C,
+                         (int)c->launch_order_valid, c->launch_order_valid ? c->h_launch_order[0] : -1, P.launch_order != nullptr);
+    }
     if (e == hipSuccess) {
         float ms = 0.f;
         e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -1119,6 +1160,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             for (auto& sb : c->stage[0])
                 if (sb.p) { (void)hipFree(sb.p); sb.p = nullptr; sb.cap = 0; }
     }
+    if (c->win_n >= 0) c->win_n += N;
     return status_code(c);
 }
 }  // namespace

@@ -173,7 +173,7 @@ __device__ __forceinline__ bool merge_core_dense(XM xm_, XMS xms_, XP xp_, XPS x
 
 template <class T, int NPL>
 __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, DenseMetric Mall) {
-    const int chain = blockIdx.x;
+    const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
     const DenseMetric M = Mall.of_chain(chain);
     const int lane = threadIdx.x;
     const int D = P.D, Dpad = P.Dpad;
@@ -487,6 +487,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_dense_kernel(RunParams P, Dens
         P.st.transition[chain] = tr0 + (uint32_t)P.N;
         P.st.status[chain] = status;
         if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
+        if (P.chain_work) P.chain_work[chain] = (unsigned)(total_steps > 0xffffffffull ? 0xffffffffull : total_steps);
     }
 }
 

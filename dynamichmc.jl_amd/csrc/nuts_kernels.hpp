@@ -94,7 +94,47 @@ struct RunParams {
     DeviceOutputs out;
     TargetParams tp;
     unsigned long long* leapfrog_counter;  // total leapfrog steps of the launch (may be null)
+    // an open metric window (include/dhmc.h dhmc_metric_window_begin): running mean and sum of squared deviations of every chain's
+    // draws, [C][Dpad] each (null: no window), and the number of draws the window held before this launch
+    double* win_mean;
+    double* win_m2;
+    int64_t win_n0;
+    // The per-draw kernels walk all N transitions of a chain in one wave, so a launch ends with its slowest chain.  chain_work[chain]
+    // := the leapfrog steps this launch spent on the chain (may be null); launch_order (may be null): workgroup b takes chain
+    // launch_order[b] — the host sorts the chains by the previous launch's work, longest first (dhmc_capi.hip run_call), so that a
+    // chain with persistently deeper trees starts in the first wave of workgroups instead of holding the last one open.
+    unsigned* chain_work;
+    const int* launch_order;
 };
+
+// One chain's position after its transition number `n_in_call` of this launch joins the window's moments: rows at `row`
+// (chain * Dpad [+ the wave's offset]), lane l's slot k is coordinate l + 64k of that row.  Pads hold zeros throughout.
+template <int N>
+__device__ __forceinline__ void window_accumulate(const RunParams& P, size_t row, int lane, const double (&q)[N], int64_t n_in_call) {
+#ifdef DHMC_NO_WINDOW      // A/B builds only (tools/experiments/build_variant_fast.sh): what the window's code costs a run without one
+    return;
+#endif
+    if (!P.win_mean) return;
+    const double rn = 1.0 / (double)(P.win_n0 + n_in_call + 1);
+    double* __restrict__ mrow = P.win_mean + row;
+    double* __restrict__ srow = P.win_m2 + row;
+    // four slots at a time (eight loads in flight): the whole row at once would cost the per-draw kernel 32 more live registers
+    // at the end of a transition, and the compiler pays for those with scratch in the tree loop
+    constexpr int B = N < 4 ? N : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < N; k0 += B) {
+        double mean[B], m2[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) { mean[k] = mrow[lane + WAVE * (k0 + k)]; m2[k] = srow[lane + WAVE * (k0 + k)]; }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            dm_window_update(q[k0 + k], rn, &mean[k], &m2[k]);
+            mrow[lane + WAVE * (k0 + k)] = mean[k];
+            srow[lane + WAVE * (k0 + k)] = m2[k];
+        }
+        asm volatile("" ::: "memory");
+    }
+}
 
 // workspace vector indices (units of Dpad doubles inside one chain's block)
 __host__ __device__ inline int ws_p0() { return 0; }
@@ -403,7 +443,7 @@ __device__ unsigned long long g_phase[16];
 // ------------------------------------------------------------------------------------------
 template <class T, int NPL, bool L1LDS>
 __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kernel(RunParams P) {
-    const int chain = blockIdx.x;
+    const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int lane = threadIdx.x;
     const int D = P.D, Dpad = P.Dpad;
 
@@ -509,6 +549,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             for (int k = 0; k < NPL; ++k)
                 if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
         }
+        window_accumulate<NPL>(P, (size_t)chain * P.Dpad, lane, q, n_);
     };
 
     PH_DECL
@@ -857,6 +898,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         P.st.transition[chain] = tr0 + (uint32_t)P.N;
         P.st.status[chain] = status;
         if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
+        if (P.chain_work) P.chain_work[chain] = (unsigned)(total_steps > 0xffffffffull ? 0xffffffffull : total_steps);
     }
 }
 

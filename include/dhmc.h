@@ -286,6 +286,24 @@ int dhmc_run(dhmc_ctx* ctx, int64_t n_transitions, const dhmc_dual_averaging* da
 int dhmc_update_metric_diag(dhmc_ctx* ctx, const double* draws, int64_t n, double lambda,
                             int on_device);
 
+/* The same update WITHOUT the draws (a tuning stage's posterior matrix is [D][N] per chain in the reference, mcmc.jl:267 — for 8192
+ * chains × 1000 coordinates the five default metric windows are 25 GB that would be written only to be read once):
+ *   dhmc_metric_window_begin   opens a window: two [chains][Dpad] rows per chain (running mean, sum of squared deviations) are
+ *                              zeroed, and from then on the kernels of every dhmc_run — whichever engine serves the context — add
+ *                              each transition's draw to them when they store it (dhmc_detmath.h dm_window_update: Welford's
+ *                              recurrence in a pinned order, so the oracle reproduces the bits);
+ *   dhmc_metric_window_count   draws in the open window (-1: none open);
+ *   dhmc_update_metric_diag_window   κ := GaussianKineticEnergy(Diagonal(m2 / (n - 1))) per chain and closes the window
+ *                              (n >= 2, else DHMC_ERR_INVALID_ARGUMENT and the window stays open);
+ *   dhmc_metric_window_end     closes a window without using it.
+ * The estimate is Statistics.var's to rounding (≈ 1e-15 relative; the two-pass dhmc_update_metric_diag is the reference's own
+ * summation order).  dhmc_outputs.draws may be NULL while a window is open — that is the point.  dhmc_init and
+ * dhmc_import_state discard an open window; a state blob does not carry one.  Diagonal metric only. */
+int dhmc_metric_window_begin(dhmc_ctx* ctx);
+int64_t dhmc_metric_window_count(const dhmc_ctx* ctx);
+int dhmc_update_metric_diag_window(dhmc_ctx* ctx, double lambda);
+int dhmc_metric_window_end(dhmc_ctx* ctx);
+
 /* Dense counterpart (contexts created with DHMC_METRIC_DENSE): κ := GaussianKineticEnergy(regularize_M⁻¹(
  * Symmetric(cov(pm; dims=2)), λ)) (mcmc.jl:210,218-222).  The reference estimates one matrix per chain; the
  * dense M⁻¹ of a context is shared, so the draws of all chains are pooled (J = C·n rows, chain-major) — with

@@ -23,6 +23,9 @@ struct Chain {
     uint32_t status = 0;
     ChainStream stream;
     bool dense_one_product = false;   // Hamiltonian::one_product for this chain's transitions (not for the search / probes)
+    // an open metric window (include/dhmc.h dhmc_metric_window_begin): running moments of the draws instead of the posterior matrix
+    int64_t win_n = -1;               // draws in the window, -1: none open
+    Vec win_mean, win_m2;
 };
 
 // src/mcmc.jl:108  random_position(rng, N) = rand(rng, N) .* 4 .- 2
@@ -48,6 +51,7 @@ inline void initialize_warmup_state(Chain& c, const Target& target, const MathOp
     if (!c.kappa.dense) c.kappa = GaussianKineticEnergy::unit(D);   // dense contexts keep their (shared) metric
     c.status = 0;
     c.transition = 0;
+    c.win_n = -1;
     Hamiltonian H{&c.kappa, &target, M, &c.status};
     c.Q = evaluate_l(H, q, true);
     c.eps = NAN;
@@ -102,6 +106,11 @@ inline void run_transitions(Chain& c, const Target& target, const MathOps& M, co
         c.transition += 1;
         if (out.draws)
             for (int k = 0; k < D; ++k) out.draws[i * D + k] = (*c.Q.q)[k];  // :275
+        if (c.win_n >= 0) {           // posterior_matrix[:, i] = Q.q (:275) goes into the window's moments (dhmc_detmath.h)
+            c.win_n += 1;
+            const double rn = 1.0 / (double)c.win_n;
+            for (int k = 0; k < D; ++k) dhmc::dm_window_update((*c.Q.q)[k], rn, &c.win_mean[k], &c.win_m2[k]);
+        }
         if (out.logdensities) out.logdensities[i] = c.Q.lq;                  // :276
         if (out.eps) out.eps[i] = eps;                                       // :273
         if (out.pi) out.pi[i] = st.pi;
@@ -133,6 +142,19 @@ inline void update_metric_diag(Chain& c, const double* draws, int64_t N, int D) 
         var[k] = ss / (double)(N - 1);
     }
     c.kappa = GaussianKineticEnergy::diagonal(var.data(), D);  // mcmc.jl:282
+}
+
+// The same estimate from a metric window's moments (include/dhmc.h dhmc_update_metric_diag_window): var = m2 / (n - 1).
+inline void metric_window_begin(Chain& c, int D) {
+    c.win_n = 0;
+    c.win_mean.assign(D, 0.0);
+    c.win_m2.assign(D, 0.0);
+}
+inline void update_metric_diag_window(Chain& c, int D) {
+    Vec var(D);
+    for (int k = 0; k < D; ++k) var[k] = c.win_m2[k] / (double)(c.win_n - 1);
+    c.kappa = GaussianKineticEnergy::diagonal(var.data(), D);  // mcmc.jl:282
+    c.win_n = -1;
 }
 
 }  // namespace oracle

@@ -307,6 +307,17 @@ int oracle_update_metric_diag(oracle_ctx* c, const double* draws, int64_t N, dou
     return DHMC_OK;
 }
 
+int oracle_metric_window_begin(oracle_ctx* c) {
+    for (auto& ch : c->chains) metric_window_begin(ch, c->cfg.dim);
+    return DHMC_OK;
+}
+int oracle_update_metric_diag_window(oracle_ctx* c, double lambda) {
+    for (auto& ch : c->chains)
+        if (ch.win_n < 2 || !(lambda >= 0)) return DHMC_ERR_INVALID_ARGUMENT;
+    for (auto& ch : c->chains) update_metric_diag_window(ch, c->cfg.dim);
+    return DHMC_OK;
+}
+
 // ----------------------------------------------------------------------------------------
 // unit hooks for the reference's known-answer tests
 // ----------------------------------------------------------------------------------------

@@ -259,6 +259,12 @@ class Oracle:
         draws = np.ascontiguousarray(draws, np.float64)
         self._chk(lib().oracle_update_metric_diag(self.h, _p(draws), C.c_int64(draws.shape[1]), C.c_double(lam)))
 
+    def metric_window_begin(self):
+        self._chk(lib().oracle_metric_window_begin(self.h))
+
+    def update_metric_diag_window(self, lam=0.0):
+        self._chk(lib().oracle_update_metric_diag_window(self.h, C.c_double(lam)))
+
     def leapfrog_trajectory(self, eps, first, last, p=None, momentum_index=0, allow_failure=False):
         npos = last - first + 1
         out = dict(delta=np.zeros((self.C, npos)), logdensity=np.zeros((self.C, npos)),

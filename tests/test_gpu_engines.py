@@ -118,6 +118,31 @@ def test_logistic_round_engine_equals_functor_kernel(pkg, N, D, C):
     _same(_run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_LOGISTIC_ROUNDS": "0"}, make, steps))
 
 
+@pytest.mark.parametrize("metric", ["diag", "dense"])
+def test_launch_order_changes_no_result(pkg, metric):
+    """The per-draw kernels start their chains in the order of the previous launch's work, longest first (csrc/nuts_kernels.hpp
+    RunParams::launch_order; dhmc_capi.hip run_call), when a chain did more than 3 % above the mean — Neal's funnel, whose chains
+    adapt to very different step sizes, always does.  Chains are independent: the order must not show in any output."""
+    D, C = 30, 300
+
+    def steps(ctx):
+        if metric == "dense":
+            ctx.set_metric_dense(np.diag(np.linspace(0.5, 2.0, D)) + 0.02)
+        ctx.init(); ctx.find_initial_stepsize()
+        a = ctx.run(40, da={})                         # identity order; its work decides the next launch's order
+        b = ctx.run(40)
+        c = ctx.run(33)
+        return {**{"a_" + k: v for k, v in a.items()}, **{"b_" + k: v for k, v in b.items()}, **{"c_" + k: v for k, v in c.items()},
+                "q": ctx.position()[0], "work_spread": np.array([a["steps"].sum(1).max() / a["steps"].sum(1).mean()])}
+    kw = dict(metric=ol.METRIC_DENSE) if metric == "dense" else {}
+    make = lambda: pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=6, **kw)
+    env = {"DHMC_DENSE_ROUNDS": "0"}
+    on = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "1"}, make, steps)
+    off = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "0"}, make, steps)
+    assert on["work_spread"][0] > 1.03                 # (the reordering did take place)
+    _same(on, off)
+
+
 @pytest.mark.parametrize("D", [500, 1000])
 def test_block_per_chain_k3_equals_wave_per_chain_k3(pkg, D):
     """Round engines, chains of 512+ coordinates: K3 as a 4-wave workgroup per chain (dots chained from wave to wave

@@ -75,6 +75,54 @@ def test_adaptive_stages_and_metric_update(pkg, D):
     assert_same(a, b, f"D={D} inference")
 
 
+@pytest.mark.parametrize("case", ["D=3", "D=100", "D=1000", "D=1000 chunked host outputs", "D=1100 batched evaluation",
+                                  "logistic rounds D=70", "logistic rounds D=600"])
+def test_metric_window_matches_oracle(pkg, case, monkeypatch):
+    """a tuning stage's metric update without its posterior matrix (include/dhmc.h dhmc_metric_window_begin). The
+    kernels add every transition's draw to per-chain running moments where they store it — the per-draw kernel, K3 and K3b of the
+    round engines — in the order dhmc_detmath.h pins (dm_window_update), so the oracle's window gives the same M⁻¹ bit for bit;
+    the window spans two calls (one of them without any output), and changes no transition."""
+    C = 5
+    kw = {}
+    if case.startswith("logistic"):
+        D = int(case.split("=")[1]); N = 900
+        rng = np.random.default_rng(D)
+        X = rng.normal(size=(N, D)) / 8; y = (rng.random(N) < 0.5).astype(float)
+        kw = dict(target=ol.TARGET_LOGISTIC, params=ol.target_params_blob(ol.TARGET_LOGISTIC, D, X=X, y=y))
+        monkeypatch.setenv("DHMC_LOGISTIC_ROUNDS", "1")
+    else:
+        D = int(case.split()[0].split("=")[1])
+    if "chunked" in case:
+        monkeypatch.setenv("DHMC_HOST_CHUNK", "4")
+    dev, ora = make_pair(pkg, D, C, seed=41, **kw)
+    dev.init(); ora.init()
+    dev.find_initial_stepsize(); ora.find_initial_stepsize()
+    assert_same(dev.run(6, da={}), ora.run(6, da={}), case + " stepsize stage")
+    assert dev.metric_window_count() == -1
+    dev.metric_window_begin(); ora.metric_window_begin()
+    a, b = dev.run(11, da={}), ora.run(11, da={})
+    assert_same(a, b, case + " window, first call")
+    assert dev.metric_window_count() == 11
+    dev.run_into(9, {}, da=dict(init=0)); ora.run(9, da=dict(init=0), fields=[])           # no outputs at all
+    assert dev.metric_window_count() == 20
+    dev.update_metric_diag_window(); ora.update_metric_diag_window()
+    assert dev.metric_window_count() == -1
+    assert np.array_equal(dev.metric_diag(), ora.metric_diag())
+    assert_same(dev.run(8), ora.run(8), case + " inference")
+    # … and the estimate is the sample variance of the window's draws, to rounding
+    ref = pkg.DeviceContext(D, C, seed=41, target=kw.get("target", ol.TARGET_STD_NORMAL), target_params=kw.get("params"))
+    ref.init(); ref.find_initial_stepsize(); ref.run(6, da={})
+    d1 = ref.run(11, da={}); d2 = ref.run(9, da=dict(init=0))
+    draws = np.concatenate([d1["draws"], d2["draws"]], axis=1)
+    assert np.array_equal(d1["draws"], a["draws"])
+    assert np.allclose(dev.metric_diag(), draws.var(axis=1, ddof=1), rtol=1e-11, atol=0)
+    with pytest.raises(ValueError):
+        dev.update_metric_diag_window()                          # no window open
+    dense = pkg.DeviceContext(8, 2, metric=ol.METRIC_DENSE)
+    with pytest.raises(ValueError):
+        dense.metric_window_begin()                              # the diagonal metric's estimate
+
+
 def test_split_stage_equals_whole_stage(pkg):
     """One TuningNUTS stage issued as two dhmc_run calls (init on the first, finalize on the
     second) equals one call: the adaptation state persists in the context."""
