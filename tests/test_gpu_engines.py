@@ -131,12 +131,20 @@ def test_launch_order_changes_no_result(pkg, metric):
         ctx.init(); ctx.find_initial_stepsize()
         a = ctx.run(40, da={})                         # identity order; its work decides the next launch's order
         b = ctx.run(40)
-        c = ctx.run(33)
-        return {**{"a_" + k: v for k, v in a.items()}, **{"b_" + k: v for k, v in b.items()}, **{"c_" + k: v for k, v in c.items()},
-                "q": ctx.position()[0], "work_spread": np.array([a["steps"].sum(1).max() / a["steps"].sum(1).mean()])}
+        # … through dual averaging (continued from the first stage), an open metric window, and host outputs that leave in chunks
+        c = ctx.run(100, da=dict(init=0))
+        res = {**{"a_" + k: v for k, v in a.items()}, **{"b_" + k: v for k, v in b.items()}, **{"c_" + k: v for k, v in c.items()}}
+        if metric == "diag":
+            ctx.metric_window_begin()
+            d = ctx.run(90)
+            ctx.update_metric_diag_window()
+            res.update({"d_" + k: v for k, v in d.items()}, minv=ctx.metric_diag())
+        e = ctx.run(150)
+        res.update({"e_" + k: v for k, v in e.items()})
+        return {**res, "q": ctx.position()[0], "eps": ctx.stepsize(), "work_spread": np.array([a["steps"].sum(1).max() / a["steps"].sum(1).mean()])}
     kw = dict(metric=ol.METRIC_DENSE) if metric == "dense" else {}
     make = lambda: pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=6, **kw)
-    env = {"DHMC_DENSE_ROUNDS": "0"}
+    env = {"DHMC_DENSE_ROUNDS": "0", "DHMC_HOST_CHUNK": "70"}
     on = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "1"}, make, steps)
     off = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "0"}, make, steps)
     assert on["work_spread"][0] > 1.03                 # (the reordering did take place)
