@@ -480,6 +480,9 @@ def main():
         ll = torch.tensor([leapfrogs, ess / ess_dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(ll, op=dist.ReduceOp.SUM, group=pg)
         t_max, total_leapfrogs, ess_rate = float(tt[0]), float(ll[0]), float(ll[1])
+        ss = torch.tensor([slowest], device=coll_dev, dtype=torch.float64)       # the rank whose slowest chain is furthest above its mean
+        dist.all_reduce(ss, op=dist.ReduceOp.MAX, group=pg)                       # sets the job's time (profiles/r04_straggler_chain.txt)
+        slowest = float(ss[0])
         # the one collective of the path: gather the last draw of every chain over RCCL/xGMI
         last = out["draws"][:, -1, :].contiguous().to(coll_dev)
         gathered = torch.empty((world * C, D), dtype=torch.float64, device=coll_dev)
@@ -524,7 +527,11 @@ def main():
                         f"the last {ess_T} draws x all chains of the last timed step, over that share of the step's time",
             "tree": {"mean_depth": mean_depth, "mean_leapfrogs_per_transition": mean_steps,
                      "mean_acceptance": mean_acc, "draw_mean": mom[0], "draw_var": mom[1],
-                     "slowest_chain_over_mean_leapfrogs": slowest},
+                     "slowest_chain_over_mean_leapfrogs": slowest,
+                     "slowest_chain_note": "a launch ends with its slowest chain (one wave walks a chain's transitions; 4096 chains = four "
+                                           "rounds of 1024 resident waves): the largest per-chain leapfrog count of the last step over "
+                                           "the mean, max over ranks; 1.0 = no chain holds a round open, 1.48 cost 11 % in "
+                                           "profiles/r04_straggler_chain.txt"},
             "warmup_phase": warm,
             "roofline": {"bound": "valu", "achieved": valu_ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": valu_ach / VALU_PEAK_TFLOPS,

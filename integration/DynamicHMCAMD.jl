@@ -119,9 +119,15 @@ function run!(ctx, N; da::Union{Nothing,DualAveraging} = nothing, on_device::Boo
     (posterior_matrix = pm, tree_statistics = stats, ϵs = ϵs, logdensities = ℓs)
 end
 
-# end of a TuningNUTS{Diagonal} stage (mcmc.jl:281-284)
+# end of a TuningNUTS{Diagonal} stage (mcmc.jl:281-284), from a posterior matrix the caller holds …
 update_metric!(ctx, pm, λ) = check(ctx, ccall((:dhmc_update_metric_diag, libdhmc), Cint,
     (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Cint), ctx.h, pointer(pm), size(pm, 2), λ, 0), "dhmc_update_metric_diag")
+# … or from a metric window: running moments that the kernels update with every draw between `metric_window_begin!` and
+# `update_metric_window!` (include/dhmc.h), so that the stage's variance needs no posterior matrix on the device
+metric_window_begin!(ctx) = check(ctx, ccall((:dhmc_metric_window_begin, libdhmc), Cint, (Ptr{Cvoid},), ctx.h), "dhmc_metric_window_begin")
+update_metric_window!(ctx, λ) = check(ctx, ccall((:dhmc_update_metric_diag_window, libdhmc), Cint, (Ptr{Cvoid}, Float64), ctx.h, λ),
+                                      "dhmc_update_metric_diag_window")
+metric_window_end!(ctx) = check(ctx, ccall((:dhmc_metric_window_end, libdhmc), Cint, (Ptr{Cvoid},), ctx.h), "dhmc_metric_window_end")
 
 # dense κ (contexts created with metric = 1): GaussianKineticEnergy(M⁻¹) (hamiltonian.jl:73) and the end of a
 # TuningNUTS{Symmetric} stage (mcmc.jl:210,218-222; pooled over the context's chains)
@@ -261,10 +267,16 @@ end
 function DynamicHMC.warmup(sl::SamplingLogDensityAMD, tuning::TuningNUTS{M}, warmup_state) where {M}
     (; N, stepsize_adaptation, λ) = tuning
     ctx = sl.ctx
-    results, mcmc_reporter = run_reported!(sl, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing,
-                                           currently_warmup = true, tuning = M ≡ Nothing ? "stepsize" : "stepsize and $(M) metric")   # mcmc.jl:268-280
+    M ≡ Diagonal && metric_window_begin!(ctx)
+    results, mcmc_reporter = try
+        run_reported!(sl, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing,
+                      currently_warmup = true, tuning = M ≡ Nothing ? "stepsize" : "stepsize and $(M) metric")   # mcmc.jl:268-280
+    catch
+        M ≡ Diagonal && metric_window_end!(ctx)
+        rethrow()
+    end
     if M ≡ Diagonal
-        update_metric!(ctx, results.posterior_matrix, λ)                                              # mcmc.jl:209,281-284
+        update_metric_window!(ctx, λ)                                                                 # mcmc.jl:209,281-284
     elseif M ≡ Symmetric
         update_metric_dense!(ctx, results.posterior_matrix, λ)                                        # mcmc.jl:210,218-222 (pooled)
     end

@@ -10,7 +10,7 @@ timeout -s KILL 200 python bench.py --config 4 --chains 32768 --steps 3 --warmup
 timeout -s KILL 300 python bench.py --config 4 --transitions 1000 --steps 1 --warmup 0 2>/dev/null | tail -1 > $O/bench_c4_1000transitions.json
 for f in bench_default bench_c3 bench_c4 bench_c5 bench_c4_32768 bench_c4_1000transitions; do python -c "
 import json; d = json.load(open('$O/$f.json')); print('$f %.4g' % d['value'], 'frac %.4f' % d['roofline']['frac'], (d.get('warmup_phase') or {}).get('value'), list((d.get('other_configs') or {}).keys()), d['roofline'].get('traffic_source'))"; done
-timeout -s KILL 200 python tools/fuzz_parity.py 90 20260927 2>/dev/null | tail -2 > $O/fuzz.txt; cat $O/fuzz.txt
+timeout -s KILL 200 python tools/fuzz_parity.py 60 20260928 2>/dev/null | tail -2 > $O/fuzz.txt; cat $O/fuzz.txt
 timeout -s KILL 500 bash tools/profile.sh r04 > $O/profile.log 2>&1; tail -60 $O/profile.log
 export TMPDIR=/tmp; REPO=$PWD; cd /tmp
 for c in 3 5; do
