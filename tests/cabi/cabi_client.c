@@ -36,6 +36,17 @@ int main(void) {
     dhmc_get_stepsize(ctx, eps, 0);
     printf("version %s\nchecksum %.17g\nsteps %lld\neps0 %.17g\nleapfrogs %llu\n", dhmc_version(), sum, nsteps, eps[0],
            (unsigned long long)dhmc_last_run_leapfrogs(ctx));
+    /* a tuning stage whose metric comes from a window the kernels accumulate: no outputs at all during the stage */
+    if (dhmc_metric_window_count(ctx) != -1) { printf("window open before begin\n"); return 2; }
+    if ((rc = dhmc_metric_window_begin(ctx)) != DHMC_OK) { printf("window begin: %d\n", rc); return 2; }
+    if ((rc = dhmc_run(ctx, n, &da, NULL)) != DHMC_OK) { printf("run(window): %d\n", rc); return 2; }
+    if (dhmc_metric_window_count(ctx) != n) { printf("window count\n"); return 2; }
+    if ((rc = dhmc_update_metric_diag_window(ctx, 0.0)) != DHMC_OK) { printf("window update: %d\n", rc); return 2; }
+    if (dhmc_update_metric_diag_window(ctx, 0.0) != DHMC_ERR_INVALID_ARGUMENT) { printf("closed window accepted\n"); return 2; }
+    if ((rc = dhmc_run(ctx, n, NULL, &out)) != DHMC_OK) { printf("run after window: %d\n", rc); return 2; }
+    sum = 0.0;
+    for (int64_t i = 0; i < 8 * n * 100; ++i) sum += draws[i];
+    printf("checksum_after_window %.17g\n", sum);
     free(draws); free(steps);
     return dhmc_destroy(ctx) == DHMC_OK ? 0 : 2;
 }

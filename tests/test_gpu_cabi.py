@@ -39,3 +39,6 @@ def test_plain_c_client_reproduces_ctypes_path(tmp_path):
     assert int(got["steps"]) == int(b["steps"].sum())
     assert float(got["eps0"]) == ctx.stepsize()[0]
     assert int(got["leapfrogs"]) == ctx.last_run_leapfrogs()
+    ctx.metric_window_begin(); ctx.run_into(30, {}, da={}); ctx.update_metric_diag_window()
+    c = ctx.run(30, fields=["draws"])
+    assert float(got["checksum_after_window"]) == float(np.cumsum(c["draws"].ravel())[-1])
