@@ -275,7 +275,7 @@ int dhmc_set_logdensity_callback(dhmc_ctx* ctx, dhmc_logdensity_fn fn, void* use
 /* ---- warmup(::InitialStepsizeSearch) (mcmc.jl:134-148 -> stepsize.jl:46-85) ---------- */
 int dhmc_find_initial_stepsize(dhmc_ctx* ctx, const dhmc_stepsize_search* params);
 
-/* ---- the per-draw loops (mcmc.jl:271-280 with `da`, :374-379 with da == NULL) -------- */
+/* ---- the per-draw loops (mcmc.jl:271-280 with `da`, :374-379 with da == NULL); `out` may be NULL (nothing recorded) -------- */
 int dhmc_run(dhmc_ctx* ctx, int64_t n_transitions, const dhmc_dual_averaging* da,
              const dhmc_outputs* out);
 
