@@ -9,6 +9,44 @@ import numpy as np
 ACCEPTANCE_QUANTILES = [0.05, 0.25, 0.5, 0.75, 0.95]      # diagnostics.jl:35
 
 
+class InvalidTree:
+    """trees.jl:180-200: positions relative to the starting node.  left < right: the tree was turning there; left == right: a
+    divergent node; (1, 0) is the sentinel REACHED_MAX_DEPTH; any other left > right is disallowed.  The statistics arrays hold the
+    two integers (`termination_left`, `termination_right`); `termination(tree_statistics, chain, i)` builds this view of one entry."""
+    __slots__ = ("left", "right")
+
+    def __init__(self, left, right=None):                  # InvalidTree(i) = InvalidTree(i, i) (trees.jl:185)
+        self.left = int(left)
+        self.right = int(left if right is None else right)
+        if self.left > self.right and (self.left, self.right) != (1, 0):
+            raise ValueError("ArgumentError: left > right is reserved for REACHED_MAX_DEPTH = InvalidTree(1, 0)")
+
+    def __eq__(self, other):
+        return isinstance(other, InvalidTree) and (self.left, self.right) == (other.left, other.right)
+
+    def __hash__(self):
+        return hash((self.left, self.right))
+
+    def __repr__(self):                                    # Base.show (trees.jl:189-199)
+        if is_divergent(self):
+            return f"divergence at position {self.left}"
+        if self == REACHED_MAX_DEPTH:
+            return "reached maximum depth without divergence or turning"
+        return f"turning at positions {self.left}:{self.right}"
+
+
+def is_divergent(invalid_tree):                            # trees.jl:187
+    return invalid_tree.left == invalid_tree.right
+
+
+REACHED_MAX_DEPTH = InvalidTree(1, 0)                      # trees.jl:202
+
+
+def termination(tree_statistics, chain, i):
+    """`tree_statistics[i].termination` of one chain (NUTS.jl:208-221) as an InvalidTree."""
+    return InvalidTree(int(tree_statistics.termination_left[chain, i]), int(tree_statistics.termination_right[chain, i]))
+
+
 def EBFMI(tree_statistics):
     """Energy Bayesian fraction of missing information (diagnostics.jl:29): mean(abs2, diff(π)) / var(π), per chain."""
     pi = np.asarray(tree_statistics.pi)

@@ -119,6 +119,22 @@ def test_diagnostics(pkg):   # test_diagnostics.jl: EBFMI of iid noise ∈ [1.8,
     assert abs(eb2 - eb) < 1e-9 * eb
 
 
+def test_invalid_tree_and_its_sentinel(pkg):   # trees.jl:180-202, exported by DynamicHMC.Diagnostics (diagnostics.jl:8-9)
+    d = pkg.diagnostics
+    assert repr(d.InvalidTree(3)) == "divergence at position 3" and d.is_divergent(d.InvalidTree(3)) and d.InvalidTree(3) == d.InvalidTree(3, 3)
+    assert repr(d.InvalidTree(-2, 5)) == "turning at positions -2:5" and not d.is_divergent(d.InvalidTree(-2, 5))
+    assert repr(d.REACHED_MAX_DEPTH) == "reached maximum depth without divergence or turning"
+    assert d.REACHED_MAX_DEPTH == d.InvalidTree(1, 0) and not d.is_divergent(d.REACHED_MAX_DEPTH)
+    with pytest.raises(ValueError):
+        d.InvalidTree(4, 2)
+    ts = pkg.TreeStatisticsNUTS(pi=np.zeros((1, 3)), depth=np.zeros((1, 3), int), termination_left=np.array([[1, -4, 2]]),
+                                termination_right=np.array([[0, 3, 2]]), acceptance_rate=np.ones((1, 3)), steps=np.ones((1, 3), int),
+                                directions=np.zeros((1, 3), np.uint32))
+    assert [repr(d.termination(ts, 0, i)) for i in range(3)] == ["reached maximum depth without divergence or turning",
+                                                                 "turning at positions -4:3", "divergence at position 2"]
+    assert d.count_terminations(ts) == dict(max_depth=1, divergence=1, turning=1)
+
+
 def test_shard_chains(pkg):
     for total, world in ((4096, 8), (10, 4), (3, 8), (32768, 8)):
         blocks = [pkg.sharding.shard_chains(total, world, r) for r in range(world)]
