@@ -32,9 +32,11 @@ def classic(work_ms, order):
     return end
 
 
-def segmented(work_ms, order, long_flag, nseg, per_xcd_count, poll_us, grid, empty_us=1.0, limit_ms=5000.0):
-    """One segment per workgroup.  Returns (makespan or None if chains were left / the time limit hit, workgroups issued)."""
+def segmented(work_ms, order, long_flag, nseg, per_xcd_count, poll_us, grid, empty_us=1.0, limit_ms=5000.0, xcd_speed=None):
+    """One segment per workgroup.  Returns (makespan or None if chains were left / the time limit hit, workgroups issued).
+    xcd_speed[x]: relative speed of XCD x (1.0 = nominal) — real XCDs do not run in lock step."""
     C = len(work_ms)
+    xcd_speed = xcd_speed or [1.0] * XCDS
     seg_ms = [work_ms[c] if long_flag[c] else work_ms[c] / nseg for c in range(C)]
     left = [1 if long_flag[c] else nseg for c in range(C)]
     fresh = 0
@@ -70,8 +72,8 @@ def segmented(work_ms, order, long_flag, nseg, per_xcd_count, poll_us, grid, emp
         elif rings[x] and rings[x][0][0] <= t:
             took = rings[x].pop(0)[1]
         if took is not None:
-            heapq.heappush(events, (t + seg_ms[took], x, took))
-            heapq.heappush(slots[x], t + seg_ms[took])
+            heapq.heappush(events, (t + seg_ms[took] / xcd_speed[x], x, took))
+            heapq.heappush(slots[x], t + seg_ms[took] / xcd_speed[x])
         else:
             # nothing to take now
             if per_xcd_count:
@@ -83,8 +85,8 @@ def segmented(work_ms, order, long_flag, nseg, per_xcd_count, poll_us, grid, emp
                         flush(nxt)
                         c = rings[x].pop(0)[1] if rings[x] else None
                         if c is not None:
-                            heapq.heappush(events, (nxt + seg_ms[c], x, c))
-                            heapq.heappush(slots[x], nxt + seg_ms[c])
+                            heapq.heappush(events, (nxt + seg_ms[c] / xcd_speed[x], x, c))
+                            heapq.heappush(slots[x], nxt + seg_ms[c] / xcd_speed[x])
                             b += 1
                             continue
                     wait = poll_us / 1000.0
@@ -112,6 +114,11 @@ def main():
         m3, w3 = segmented(work, lpt, longf, nseg, False, 0, 2 * total + 2048)
         m4, w4 = segmented(work, lpt, longf, nseg, True, 30.0, 8 * total + 8192)
         print(f" | v3 {'does not finish' if m3 is None else '%.1f' % m3} ({w3} workgroups) | v4 {'chains left' if m4 is None else '%.1f' % m4} ({w4} of {8 * total + 8192} workgroups)")
+        # the same with XCDs that differ by a percent or two in speed: one of them runs out of its own chains first
+        speed = [1.0, 0.99, 1.01, 1.0, 0.985, 1.015, 1.0, 1.02]
+        m3, w3 = segmented(work, lpt, longf, nseg, False, 0, 2 * total + 2048, xcd_speed=speed)
+        m4, w4 = segmented(work, lpt, longf, nseg, True, 30.0, 8 * total + 8192, xcd_speed=speed)
+        print(f"      XCD speeds within 2 %: v3 {'does not finish within 5 s' if m3 is None else '%.1f' % m3} ({w3} workgroups) | v4 {'chains left' if m4 is None else '%.1f' % m4} ({w4} of {8 * total + 8192} workgroups)")
 
 
 if __name__ == "__main__":
