@@ -245,11 +245,18 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_GRAPH")) c->use_graph = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_HOST_CHUNK")) c->host_chunk = std::atoll(e);
     if (const char* e = std::getenv("DHMC_LAUNCH_ORDER")) c->launch_order_on = std::atoi(e) != 0;
+    // Chains of at most 64 coordinates with a diagonal metric: several chains per wavefront (packed_core.hpp) for the families that
+    // have a packed evaluator; the same bits as the wave-per-chain kernel, which DHMC_PACKED=0 brings back.
+    c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::lanes_per_chain(D) > 0;
+    if (const char* e = std::getenv("DHMC_PACKED")) c->packed = c->packed && std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_PK_ALIGN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->pk_align = v; }
+    if (const char* e = std::getenv("DHMC_PK_LDS_LEVELS")) c->pk_lds_levels = std::atoi(e);
     if (const char* e = std::getenv("DHMC_FUSE_K2")) c->fuse_k2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
     auto fail = [&](int rc) { dhmc_destroy(c); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(DHMC_ERR_NO_DEVICE);
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && n > 0) c->num_cus = n; }
     const size_t C = cfg->chains, Dp = c->Dpad;
     int rc;
     if ((rc = dev_alloc(c, &c->st.q, C * Dp))) return fail(rc);
@@ -747,6 +754,23 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         P.chain_work = c->d_chain_work;
         P.launch_order = c->launch_order_valid ? c->d_launch_order : nullptr;
     }
+    const bool packed = per_draw_kernel && c->packed;
+    const Op run_op = packed ? Op::RunPacked : Op::Run;
+    if (packed) {
+        // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs at most 2 waves per SIMD, and a
+        // launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has the CU's 160 KB almost to itself)
+        const int L = pk::lanes_per_chain(D), gpw = 64 / L;
+        const long long waves = ((long long)C + gpw - 1) / gpw;
+        const long long wpc = std::min<long long>(8, std::max<long long>(1, (waves + c->num_cus - 1) / c->num_cus));
+        const size_t budget = std::min<size_t>((size_t)64 * 1024, (size_t)160 * 1024 / (size_t)wpc);
+        const size_t scal = pk::lds_bytes_per_wave(L, P.max_depth, 0);
+        int levels = budget > scal ? (int)((budget - scal) / pk::lds_bytes_per_wave(L, 0, 1)) : 0;
+        if (c->pk_lds_levels >= 0) levels = c->pk_lds_levels;
+        levels = std::max(0, std::min(levels, std::max(0, P.max_depth - 1)));
+        while (levels > 0 && pk::lds_bytes_per_wave(L, P.max_depth, levels) > (size_t)64 * 1024) levels -= 1;
+        P.pk_lds_levels = levels;
+        P.pk_align = c->pk_align;
+    }
     if (c->win_n >= 0) {       // an open metric window: every transition's draw joins the running moments (capi_metric.hip)
         P.win_mean = c->d_win; P.win_m2 = c->d_win + (size_t)C * c->Dpad; P.win_n0 = c->win_n;
     }
@@ -1088,7 +1112,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 chunk_ms += ms;
             }
             if (e == hipSuccess) e = hipEventRecord(c->ev_k0[b], c->stream);
-            if (e == hipSuccess && (rc = dispatch(c, Op::Run, &Q))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
+            if (e == hipSuccess && (rc = dispatch(c, run_op, &Q))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(c->ev_k1[b], c->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_k1[b], 0);
@@ -1105,7 +1129,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             }
         if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
     } else if (e == hipSuccess) {
-        rc = dispatch(c, Op::Run, &P);
+        rc = dispatch(c, run_op, &P);
         if (rc) { cleanup(); return rc; }
         e = hipGetLastError();
     }

@@ -6,6 +6,7 @@
 #include "dense_rounds.hpp"
 #include "nuts_dense_kernel.hpp"
 #include "nuts_kernels.hpp"
+#include "packed_core.hpp"
 #include "probe_kernels.hpp"
 
 namespace dhmc {
@@ -15,7 +16,7 @@ struct RoundArgs {
     RoundBuffers R;
 };
 
-enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3, ProbeTrajectory, ProbeRatios };
+enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3, ProbeTrajectory, ProbeRatios, RunPacked };
 
 // launches `op` of family T with NPL = npl slots per lane on stream s (M: the dense metric, or null)
 template <class T>

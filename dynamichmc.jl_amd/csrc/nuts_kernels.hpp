@@ -28,6 +28,7 @@
 #include "../../include/dhmc_detmath.h"
 #include "detmath_dev.hpp"
 #include "philox_dev.hpp"
+#include "run_params.hpp"
 #include "targets.hpp"
 #include "wave.hpp"
 
@@ -41,71 +42,6 @@ namespace dhmc {
 #define DHMC_BLOCK_FENCE(k) do { } while (0)
 #endif
 
-// DualAveragingState (stepsize.jl:121-127)
-struct DAState {
-    double mu;
-    double Hbar;
-    double logeps;
-    double logeps_bar;
-    int64_t m;
-};
-
-struct DeviceOutputs {
-    double* draws;
-    double* logdensities;
-    double* eps;
-    double* pi;
-    double* acceptance_rate;
-    int64_t* steps;
-    int64_t* term_left;
-    int64_t* term_right;
-    int32_t* depth;
-    uint32_t* directions;
-};
-
-struct ChainArrays {
-    double* q;       // [C][Dpad]
-    double* g;       // [C][Dpad]
-    double* lq;      // [C]
-    double* minv;    // [C][Dpad]  pads = 1
-    double* W;       // [C][Dpad]  sqrt(1/minv), pads = 0
-    double* eps;     // [C]
-    DAState* da;     // [C]
-    uint32_t* transition;  // [C]
-    uint32_t* status;      // [C]
-    double* ws;      // [C][nvec][Dpad] workspace
-};
-
-struct RunParams {
-    int D, Dpad, C, chain_offset, max_depth, nvec;
-    int l1_in_lds, chain_base;   // chain_base: first chain of this launch (round engines run half-batches)
-    int k3_block;                // round engines: K3 as a workgroup per chain (dense_rounds_k3b.hpp) where it applies
-    int one_product;             // dense round engine: one M⁻¹ product per leapfrog (dense_rounds.hpp; include/dhmc.h dhmc_set_dense_products)
-    int fuse_k2;                 // … and K3b also takes the chain's next position update and density evaluation (K2's work) where the
-                                 // family can be evaluated a block per wave (targets.hpp BlockEval)
-    double min_delta;
-    uint64_t seed;
-    int64_t N;
-    int64_t out_stride;          // record (chain, n) of the outputs is at chain * out_stride + n (0: out_stride = N): a call whose
-                                 // host outputs leave in chunks writes every chunk into a staging buffer of the chunk's length
-    ChainArrays st;
-    int adapt, da_init, da_finalize, t0;
-    double delta, gamma, kappa;
-    DeviceOutputs out;
-    TargetParams tp;
-    unsigned long long* leapfrog_counter;  // total leapfrog steps of the launch (may be null)
-    // an open metric window (include/dhmc.h dhmc_metric_window_begin): running mean and sum of squared deviations of every chain's
-    // draws, [C][Dpad] each (null: no window), and the number of draws the window held before this launch
-    double* win_mean;
-    double* win_m2;
-    int64_t win_n0;
-    // The per-draw kernels walk all N transitions of a chain in one wave, so a launch ends with its slowest chain.  chain_work[chain]
-    // := the leapfrog steps this launch spent on the chain (may be null); launch_order (may be null): workgroup b takes chain
-    // launch_order[b] — the host sorts the chains by the previous launch's work, longest first (dhmc_capi.hip run_call), so that a
-    // chain with persistently deeper trees starts in the first wave of workgroups instead of holding the last one open.
-    unsigned* chain_work;
-    const int* launch_order;
-};
 
 // One chain's position after its transition number `n_in_call` of this launch joins the window's moments: rows at `row`
 // (chain * Dpad [+ the wave's offset]), lane l's slot k is coordinate l + 64k of that row.  Pads hold zeros throughout.
@@ -136,14 +72,6 @@ __device__ __forceinline__ void window_accumulate(const RunParams& P, size_t row
     }
 }
 
-// workspace vector indices (units of Dpad doubles inside one chain's block)
-__host__ __device__ inline int ws_p0() { return 0; }
-__host__ __device__ inline int ws_edge(int dir, int which) { return 1 + 3 * dir + which; }  // which: 0 q, 1 p, 2 g
-__host__ __device__ inline int ws_rho_top() { return 7; }
-__host__ __device__ inline int ws_stack(int level, int which) { return 8 + 3 * level + which; }  // 0 first, 1 last, 2 rho
-__host__ __device__ inline int ws_slot(int max_depth, int s, int which) { return 8 + 3 * max_depth + 2 * s + which; }  // 0 q, 1 g
-__host__ __device__ inline int ws_nslots(int max_depth) { return max_depth + 3; }
-__host__ __device__ inline int ws_nvec(int max_depth) { return 8 + 3 * max_depth + 2 * ws_nslots(max_depth); }
 
 // LDS carve (one wave per block): m[Dpad], the level-0 suspended momentum [Dpad], (optionally)
 // the level-1 suspended summary first/last [2][Dpad] — its ρ is first+last, recomputed — then

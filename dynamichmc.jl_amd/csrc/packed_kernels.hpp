@@ -1,0 +1,139 @@
+// Device side of the packed small-D engine (packed_core.hpp): the group's cross-lane operations on gfx950 and the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "detmath_dev.hpp"
+#include "packed_core.hpp"
+#include "targets.hpp"
+#include "wave.hpp"
+
+namespace dhmc {
+
+// DHMC_TARGET_* of a functor of targets.hpp that has a packed evaluator (-1: none)
+template <class T> struct PackedId { static constexpr int value = -1; };
+template <> struct PackedId<StdNormalT> { static constexpr int value = DHMC_TARGET_STD_NORMAL; };
+template <> struct PackedId<DiagNormalT> { static constexpr int value = DHMC_TARGET_DIAG_NORMAL; };
+template <> struct PackedId<FunnelT> { static constexpr int value = DHMC_TARGET_FUNNEL; };
+template <> struct PackedId<AlwaysDivergentT> { static constexpr int value = DHMC_TARGET_ALWAYS_DIVERGENT; };
+
+// A chain's group: L adjacent lanes, aligned to L.  Every operation is called with all lanes of the group active (the group's
+// lanes hold identical control state), possibly under a divergent exec mask of the wave.
+//   sum      the top log2(L) levels of the ABI's summation tree: xor butterfly 1, 2, 4, 8 inside the group by DPP (quad_perm,
+//            quad_perm, row_half_mirror, row_mirror — equal to the xor pairing because the lanes of an already reduced subgroup
+//            hold identical values); every lane of the group gets the total
+//   first    the value of the group's lane 0, bit for bit (a DPP broadcast, not a sum: -0 stays -0)
+//   pick     the value of the group's lane `src` (run-time index: ds_bpermute)
+//   all      a predicate over the group's lanes (ballot of the wave's active lanes, masked to the group)
+template <int L>
+struct PackedGroup {
+    template <int N>
+    static __device__ __forceinline__ void sum_n(double (&v)[N]) {
+        if constexpr (L >= 2) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
+        }
+        if constexpr (L >= 4) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x4E>(v[i]);   // quad_perm [2,3,0,1]
+        }
+        if constexpr (L >= 8) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x141>(v[i]);  // row_half_mirror
+        }
+        if constexpr (L >= 16) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_f64<0x140>(v[i]);  // row_mirror
+        }
+    }
+    static __device__ __forceinline__ double sum(double x) {
+        double v[1] = {x};
+        sum_n<1>(v);
+        return v[0];
+    }
+    static __device__ __forceinline__ double first(double x) {
+        if constexpr (L == 1) return x;
+        else if constexpr (L == 2) return dpp_f64<0xA0>(x);                   // quad_perm [0,0,2,2]
+        else {
+            const int sub = (int)(threadIdx.x & (L - 1));
+            double b = dpp_f64<0x00>(x);                                      // quad_perm [0,0,0,0]: every quad's lane 0
+            if constexpr (L >= 8) {
+                const double hm = dpp_f64<0x141>(b);                          // lanes 4..7 of a half row read lanes 3..0
+                b = (sub & 4) ? hm : b;
+            }
+            if constexpr (L >= 16) {
+                const double mr = dpp_f64<0x140>(b);                          // lanes 8..15 of a row read lanes 7..0
+                b = (sub & 8) ? mr : b;
+            }
+            return b;
+        }
+    }
+    static __device__ __forceinline__ double pick(double x, int src) {
+        if constexpr (L == 1) return x;
+        else return __shfl(x, (int)((threadIdx.x & ~(unsigned)(L - 1)) + (unsigned)src));
+    }
+    static __device__ __forceinline__ bool all(bool pred) {
+        if constexpr (L == 1) return pred;
+        else {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(pred);
+            const unsigned long long gm = ((L >= 64 ? 0ull : (1ull << L)) - 1ull) << (threadIdx.x & ~(unsigned)(L - 1));
+            return (b & gm) == gm;
+        }
+    }
+    static __device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+};
+
+// One wavefront per workgroup, 64 / L chains in it: group `grp` of workgroup b runs the chain in place b·(64/L) + grp of the launch
+// order (RunParams::launch_order: the chains sorted by the previous launch's work, longest first — so that chains with
+// persistently deep trees share waves instead of each holding a wave of finished chains open).
+template <int TGT, int L>
+__global__ __launch_bounds__(64, 2) void nuts_run_packed_kernel(RunParams P) {
+    constexpr int CPL = pk::kCPL;
+    constexpr int GPW = 64 / L;
+    const int sub = (int)(threadIdx.x & (L - 1));
+    const int grp = (int)(threadIdx.x / L);
+    const int place = (int)blockIdx.x * GPW + grp;
+    const int chain = place < P.C ? (P.launch_order ? P.launch_order[place] : place) : P.C;
+    extern __shared__ double pk_lds[];
+    double* const lds_rows = pk_lds;
+    double* const lds_sc = pk_lds + (size_t)P.pk_lds_levels * 4 * 64 * CPL;
+    typedef PackedGroup<L> Grp;
+    typedef dm_vector Pol;
+#define PK_ATOMIC_ADD_ULL(ptr, v) atomicAdd((ptr), (v))
+#include "packed_body.inc"
+#undef PK_ATOMIC_ADD_ULL
+}
+
+template <class T>
+int launch_run_packed(const RunParams& P, hipStream_t s) {
+    constexpr int TGT = PackedId<T>::value;
+    if constexpr (TGT < 0) {
+        return DHMC_ERR_UNSUPPORTED;
+    } else {
+        const int L = pk::lanes_per_chain(P.D);
+        if (L == 0) return DHMC_ERR_UNSUPPORTED;
+        const int gpw = 64 / L;
+        const dim3 grid((unsigned)((P.C + gpw - 1) / gpw)), block(64);
+        const size_t lds = pk::lds_bytes_per_wave(L, P.max_depth, P.pk_lds_levels);
+#define DHMC_PK_LAUNCH(LL)                                                                                                     \
+    case LL: {                                                                                                                 \
+        static bool once = [] {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            return true;                                                                                                       \
+        }();                                                                                                                   \
+        (void)once;                                                                                                            \
+        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL>), grid, block, lds, s, P);                                         \
+        break;                                                                                                                 \
+    }
+        switch (L) {
+            DHMC_PK_LAUNCH(1)
+            DHMC_PK_LAUNCH(2)
+            DHMC_PK_LAUNCH(4)
+            DHMC_PK_LAUNCH(8)
+            DHMC_PK_LAUNCH(16)
+        default: return DHMC_ERR_UNSUPPORTED;
+        }
+#undef DHMC_PK_LAUNCH
+        return DHMC_OK;
+    }
+}
+
+}  // namespace dhmc

@@ -26,19 +26,11 @@
 #include "../../include/dhmc.h"
 #include "../../include/dhmc_detmath.h"
 #include "detmath_dev.hpp"
+#include "run_params.hpp"
 #include "wave.hpp"
 
 namespace dhmc {
 
-struct TargetParams {
-    const double* a;  // DIAG_NORMAL: mu      TRIDIAG: diag      LOGISTIC: X  [n][Dpad]     DENSE_NORMAL: mu        (padded, device)
-    const double* b;  // DIAG_NORMAL: prec    TRIDIAG: off       LOGISTIC: Xᵀ [D][npad]    DENSE_NORMAL: P [Dpad][Dpad]
-    const double* c;  //                                          LOGISTIC: y  [npad]
-    int64_t n;        //                                          LOGISTIC: observations
-    int64_t npad;     //                                          LOGISTIC: n rounded up to 64
-    int32_t Dpad;
-    int32_t pad_;
-};
 
 struct StdNormalT {
     static constexpr bool kDeferred = true;

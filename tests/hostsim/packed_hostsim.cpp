@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE — a CPU simulation of the packed per-draw kernel (dynamichmc.jl_amd/csrc/packed_body.inc).
+//
+// The kernel's body is written against a small environment (the chain's lane group, LDS, an atomic add), so the same text that
+// nuts_run_packed_kernel includes compiles here with g++ for L = 1: one "lane" holds all 64 padded coordinates of a chain, the
+// group operations are identities, and the lane-local summation tree over 64 leaves is the ABI's tree (packed_core.hpp).  The
+// CPU suite (tests/test_packed_hostsim.py) runs it against the oracle bit for bit — the tree logic, the gate, the RNG
+// bookkeeping and the per-family arithmetic of the packed engine are checked without a GPU; what is left for the GPU suite is
+// the DPP group operations and the launch geometry.  Nothing here is linked into libdhmc_amd.so.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../dynamichmc.jl_amd/csrc/packed_core.hpp"
+
+namespace dhmc {
+
+struct HostGroup {
+    template <int N> static void sum_n(double (&)[N]) {}
+    static double sum(double x) { return x; }
+    static double first(double x) { return x; }
+    static double pick(double x, int) { return x; }
+    static bool all(bool p) { return p; }
+    static bool wave_any(bool p) { return p; }
+};
+
+template <int TGT>
+static void run_chain(const RunParams& P, int chain, double* lds_rows, double* lds_sc) {
+    constexpr int L = 1, CPL = 64, GPW = 1;
+    const int sub = 0, grp = 0;
+    typedef HostGroup Grp;
+    typedef dm_generic Pol;
+#define PK_ATOMIC_ADD_ULL(ptr, v) (*(ptr) += (v))
+#include "../../dynamichmc.jl_amd/csrc/packed_body.inc"
+#undef PK_ATOMIC_ADD_ULL
+}
+
+}  // namespace dhmc
+
+extern "C" int hostsim_packed_run(int target, const dhmc::RunParams* Pin) {
+    using namespace dhmc;
+    RunParams P = *Pin;
+    if (P.Dpad != 64 || P.D > 64) return 1;
+    std::vector<double> ws((size_t)P.C * P.nvec * P.Dpad, 0.0);
+    P.st.ws = ws.data();
+    std::vector<double> rows((size_t)(P.pk_lds_levels > 0 ? P.pk_lds_levels : 1) * 4 * 64, 0.0), sc((size_t)P.max_depth * 4 + 4, 0.0);
+    for (int chain = 0; chain < P.C; ++chain) {
+        switch (target) {
+        case DHMC_TARGET_STD_NORMAL: run_chain<DHMC_TARGET_STD_NORMAL>(P, chain, rows.data(), sc.data()); break;
+        case DHMC_TARGET_DIAG_NORMAL: run_chain<DHMC_TARGET_DIAG_NORMAL>(P, chain, rows.data(), sc.data()); break;
+        case DHMC_TARGET_FUNNEL: run_chain<DHMC_TARGET_FUNNEL>(P, chain, rows.data(), sc.data()); break;
+        case DHMC_TARGET_ALWAYS_DIVERGENT: run_chain<DHMC_TARGET_ALWAYS_DIVERGENT>(P, chain, rows.data(), sc.data()); break;
+        default: return 2;
+        }
+    }
+    return 0;
+}
+extern "C" int hostsim_ws_nvec(int max_depth) { return dhmc::ws_nvec(max_depth); }
+extern "C" int hostsim_sizeof_runparams() { return (int)sizeof(dhmc::RunParams); }
