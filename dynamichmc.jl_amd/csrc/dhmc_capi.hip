@@ -757,17 +757,17 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     const bool packed = per_draw_kernel && c->packed;
     const Op run_op = packed ? Op::RunPacked : Op::Run;
     if (packed) {
-        // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs at most 2 waves per SIMD, and a
-        // launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has the CU's 160 KB almost to itself)
+        // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
+        // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)
         const int L = pk::lanes_per_chain(D), gpw = 64 / L;
         const long long waves = ((long long)C + gpw - 1) / gpw;
-        const long long wpc = std::min<long long>(8, std::max<long long>(1, (waves + c->num_cus - 1) / c->num_cus));
-        const size_t budget = std::min<size_t>((size_t)64 * 1024, (size_t)160 * 1024 / (size_t)wpc);
-        const size_t scal = pk::lds_bytes_per_wave(L, P.max_depth, 0);
-        int levels = budget > scal ? (int)((budget - scal) / pk::lds_bytes_per_wave(L, 0, 1)) : 0;
+        const long long wpc = std::min<long long>(4, std::max<long long>(1, (waves + c->num_cus - 1) / c->num_cus));
+        const size_t budget = std::min<size_t>(pk::kMaxLdsPerWave, (size_t)160 * 1024 / (size_t)wpc);
+        const size_t fixed = pk::lds_bytes_per_wave(L, P.max_depth, 0);
+        int levels = budget > fixed ? (int)((budget - fixed) / pk::lds_bytes_per_level()) : 0;
         if (c->pk_lds_levels >= 0) levels = c->pk_lds_levels;
         levels = std::max(0, std::min(levels, std::max(0, P.max_depth - 1)));
-        while (levels > 0 && pk::lds_bytes_per_wave(L, P.max_depth, levels) > (size_t)64 * 1024) levels -= 1;
+        while (levels > 0 && pk::lds_bytes_per_wave(L, P.max_depth, levels) > pk::kMaxLdsPerWave) levels -= 1;
         P.pk_lds_levels = levels;
         P.pk_align = c->pk_align;
     }

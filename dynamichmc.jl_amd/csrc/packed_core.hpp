@@ -224,10 +224,12 @@ inline bool family_is_packed(int target) {
     return target == DHMC_TARGET_STD_NORMAL || target == DHMC_TARGET_DIAG_NORMAL || target == DHMC_TARGET_FUNNEL ||
            target == DHMC_TARGET_ALWAYS_DIVERGENT;
 }
-// LDS of one wave (bytes): `levels` suspended levels (1 .. levels: first, last, ρ, proposal) of the wave's 64 / L chains — 64·CPL
-// doubles per row set — and four scalars per level and chain
+// LDS of one wave (bytes): six rows per chain that are touched once per doubling (64·CPL doubles per row set of the wave's 64 / L
+// chains), `levels` suspended levels (1 .. levels: first, last, ρ, proposal), and four scalars per level and chain
+constexpr size_t kMaxLdsPerWave = 64 * 1024;
+inline size_t lds_bytes_per_level() { return sizeof(double) * 4 * 64 * kCPL; }
 inline size_t lds_bytes_per_wave(int L, int max_depth, int levels) {
-    return sizeof(double) * ((size_t)levels * 4 * 64 * kCPL + (size_t)max_depth * 4 * (64 / L));
+    return sizeof(double) * ((size_t)(6 + 4 * levels) * 64 * kCPL + (size_t)max_depth * 4 * (64 / L));
 }
 
 }  // namespace pk

@@ -85,7 +85,7 @@ struct PackedGroup {
 // order (RunParams::launch_order: the chains sorted by the previous launch's work, longest first — so that chains with
 // persistently deep trees share waves instead of each holding a wave of finished chains open).
 template <int TGT, int L>
-__global__ __launch_bounds__(64, 2) void nuts_run_packed_kernel(RunParams P) {
+__global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
     constexpr int CPL = pk::kCPL;
     constexpr int GPW = 64 / L;
     const int sub = (int)(threadIdx.x & (L - 1));
@@ -93,8 +93,9 @@ __global__ __launch_bounds__(64, 2) void nuts_run_packed_kernel(RunParams P) {
     const int place = (int)blockIdx.x * GPW + grp;
     const int chain = place < P.C ? (P.launch_order ? P.launch_order[place] : place) : P.C;
     extern __shared__ double pk_lds[];
-    double* const lds_rows = pk_lds;
-    double* const lds_sc = pk_lds + (size_t)P.pk_lds_levels * 4 * 64 * CPL;
+    double* const lds_cold = pk_lds;
+    double* const lds_rows = pk_lds + (size_t)6 * 64 * CPL;
+    double* const lds_sc = lds_rows + (size_t)P.pk_lds_levels * 4 * 64 * CPL;
     typedef PackedGroup<L> Grp;
     typedef dm_vector Pol;
 #define PK_ATOMIC_ADD_ULL(ptr, v) atomicAdd((ptr), (v))
@@ -116,7 +117,7 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
 #define DHMC_PK_LAUNCH(LL)                                                                                                     \
     case LL: {                                                                                                                 \
         static bool once = [] {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk::kMaxLdsPerWave); \
             return true;                                                                                                       \
         }();                                                                                                                   \
         (void)once;                                                                                                            \

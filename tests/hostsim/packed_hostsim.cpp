@@ -24,7 +24,7 @@ struct HostGroup {
 };
 
 template <int TGT>
-static void run_chain(const RunParams& P, int chain, double* lds_rows, double* lds_sc) {
+static void run_chain(const RunParams& P, int chain, double* lds_cold, double* lds_rows, double* lds_sc) {
     constexpr int L = 1, CPL = 64, GPW = 1;
     const int sub = 0, grp = 0;
     typedef HostGroup Grp;
@@ -42,13 +42,13 @@ extern "C" int hostsim_packed_run(int target, const dhmc::RunParams* Pin) {
     if (P.Dpad != 64 || P.D > 64) return 1;
     std::vector<double> ws((size_t)P.C * P.nvec * P.Dpad, 0.0);
     P.st.ws = ws.data();
-    std::vector<double> rows((size_t)(P.pk_lds_levels > 0 ? P.pk_lds_levels : 1) * 4 * 64, 0.0), sc((size_t)P.max_depth * 4 + 4, 0.0);
+    std::vector<double> coldv(6 * 64, 0.0), rows((size_t)(P.pk_lds_levels > 0 ? P.pk_lds_levels : 1) * 4 * 64, 0.0), sc((size_t)P.max_depth * 4 + 4, 0.0);
     for (int chain = 0; chain < P.C; ++chain) {
         switch (target) {
-        case DHMC_TARGET_STD_NORMAL: run_chain<DHMC_TARGET_STD_NORMAL>(P, chain, rows.data(), sc.data()); break;
-        case DHMC_TARGET_DIAG_NORMAL: run_chain<DHMC_TARGET_DIAG_NORMAL>(P, chain, rows.data(), sc.data()); break;
-        case DHMC_TARGET_FUNNEL: run_chain<DHMC_TARGET_FUNNEL>(P, chain, rows.data(), sc.data()); break;
-        case DHMC_TARGET_ALWAYS_DIVERGENT: run_chain<DHMC_TARGET_ALWAYS_DIVERGENT>(P, chain, rows.data(), sc.data()); break;
+        case DHMC_TARGET_STD_NORMAL: run_chain<DHMC_TARGET_STD_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
+        case DHMC_TARGET_DIAG_NORMAL: run_chain<DHMC_TARGET_DIAG_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
+        case DHMC_TARGET_FUNNEL: run_chain<DHMC_TARGET_FUNNEL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
+        case DHMC_TARGET_ALWAYS_DIVERGENT: run_chain<DHMC_TARGET_ALWAYS_DIVERGENT>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         default: return 2;
         }
     }

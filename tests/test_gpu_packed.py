@@ -1,0 +1,148 @@
+"""GPU: the packed small-D engine (csrc/packed_core.hpp: several chains per wavefront, L lanes × 4 coordinates per chain) against
+the oracle and against the wave-per-chain kernel, bit for bit — every group width (L = 1, 2, 4, 8, 16), every packed family,
+chain counts that leave idle groups in the last wave, metric windows, launch order, host outputs in chunks, gate widths and LDS
+level counts.  The CPU suite runs the same body through tests/hostsim (L = 1); this file adds the DPP group operations."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same(a, b, what=""):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{what}: field {k} differs"
+
+
+def _stages(dev, ora, what):
+    for i, (N, da) in enumerate([(24, dict()), (16, None), (9, dict(init=1, finalize=0)), (7, dict(init=0, finalize=1))]):
+        _same(dev.run(N, da=da), ora.run(N, da=da), f"{what} stage {i}")
+        assert np.array_equal(dev.stepsize(), ora.stepsize()), what
+    for x, y in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, y), what
+    assert np.array_equal(dev.status(), ora.status())
+
+
+@pytest.mark.parametrize("D,C", [(2, 5), (4, 70), (7, 33), (13, 17), (30, 11), (32, 64), (33, 9), (64, 6)])
+def test_funnel_every_group_width_matches_oracle(pkg, D, C):
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=100 + D)
+    ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=100 + D, threads=8)
+    for e in (dev, ora):
+        e.init(); e.set_stepsize(0.2)
+    _stages(dev, ora, f"funnel D={D} C={C}")
+
+
+@pytest.mark.parametrize("D", [3, 10, 30, 50])
+def test_normal_families_match_oracle(pkg, D):
+    C = 21
+    rng = np.random.default_rng(D)
+    minv = rng.uniform(0.3, 3.0, size=(C, D))
+    dev = pkg.DeviceContext(D, C, seed=2)
+    ora = ol.Oracle(D, C, seed=2, threads=8)
+    for e in (dev, ora):
+        e.init(); e.set_metric_diag(minv); e.find_initial_stepsize()
+    assert np.array_equal(dev.stepsize(), ora.stepsize())
+    _stages(dev, ora, f"std normal D={D}")
+    mu, prec = rng.normal(size=D), rng.uniform(0.2, 5.0, size=D)
+    blob = ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_DIAG_NORMAL, target_params=blob, seed=4)
+    ora = ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=blob, seed=4, threads=8)
+    for e in (dev, ora):
+        e.init(); e.set_stepsize(0.3)
+    _stages(dev, ora, f"diag normal D={D}")
+
+
+def test_divergences_depth_limits_and_always_divergent(pkg):
+    D, C = 30, 24
+    rng = np.random.default_rng(3)
+    q0 = rng.normal(size=(C, D)) * 0.05
+    q0[:, 0] = np.linspace(-6.0, 2.0, C)
+    for eps, md in ((0.9, 6), (0.02, 5), (3.0, 10)):
+        dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=5, max_depth=md)
+        ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=5, max_depth=md, threads=8)
+        for e in (dev, ora):
+            e.init(q0); e.set_stepsize(eps)
+        a, b = dev.run(40), ora.run(40)
+        _same(a, b, f"eps {eps}")
+        assert np.array_equal(dev.status(), ora.status())
+    assert (b["term_left"] == b["term_right"]).any()
+    dev = pkg.DeviceContext(3, 5, target=ol.TARGET_ALWAYS_DIVERGENT, seed=9)
+    ora = ol.Oracle(3, 5, target=ol.TARGET_ALWAYS_DIVERGENT, seed=9)
+    for e in (dev, ora):
+        e.init(np.zeros((5, 3))); e.set_stepsize(0.5)
+    a = dev.run(6)
+    _same(a, ora.run(6), "always divergent")
+    assert (a["depth"] == 0).all() and (a["steps"] == 1).all()
+
+
+def test_packed_equals_wave_kernel_windows_and_launch_order(pkg):
+    """The same 300 chains through both engines: a warmup with two metric windows (the chains' work diverges, so the second and
+    later launches run in launch order), then inference with host outputs in chunks."""
+    D, C = 30, 300
+    res = []
+    for packed in (1, 0):
+        with _env(DHMC_PACKED=packed, DHMC_HOST_CHUNK=7):
+            dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=8)
+        dev.init(); dev.find_initial_stepsize()
+        out = [dev.run(30, da={})]
+        for n in (25, 40):
+            dev.metric_window_begin()
+            out.append(dev.run(n, da={}))
+            dev.update_metric_diag_window()
+        out.append(dev.run(33))
+        res.append((out, dev.metric_diag(), dev.stepsize(), dev.position(), dev.last_run_leapfrogs()))
+    for a, b in zip(res[0][0], res[1][0]):
+        _same(a, b, "packed vs wave")
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    for x, y in zip(res[0][3], res[1][3]):
+        assert np.array_equal(x, y)
+    assert res[0][4] == res[1][4] == int(res[0][0][-1]["steps"].sum())
+
+
+@pytest.mark.parametrize("align,levels", [(1, 0), (2, 1), (8, 2), (16, 6)])
+def test_gate_width_and_lds_levels_change_no_result(pkg, align, levels):
+    D, C = 30, 40
+    with _env(DHMC_PK_ALIGN=align, DHMC_PK_LDS_LEVELS=levels):
+        dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=21)
+    ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=21, threads=8)
+    for e in (dev, ora):
+        e.init(); e.set_stepsize(0.15)
+    _same(dev.run(30, da={}), ora.run(30, da={}), f"align {align} levels {levels}")
+    _same(dev.run(30), ora.run(30), f"align {align} levels {levels}")
+
+
+def test_chain_offset_is_the_rng_key(pkg):
+    """Chains 40..79 of a job run as their own context: the same draws as in the whole job (sharding over GPUs)."""
+    D = 30
+    whole = pkg.DeviceContext(D, 80, target=ol.TARGET_FUNNEL, seed=6)
+    part = pkg.DeviceContext(D, 40, target=ol.TARGET_FUNNEL, seed=6, chain_offset=40)
+    for e in (whole, part):
+        e.init(); e.set_stepsize(0.2)
+    a, b = whole.run(25, da={}), part.run(25, da={})
+    for k in a:
+        assert np.array_equal(a[k][40:], b[k]), k
