@@ -86,10 +86,14 @@ struct dhmc_ctx {
     bool launch_order_valid = false;
     int launch_order_on = 1;               // DHMC_LAUNCH_ORDER=0: workgroup b takes chain b, always
     // the packed small-D engine (packed_core.hpp): several chains per wavefront for diagonal-metric chains of at most 64 coordinates
-    int packed = 0;                        // DHMC_PACKED=0: the wave-per-chain kernel instead
+    int packed = 0;                        // the context's chains can run packed; DHMC_PACKED=0: never, =1: always, unset: by the previous launch's work
+    int packed_force = 0;
     int pk_align = 4;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two)
+    int pk_cpl = 0;                        // DHMC_PK_CPL: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
     int pk_lds_levels = -1;                // DHMC_PK_LDS_LEVELS: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)
     int num_cus = 256;
+    bool tail_bound = false;               // the previous launch was held open by a few chains with many times the mean's leapfrog steps
+                                           // (dhmc_run: such launches go to the wave-per-chain kernel, whose leapfrog latency is lower)
     double* d_win = nullptr;   // dhmc_metric_window_begin: [2][C][Dpad] running mean / sum of squared deviations of every chain's draws
     int64_t win_n = -1;        // draws in the open metric window (-1: none open)
     bool poisoned = false;     // an external callback failed in the middle of dhmc_run: (q, ℓq, ∇ℓ) are inconsistent until dhmc_init / dhmc_import_state

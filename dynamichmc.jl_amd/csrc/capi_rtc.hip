@@ -42,6 +42,15 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     src += source;
     src += "\n";
     const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
+    // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
+    // whatever device it will run beside them on)
+    std::string arch = "--offload-arch=gfx950";
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0])
+            arch = std::string("--offload-arch=") + prop.gcnArchName;
+    }
     // DHMC_RTC_CACHE=<directory>: code objects are kept there, keyed by everything that went into them, so that the next
     // process (a new Julia session) loads instead of compiling (≈ 2 s diagonal, ≈ 15 s dense per functor and chain width)
     std::string cache_file;
@@ -51,6 +60,7 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
         int major = 0, minor = 0;
         (void)hiprtcVersion(&major, &minor);
         mix(src); mix(dhmc_version()); mix(std::to_string(major) + "." + std::to_string(minor));
+        mix(arch);                                  // a cache directory shared by machines with different GPUs holds one object per architecture
         for (const auto& e : exprs) mix(e);
         char hex[17];
         std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
@@ -82,15 +92,6 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "dhmc_user_target.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return DHMC_ERR_HIP;
     for (const auto& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
-    // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
-    // whatever device it will run beside them on)
-    std::string arch = "--offload-arch=gfx950";
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0])
-            arch = std::string("--offload-arch=") + prop.gcnArchName;
-    }
     const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"};
     const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
     size_t ls = 0;

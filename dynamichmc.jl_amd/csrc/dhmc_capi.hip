@@ -247,10 +247,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_LAUNCH_ORDER")) c->launch_order_on = std::atoi(e) != 0;
     // Chains of at most 64 coordinates with a diagonal metric: several chains per wavefront (packed_core.hpp) for the families that
     // have a packed evaluator; the same bits as the wave-per-chain kernel, which DHMC_PACKED=0 brings back.
-    c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::lanes_per_chain(D) > 0;
-    if (const char* e = std::getenv("DHMC_PACKED")) c->packed = c->packed && std::atoi(e) != 0;
+    c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::dim_is_packed(D);
+    if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = c->packed && std::atoi(e) != 0; c->packed_force = c->packed; }
     if (const char* e = std::getenv("DHMC_PK_ALIGN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->pk_align = v; }
     if (const char* e = std::getenv("DHMC_PK_LDS_LEVELS")) c->pk_lds_levels = std::atoi(e);
+    if (const char* e = std::getenv("DHMC_PK_CPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) c->pk_cpl = v; }
     if (const char* e = std::getenv("DHMC_FUSE_K2")) c->fuse_k2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_ROW_LISTS")) c->dense_row_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_DENSE_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->dense_parts = v; }
@@ -754,22 +755,36 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         P.chain_work = c->d_chain_work;
         P.launch_order = c->launch_order_valid ? c->d_launch_order : nullptr;
     }
-    const bool packed = per_draw_kernel && c->packed;
+    // Which per-draw kernel.  The packed kernel serves several chains per instruction — 1.1 (60 coordinates) to 5 times (8) the
+    // wave-per-chain kernel's throughput on chains of even work — but a trip of its loop costs more clocks than the other
+    // kernel's leapfrog (4 300 against 3 700 at 30 coordinates), and a launch ends with its slowest chain, whose leapfrogs are
+    // sequential: when the previous launch was held open by a few chains with many times the mean's work (Neal's funnel: chains in
+    // the neck run trees of the depth limit, 13 × the mean over 1000 transitions), the launch goes to the kernel with the lower
+    // latency.  The same bits either way (both kernels are checked against the oracle).  DHMC_PACKED=1 / 0: always / never.
+    const bool packed = per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
     const Op run_op = packed ? Op::RunPacked : Op::Run;
     if (packed) {
         // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
         // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)
-        const int L = pk::lanes_per_chain(D), gpw = 64 / L;
+        // coordinates per lane: two while that still leaves every wave a SIMD of its own (or when the row needs no more: D <= 32 is
+        // 16 lanes × 2), four beyond (D > 32 always: 16 lanes × 4)
+        int cpl = D > 32 ? 4 : 2;
+        if (cpl == 2) {
+            const int L2 = pk::lanes_per_chain(D, 2);
+            const long long waves2 = ((long long)C + 64 / L2 - 1) / (64 / L2);
+            if (waves2 > 4LL * c->num_cus && pk::lanes_per_chain(D, 4) < L2) cpl = 4;
+        }
+        if (c->pk_cpl && D <= 32) cpl = c->pk_cpl;
+        const int L = pk::lanes_per_chain(D, cpl), gpw = 64 / L;
         const long long waves = ((long long)C + gpw - 1) / gpw;
         const long long wpc = std::min<long long>(4, std::max<long long>(1, (waves + c->num_cus - 1) / c->num_cus));
         const size_t budget = std::min<size_t>(pk::kMaxLdsPerWave, (size_t)160 * 1024 / (size_t)wpc);
-        const size_t fixed = pk::lds_bytes_per_wave(L, P.max_depth, 0);
-        int levels = budget > fixed ? (int)((budget - fixed) / pk::lds_bytes_per_level()) : 0;
+        const size_t fixed = pk::lds_bytes_per_wave(L, cpl, P.max_depth, 0);
+        int levels = budget > fixed ? (int)((budget - fixed) / pk::lds_bytes_per_level(cpl)) : 0;
         if (c->pk_lds_levels >= 0) levels = c->pk_lds_levels;
         levels = std::max(0, std::min(levels, std::max(0, P.max_depth - 1)));
-        while (levels > 0 && pk::lds_bytes_per_wave(L, P.max_depth, levels) > pk::kMaxLdsPerWave) levels -= 1;
-        P.pk_lds_levels = levels;
-        P.pk_align = c->pk_align;
+        while (levels > 0 && pk::lds_bytes_per_wave(L, cpl, P.max_depth, levels) > pk::kMaxLdsPerWave) levels -= 1;
+        P.pk_cpl = cpl;
     }
     if (c->win_n >= 0) {       // an open metric window: every transition's draw joins the running moments (capi_metric.hip)
         P.win_mean = c->d_win; P.win_m2 = c->d_win + (size_t)C * c->Dpad; P.win_n0 = c->win_n;
@@ -1160,9 +1175,10 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             c->launch_order_valid = e == hipSuccess;
         }
+        c->tail_bound = (double)mx * C > 3.0 * (double)sum;       // (the packed engine's choice, above)
         if (std::getenv("DHMC_DEBUG_ORDER"))
-            std::fprintf(stderr, "[dhmc] launch order: N=%lld max=%u mean=%.1f valid=%d first=%d used_this_call=%d\n", (long long)N, mx, (double)sum / C,
-                         (int)c->launch_order_valid, c->launch_order_valid ? c->h_launch_order[0] : -1, P.launch_order != nullptr);
+            std::fprintf(stderr, "[dhmc] launch order: N=%lld max=%u mean=%.1f valid=%d first=%d used_this_call=%d tail_bound=%d\n", (long long)N, mx, (double)sum / C,
+                         (int)c->launch_order_valid, c->launch_order_valid ? c->h_launch_order[0] : -1, P.launch_order != nullptr, (int)c->tail_bound);
     }
     if (e == hipSuccess) {
         float ms = 0.f;

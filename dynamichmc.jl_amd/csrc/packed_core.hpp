@@ -80,6 +80,28 @@ PK_FN double demote_lq(double lq, bool pos_finite, bool grad_finite) {  // hamil
     return ok ? lq : -dm_inf();
 }
 
+// The two logaddexp's of a merge (visited statistic, ω) in one basic block when both |x - y| < 16 — the common case: the two
+// softplus rows are requested together and the Horner chains interleave; each value by exactly the operations of
+// det_logaddexp_t, so the bits of two separate calls (the wave kernels' det_logaddexp_pair_u, csrc/detmath_dev.hpp).
+template <class Pol>
+PK_FN void logaddexp_pair(double x1, double y1, double x2, double y2, double& r1, double& r2) {
+    const double d1 = __builtin_fabs(x1 - y1), d2 = __builtin_fabs(x2 - y2);
+    if ((d1 < 16.0) & (d2 < 16.0)) {
+        const int i1 = Pol::idx((int)(d1 * 16.0)), i2 = Pol::idx((int)(d2 * 16.0));
+        double c1[8], c2[8];
+        Pol::row8(DM_SOFTPLUS_TBL[i1], c1);
+        Pol::row8(DM_SOFTPLUS_TBL[i2], c2);
+        const double t1 = d1 - (double)(2 * i1 + 1) * 0.03125, t2 = d2 - (double)(2 * i2 + 1) * 0.03125;
+        const double m1 = Pol::max_nonnan(x1, y1), m2 = Pol::max_nonnan(x2, y2);
+        const double s1 = Pol::template horner_row<8>(t1, c1), s2 = Pol::template horner_row<8>(t2, c2);
+        r1 = m1 + s1;
+        r2 = m2 + s2;
+    } else {
+        r1 = det_logaddexp_t<Pol>(x1, y1);
+        r2 = det_logaddexp_t<Pol>(x2, y2);
+    }
+}
+
 // combine_turn_statistics (NUTS.jl:132-139) of two adjacent subtrees, time-ordered: x earlier, y later, each (p₋, p₊, ρ) as the
 // lane's CPL slots.  Writes ρ of the merge to rho_out (which may alias an input) and returns is_turning.  The arithmetic is
 // merge_core's (nuts_kernels.hpp), slot by slot.
@@ -217,9 +239,15 @@ struct PackedTarget<DHMC_TARGET_ALWAYS_DIVERGENT> {
     }
 };
 
-// lanes per chain for a chain of D coordinates at 4 coordinates per lane (0: not served by this engine)
-constexpr int kCPL = 4;
-inline int lanes_per_chain(int D) { return D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : 0; }
+// Lanes per chain for a chain of D coordinates at `cpl` (2 or 4) coordinates per lane; 0: not served.  Two coordinates per lane
+// (16 lanes for the 30-dim funnel, 4 chains per wave) halve the vector work and the register rows of a trip — the shorter trip is
+// what a launch waits for when a few chains with deep trees hold it open; four (8 lanes, 8 chains per wave) serve more chains per
+// instruction — the better choice once there are more chains than the chip has SIMDs to give a wave each.
+inline int lanes_per_chain(int D, int cpl) {
+    const int L = (D + cpl - 1) / cpl;
+    return L <= 1 ? 1 : L <= 2 ? 2 : L <= 4 ? 4 : L <= 8 ? 8 : L <= 16 ? 16 : 0;
+}
+inline bool dim_is_packed(int D) { return D >= 1 && D <= 64; }
 inline bool family_is_packed(int target) {
     return target == DHMC_TARGET_STD_NORMAL || target == DHMC_TARGET_DIAG_NORMAL || target == DHMC_TARGET_FUNNEL ||
            target == DHMC_TARGET_ALWAYS_DIVERGENT;
@@ -227,9 +255,9 @@ inline bool family_is_packed(int target) {
 // LDS of one wave (bytes): six rows per chain that are touched once per doubling (64·CPL doubles per row set of the wave's 64 / L
 // chains), `levels` suspended levels (1 .. levels: first, last, ρ, proposal), and four scalars per level and chain
 constexpr size_t kMaxLdsPerWave = 64 * 1024;
-inline size_t lds_bytes_per_level() { return sizeof(double) * 4 * 64 * kCPL; }
-inline size_t lds_bytes_per_wave(int L, int max_depth, int levels) {
-    return sizeof(double) * ((size_t)(6 + 4 * levels) * 64 * kCPL + (size_t)max_depth * 4 * (64 / L));
+inline size_t lds_bytes_per_level(int cpl) { return sizeof(double) * 4 * 64 * (size_t)cpl; }
+inline size_t lds_bytes_per_wave(int L, int cpl, int max_depth, int levels) {
+    return sizeof(double) * ((size_t)(6 + 4 * levels) * 64 * (size_t)cpl + (size_t)max_depth * 4 * (64 / L));
 }
 
 }  // namespace pk

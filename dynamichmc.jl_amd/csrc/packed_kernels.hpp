@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "detmath_dev.hpp"
 #include "packed_core.hpp"
+#include "nuts_kernels.hpp"
 #include "targets.hpp"
 #include "wave.hpp"
 
@@ -81,12 +82,27 @@ struct PackedGroup {
     static __device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
 };
 
+// Phase timing (tools/experiments/phase_timing.sh, -DDHMC_PHASE_TIMING builds only): the clocks a wave spends in each region of
+// the packed body, added to g_phase (nuts_kernels.hpp) — [14] counts trips of the main loop, [15] waves.
+#ifdef DHMC_PHASE_TIMING
+#define PK_PH_DECL unsigned long long ph_a0 = 0, ph_a1 = 0, ph_a2 = 0, ph_a3 = 0, ph_a4 = 0, ph_a5 = 0, ph_a6 = 0, ph_a7 = 0, ph_a8 = 0; unsigned long long ph_t0 = __builtin_readcyclecounter();
+#define PK_PH_END(i) { const unsigned long long t_ = __builtin_readcyclecounter(); ph_a##i += t_ - ph_t0; ph_t0 = t_; }
+#define PK_PH_FLUSH(trips) { PK_PH_END(0) if (threadIdx.x == 0) { const unsigned long long a_[9] = {ph_a0, ph_a1, ph_a2, ph_a3, ph_a4, ph_a5, ph_a6, ph_a7, ph_a8}; for (int i_ = 0; i_ < 9; ++i_) atomicAdd(&g_phase[i_], a_[i_]); atomicAdd(&g_phase[14], (unsigned long long)(trips)); atomicAdd(&g_phase[15], 1ull); } }
+#elif defined(DHMC_PHASE_MARK)   // region boundaries as comments in the assembly (static instruction counts per region)
+#define PK_PH_DECL
+#define PK_PH_END(i) asm volatile("; PKPH " #i);
+#define PK_PH_FLUSH(trips) asm volatile("; PKPH 0");
+#else
+#define PK_PH_DECL
+#define PK_PH_END(i)
+#define PK_PH_FLUSH(trips)
+#endif
+
 // One wavefront per workgroup, 64 / L chains in it: group `grp` of workgroup b runs the chain in place b·(64/L) + grp of the launch
 // order (RunParams::launch_order: the chains sorted by the previous launch's work, longest first — so that chains with
 // persistently deep trees share waves instead of each holding a wave of finished chains open).
-template <int TGT, int L>
+template <int TGT, int L, int CPL>
 __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
-    constexpr int CPL = pk::kCPL;
     constexpr int GPW = 64 / L;
     const int sub = (int)(threadIdx.x & (L - 1));
     const int grp = (int)(threadIdx.x / L);
@@ -109,31 +125,26 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
     if constexpr (TGT < 0) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
-        const int L = pk::lanes_per_chain(P.D);
-        if (L == 0) return DHMC_ERR_UNSUPPORTED;
+        const int cpl = P.pk_cpl;
+        const int L = pk::lanes_per_chain(P.D, cpl);
+        if (L == 0 || (cpl != 2 && cpl != 4)) return DHMC_ERR_UNSUPPORTED;
         const int gpw = 64 / L;
         const dim3 grid((unsigned)((P.C + gpw - 1) / gpw)), block(64);
-        const size_t lds = pk::lds_bytes_per_wave(L, P.max_depth, P.pk_lds_levels);
-#define DHMC_PK_LAUNCH(LL)                                                                                                     \
-    case LL: {                                                                                                                 \
+        const size_t lds = pk::lds_bytes_per_wave(L, cpl, P.max_depth, P.pk_lds_levels);
+#define DHMC_PK_LAUNCH(LL, CC)                                                                                                 \
+    if (L == LL && cpl == CC) {                                                                                                \
         static bool once = [] {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk::kMaxLdsPerWave); \
+            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk::kMaxLdsPerWave); \
             return true;                                                                                                       \
         }();                                                                                                                   \
         (void)once;                                                                                                            \
-        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL>), grid, block, lds, s, P);                                         \
-        break;                                                                                                                 \
+        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL, CC>), grid, block, lds, s, P);                                     \
+        return DHMC_OK;                                                                                                        \
     }
-        switch (L) {
-            DHMC_PK_LAUNCH(1)
-            DHMC_PK_LAUNCH(2)
-            DHMC_PK_LAUNCH(4)
-            DHMC_PK_LAUNCH(8)
-            DHMC_PK_LAUNCH(16)
-        default: return DHMC_ERR_UNSUPPORTED;
-        }
+        DHMC_PK_LAUNCH(1, 2) DHMC_PK_LAUNCH(2, 2) DHMC_PK_LAUNCH(4, 2) DHMC_PK_LAUNCH(8, 2) DHMC_PK_LAUNCH(16, 2)
+        DHMC_PK_LAUNCH(1, 4) DHMC_PK_LAUNCH(2, 4) DHMC_PK_LAUNCH(4, 4) DHMC_PK_LAUNCH(8, 4) DHMC_PK_LAUNCH(16, 4)
 #undef DHMC_PK_LAUNCH
-        return DHMC_OK;
+        return DHMC_ERR_UNSUPPORTED;
     }
 }
 

@@ -85,6 +85,8 @@ struct RunParams {
     // the packed small-D engine (packed_core.hpp): suspended levels 1 .. pk_lds_levels of a chain live in LDS (the rest in the HBM
     // workspace), and a transition starts only on trips of the wave's main loop that are multiples of pk_align (a power of two)
     int pk_lds_levels, pk_align;
+    int pk_cpl;                  // coordinates per lane of the packed layout (2 or 4)
+    int pk_pad_;
 };
 
 // workspace vector indices (units of Dpad doubles inside one chain's block)

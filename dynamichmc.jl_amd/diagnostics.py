@@ -10,16 +10,17 @@ ACCEPTANCE_QUANTILES = [0.05, 0.25, 0.5, 0.75, 0.95]      # diagnostics.jl:35
 
 
 class InvalidTree:
-    """trees.jl:180-200: positions relative to the starting node.  left < right: the tree was turning there; left == right: a
-    divergent node; (1, 0) is the sentinel REACHED_MAX_DEPTH; any other left > right is disallowed.  The statistics arrays hold the
-    two integers (`termination_left`, `termination_right`); `termination(tree_statistics, chain, i)` builds this view of one entry."""
+    """trees.jl:180-200: positions relative to the starting node.  left == right: a divergent node; (1, 0): the sentinel
+    REACHED_MAX_DEPTH; anything else: the tree was turning between the two positions.  Like the reference's struct, the
+    constructor validates nothing: a subtree that turns while the trajectory is extended BACKWARD is recorded in build order,
+    InvalidTree(i′, i₊) with i′ > i₊ (trees.jl:255 — e.g. (-1, -8); about 7 % of the transitions of the funnel golden), so
+    left > right is ordinary data here although the reference's docstring reserves it for the sentinel.  The statistics arrays hold
+    the two integers (`termination_left`, `termination_right`); `termination(tree_statistics, chain, i)` builds this view of one entry."""
     __slots__ = ("left", "right")
 
     def __init__(self, left, right=None):                  # InvalidTree(i) = InvalidTree(i, i) (trees.jl:185)
         self.left = int(left)
         self.right = int(left if right is None else right)
-        if self.left > self.right and (self.left, self.right) != (1, 0):
-            raise ValueError("ArgumentError: left > right is reserved for REACHED_MAX_DEPTH = InvalidTree(1, 0)")
 
     def __eq__(self, other):
         return isinstance(other, InvalidTree) and (self.left, self.right) == (other.left, other.right)

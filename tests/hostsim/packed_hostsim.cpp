@@ -30,6 +30,9 @@ static void run_chain(const RunParams& P, int chain, double* lds_cold, double* l
     typedef HostGroup Grp;
     typedef dm_generic Pol;
 #define PK_ATOMIC_ADD_ULL(ptr, v) (*(ptr) += (v))
+#define PK_PH_DECL
+#define PK_PH_END(i)
+#define PK_PH_FLUSH(t)
 #include "../../dynamichmc.jl_amd/csrc/packed_body.inc"
 #undef PK_ATOMIC_ADD_ULL
 }

@@ -37,7 +37,7 @@ class RunParams(C.Structure):      # csrc/run_params.hpp, field for field
                 ("st", ChainArrays), ("adapt", C.c_int), ("da_init", C.c_int), ("da_finalize", C.c_int), ("t0", C.c_int),
                 ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("out", DeviceOutputs), ("tp", TargetParams),
                 ("leapfrog_counter", P), ("win_mean", P), ("win_m2", P), ("win_n0", C.c_int64), ("chain_work", P), ("launch_order", P),
-                ("pk_lds_levels", C.c_int), ("pk_align", C.c_int)]
+                ("pk_lds_levels", C.c_int), ("pk_align", C.c_int), ("pk_cpl", C.c_int), ("pk_pad_", C.c_int)]
 
 
 DA_DTYPE = np.dtype([("mu", "f8"), ("Hbar", "f8"), ("logeps", "f8"), ("logeps_bar", "f8"), ("m", "i8")])

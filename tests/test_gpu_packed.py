@@ -18,6 +18,19 @@ def pkg():
     return load_package()
 
 
+@pytest.fixture(autouse=True)
+def _always_packed():
+    """Every context of this file runs the packed kernel (DHMC_PACKED=1) unless a test says otherwise: without the variable the
+    library picks the engine per launch from the previous launch's work."""
+    old = os.environ.get("DHMC_PACKED")
+    os.environ["DHMC_PACKED"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("DHMC_PACKED", None)
+    else:
+        os.environ["DHMC_PACKED"] = old
+
+
 class _env:
     def __init__(self, **kw):
         self.kw = {k: str(v) for k, v in kw.items()}
@@ -48,9 +61,12 @@ def _stages(dev, ora, what):
     assert np.array_equal(dev.status(), ora.status())
 
 
+@pytest.mark.parametrize("cpl", [2, 4])
 @pytest.mark.parametrize("D,C", [(2, 5), (4, 70), (7, 33), (13, 17), (30, 11), (32, 64), (33, 9), (64, 6)])
-def test_funnel_every_group_width_matches_oracle(pkg, D, C):
-    dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=100 + D)
+def test_funnel_every_group_width_matches_oracle(pkg, D, C, cpl):
+    """Both layouts (2 and 4 coordinates per lane: L = 1 … 16 lanes per chain), chain counts that leave idle groups."""
+    with _env(DHMC_PK_CPL=cpl):
+        dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=100 + D)
     ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=100 + D, threads=8)
     for e in (dev, ora):
         e.init(); e.set_stepsize(0.2)
@@ -124,10 +140,32 @@ def test_packed_equals_wave_kernel_windows_and_launch_order(pkg):
     assert res[0][4] == res[1][4] == int(res[0][0][-1]["steps"].sum())
 
 
-@pytest.mark.parametrize("align,levels", [(1, 0), (2, 1), (8, 2), (16, 6)])
-def test_gate_width_and_lds_levels_change_no_result(pkg, align, levels):
+def test_engine_choice_follows_the_previous_launchs_work(pkg):
+    """Without DHMC_PACKED the engine is chosen per launch (dhmc_run): packed until a launch is held open by a few chains with many
+    times the mean's work, the wave-per-chain kernel after such a launch.  Whatever is chosen: the bits of either engine alone."""
+    D, C = 30, 512
+    res = []
+    for env in (dict(), dict(DHMC_PACKED=1), dict(DHMC_PACKED=0)):
+        old = os.environ.pop("DHMC_PACKED", None)
+        try:
+            with _env(**env):
+                dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=31)
+        finally:
+            if old is not None:
+                os.environ["DHMC_PACKED"] = old
+        dev.init(); dev.find_initial_stepsize()
+        res.append([dev.run(60, da={}), dev.run(50), dev.run(40, da=dict(init=1, finalize=1)), dev.run(35)])
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            _same(a, b, "engine choice")
+    work = res[0][1]["steps"].sum(axis=1)
+    assert work.max() > 3 * work.mean(), "the case should have a launch that is held open by a few chains"
+
+
+@pytest.mark.parametrize("align,levels,cpl", [(1, 0, 2), (2, 1, 4), (8, 2, 2), (16, 6, 4), (4, 9, 2)])
+def test_gate_width_and_lds_levels_change_no_result(pkg, align, levels, cpl):
     D, C = 30, 40
-    with _env(DHMC_PK_ALIGN=align, DHMC_PK_LDS_LEVELS=levels):
+    with _env(DHMC_PK_ALIGN=align, DHMC_PK_LDS_LEVELS=levels, DHMC_PK_CPL=cpl):
         dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=21)
     ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=21, threads=8)
     for e in (dev, ora):

@@ -125,14 +125,24 @@ def test_invalid_tree_and_its_sentinel(pkg):   # trees.jl:180-202, exported by D
     assert repr(d.InvalidTree(-2, 5)) == "turning at positions -2:5" and not d.is_divergent(d.InvalidTree(-2, 5))
     assert repr(d.REACHED_MAX_DEPTH) == "reached maximum depth without divergence or turning"
     assert d.REACHED_MAX_DEPTH == d.InvalidTree(1, 0) and not d.is_divergent(d.REACHED_MAX_DEPTH)
-    with pytest.raises(ValueError):
-        d.InvalidTree(4, 2)
+    assert repr(d.InvalidTree(-1, -8)) == "turning at positions -1:-8"   # a subtree turning while moving backward (trees.jl:255): no validation, as in the reference
     ts = pkg.TreeStatisticsNUTS(pi=np.zeros((1, 3)), depth=np.zeros((1, 3), int), termination_left=np.array([[1, -4, 2]]),
                                 termination_right=np.array([[0, 3, 2]]), acceptance_rate=np.ones((1, 3)), steps=np.ones((1, 3), int),
                                 directions=np.zeros((1, 3), np.uint32))
     assert [repr(d.termination(ts, 0, i)) for i in range(3)] == ["reached maximum depth without divergence or turning",
                                                                  "turning at positions -4:3", "divergence at position 2"]
     assert d.count_terminations(ts) == dict(max_depth=1, divergence=1, turning=1)
+    # every entry of a golden run (it holds backward-turning subtrees, left > right) goes through termination()
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "funnel_d30.npz"))
+    tl, tr = [np.asarray(g[k]) for k in sorted(k for k in g.files if "term_left" in k or "term_right" in k)][:2]
+    tl, tr = tl.reshape(1, -1), tr.reshape(1, -1)
+    ts = pkg.TreeStatisticsNUTS(pi=np.zeros(tl.shape), depth=np.zeros(tl.shape, int), termination_left=tl, termination_right=tr,
+                                acceptance_rate=np.ones(tl.shape), steps=np.ones(tl.shape, int), directions=np.zeros(tl.shape, np.uint32))
+    kinds = [repr(d.termination(ts, 0, i)).split()[0] for i in range(tl.shape[1])]
+    assert ((tl > tr) & ~((tl == 1) & (tr == 0))).any(), "the golden should hold backward-turning subtrees"
+    c = d.count_terminations(ts)
+    assert kinds.count("divergence") == c["divergence"] and kinds.count("turning") == c["turning"] and kinds.count("reached") == c["max_depth"]
 
 
 def test_shard_chains(pkg):
