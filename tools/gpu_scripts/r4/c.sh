@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: per-case detmath self-test first (stops at the first case that does not come back); only then the GPU suite, the
 # bench lines and the PMC profile.
-bash tools/gpu_scripts/r4_b.sh || exit 1
+bash tools/gpu_scripts/r4/b.sh || exit 1
 O=gpurun_out/r4c; mkdir -p $O
 timeout -s KILL 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > $O/pytest.log; tail -5 $O/pytest.log
 timeout -s KILL 120 python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_default.json
