@@ -64,7 +64,7 @@ OUTPUT_FIELDS = [("draws", np.float64), ("logdensities", np.float64), ("eps", np
                  ("directions", np.uint32)]
 
 # every symbol include/dhmc.h declares
-SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", "dhmc_version",
+SYMBOLS = ["dhmc_create", "dhmc_destroy", "dhmc_set_stream", "dhmc_last_error", "dhmc_version", "dhmc_detmath_version",
            "dhmc_init", "dhmc_set_position", "dhmc_get_position", "dhmc_set_metric_diag", "dhmc_get_metric_diag",
            "dhmc_set_metric_dense", "dhmc_get_metric_dense", "dhmc_get_metric_dense_chain", "dhmc_set_stepsize", "dhmc_get_stepsize", "dhmc_get_status",
            "dhmc_find_initial_stepsize", "dhmc_run", "dhmc_update_metric_diag", "dhmc_update_metric_dense", "dhmc_state_bytes",

@@ -198,9 +198,58 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
     const int nest = c->per_chain_dense ? c->cfg.chains : 1;
     const int64_t J = c->per_chain_dense ? n : (int64_t)c->cfg.chains * n;
     Staged s;
-    int rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s);
-    if (rc) return rc;
+    int rc = DHMC_OK;
     int refused = 0, first_refused = -1;
+    if (!c->per_chain_dense && c->metric_allreduce) {
+        // Job-wide estimate (include/dhmc.h dhmc_set_metric_allreduce): column sums + row count over the ranks, then the scatter about
+        // the job's mean over the ranks.  EVERY rank makes the same sequence of collective calls whatever happens to it locally: a
+        // rank that cannot stage its draws or allocate its buffers takes part in the first all-reduce with zeros and a raised error
+        // slot, all ranks read the reduced slot, and all of them return the error together before the second collective — a rank
+        // that left early would leave the others blocked in it.  The first buffer is the factorisation's work space (free until
+        // device_dense_metric below), so that taking part needs no allocation.
+        DevBuf bmean, bS;
+        double local_err = 0.0;
+        if (stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s) != DHMC_OK) local_err = 1.0;
+        if (hipMalloc(&bmean.p, sizeof(double) * ld) != hipSuccess) local_err = 1.0;
+        if (hipMalloc(&bS.p, sizeof(double) * (size_t)ld * ld) != hipSuccess) local_err = 1.0;
+        double* const mean = (double*)bmean.p;
+        double* const S = (double*)bS.p;
+        double* const sums = c->d_fwork;                      // D + 2 slots: column sums, row count, error flag
+        const double* x = (const double*)s.dev;
+        double tail[2] = {local_err != 0.0 ? 0.0 : (double)J, local_err};
+        HIP_TRY(c, hipMemsetAsync(sums, 0, sizeof(double) * (size_t)(D + 2), c->stream));
+        if (local_err == 0.0)
+            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, sums, (size_t)0, (size_t)0, 1);
+        HIP_TRY(c, hipMemcpyAsync(sums + D, tail, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (c->metric_allreduce(c->metric_allreduce_user, sums, (int64_t)D + 2, (void*)c->stream) != 0) {
+            c->err = "dhmc_update_metric_dense: the all-reduce callback failed (column sums)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
+        }
+        HIP_TRY(c, hipMemcpyAsync(tail, sums + D, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));           // the job's row count and error count are on the host now — on every rank
+        const double Jtot = tail[0];
+        if (tail[1] != 0.0) {
+            c->err = local_err != 0.0 ? "dhmc_update_metric_dense: this rank could not stage its draws / allocate its buffers (all ranks return)"
+                                      : "dhmc_update_metric_dense: another rank of the job failed before the estimate (all ranks return)";
+            stage_free(c, &s);
+            return DHMC_ERR_HIP;
+        }
+        if (!(Jtot >= 2.0)) { stage_free(c, &s); return DHMC_ERR_INVALID_ARGUMENT; }
+        hipLaunchKernelGGL(pooled_mean_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, sums);
+        HIP_TRY(c, hipMemcpyAsync(mean, sums, sizeof(double) * (size_t)D, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
+        if (c->metric_allreduce(c->metric_allreduce_user, S, (int64_t)ld * ld, (void*)c->stream) != 0) {
+            c->err = "dhmc_update_metric_dense: the all-reduce callback failed (scatter matrix)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
+        }
+        // from here on every rank holds the same S: regularisation and factorisation succeed or fail on all of them alike
+        hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, (int64_t)Jtot, lambda, S, (size_t)0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }
+        else rc = device_dense_metric(c, S, ld, -1);   // DHMC_ERR_INVALID_ARGUMENT: the estimate is not positive definite
+        stage_free(c, &s);
+        return rc;
+    }
+    rc = stage_in(c, draws, sizeof(double) * (size_t)c->cfg.chains * n * D, on_device, &s);
+    if (rc) return rc;
     if (!c->per_chain_dense) {
         DevBuf bmean, bS;
         HIP_TRY(c, hipMalloc(&bmean.p, sizeof(double) * ld));
@@ -208,31 +257,9 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
         double* const mean = (double*)bmean.p;
         double* const S = (double*)bS.p;
         const double* x = (const double*)s.dev;
-        double Jtot = (double)J;
-        if (!c->metric_allreduce) {
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0, 0);
-            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
-        } else {
-            // job-wide estimate (include/dhmc.h dhmc_set_metric_allreduce): column sums + row count over the ranks, then the
-            // scatter about the job's mean over the ranks; `mean` has Dpad >= D + 1 slots except when D is a multiple of 64
-            DevBuf bsum;
-            HIP_TRY(c, hipMalloc(&bsum.p, sizeof(double) * (size_t)(D + 1)));
-            double* const sums = (double*)bsum.p;
-            hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, sums, (size_t)0, (size_t)0, 1);
-            HIP_TRY(c, hipMemcpyAsync(sums + D, &Jtot, sizeof(double), hipMemcpyHostToDevice, c->stream));
-            if (c->metric_allreduce(c->metric_allreduce_user, sums, (int64_t)D + 1, (void*)c->stream) != 0) {
-                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (column sums)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
-            }
-            HIP_TRY(c, hipMemcpyAsync(&Jtot, sums + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            hipLaunchKernelGGL(pooled_mean_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, sums);
-            HIP_TRY(c, hipMemcpyAsync(mean, sums, sizeof(double) * (size_t)D, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
-            if (c->metric_allreduce(c->metric_allreduce_user, S, (int64_t)ld * ld, (void*)c->stream) != 0) {
-                c->err = "dhmc_update_metric_dense: the all-reduce callback failed (scatter matrix)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
-            }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));       // Jtot is on the host now
-            if (!(Jtot >= 2.0)) { stage_free(c, &s); return DHMC_ERR_INVALID_ARGUMENT; }
-        }
+        const double Jtot = (double)J;
+        hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, mean, (size_t)0, (size_t)0, 0);
+        hipLaunchKernelGGL(pooled_cov_kernel, dim3(ld / 64, ld / 64), dim3(256), 0, c->stream, D, J, x, mean, S, ld, (size_t)0, (size_t)0, (size_t)0);
         hipLaunchKernelGGL(cov_regularize_kernel, dim3((unsigned)(((size_t)D * D + 255) / 256)), dim3(256), 0, c->stream, D, ld, (int64_t)Jtot, lambda, S, (size_t)0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("dhmc_update_metric_dense: ") + hipGetErrorString(e); rc = DHMC_ERR_HIP; }

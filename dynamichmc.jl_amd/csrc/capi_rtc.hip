@@ -35,7 +35,7 @@ std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool
 }
 }  // namespace
 // compile `source` (which defines dhmc::`name`) with the kernel templates for one chain width; *code receives the code object
-int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered) {
+int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered, bool fresh) {
     std::string src = rtc_prelude();
     src += dhmc_rtc_headers;
     src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
@@ -65,7 +65,7 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
         char hex[17];
         std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
         cache_file = std::string(dir) + "/dhmc_rtc_" + hex + ".co";
-        if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
+        if (FILE* f = fresh ? nullptr : std::fopen(cache_file.c_str(), "rb")) {     // fresh: the cached object did not load — compile and replace it
             bool ok = false;
             char magic[8];
             uint32_t n = 0;
@@ -169,7 +169,7 @@ int dhmc_check_target_source(const char* hip_source, const char* functor_name, i
     const int npl = npl_for_user_dim(dim);
     if (npl == 0) return DHMC_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(g_user_mutex);
-    const int rc = rtc_compile(hip_source, functor_name, npl, metric == DHMC_METRIC_DENSE, nullptr, nullptr);
+    const int rc = rtc_compile(hip_source, functor_name, npl, metric == DHMC_METRIC_DENSE, nullptr, nullptr, false);
     if (log && log_bytes) {
         const size_t n = std::min<size_t>(g_rtc_log.size(), (size_t)log_bytes - 1);
         std::memcpy(log, g_rtc_log.data(), n);

@@ -51,7 +51,7 @@ int dhmc_export_state(dhmc_ctx* c, void* host_blob, uint64_t nbytes) {
     DHMC_CHECK_USABLE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    BlobHeader h{BLOB_MAGIC, c->cfg.dim, c->cfg.chains, c->Dpad, 0};
+    BlobHeader h{BLOB_MAGIC, c->cfg.dim, c->cfg.chains, c->Dpad, DHMC_DETMATH_VERSION};   // `reserved`: the scalar math the chains were advanced with
     std::memcpy(host_blob, &h, sizeof(h));
     return blob_io(c, (char*)host_blob, true);
 }
@@ -62,6 +62,13 @@ int dhmc_import_state(dhmc_ctx* c, const void* host_blob, uint64_t nbytes) {
     BlobHeader h;
     std::memcpy(&h, host_blob, sizeof(h));
     if (h.magic != BLOB_MAGIC || h.dim != c->cfg.dim || h.chains != c->cfg.chains || h.Dpad != c->Dpad) return DHMC_ERR_INVALID_ARGUMENT;
+    // A blob written under another version of the scalar math (include/dhmc_detmath.h) would resume with different bits than the run
+    // it continues: refused (0 = a blob from before the field existed, i.e. version 1 or 2 — accepted only when the caller says so).
+    if (h.reserved != DHMC_DETMATH_VERSION && !(h.reserved == 0 && std::getenv("DHMC_ACCEPT_UNVERSIONED_STATE"))) {
+        c->err = "dhmc_import_state: the blob was written under detmath version " + std::to_string(h.reserved) + ", this library is version " +
+                 std::to_string(DHMC_DETMATH_VERSION) + " (0: unversioned; DHMC_ACCEPT_UNVERSIONED_STATE=1 accepts it)";
+        return DHMC_ERR_INVALID_ARGUMENT;
+    }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->poisoned = true;    // a partially copied blob is no state

@@ -43,7 +43,7 @@ struct UserTarget {
 extern std::vector<UserTarget> g_user_targets;
 extern std::mutex g_user_mutex;
 extern std::string g_rtc_log;
-int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered);
+int rtc_compile(const std::string& source, const std::string& name, int npl, bool dense, std::vector<char>* code, std::vector<std::string>* lowered, bool fresh = false);
 int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low, hipModule_t* mod, std::initializer_list<hipFunction_t*> fns);
 int npl_for_user_dim(int D);
 

@@ -163,7 +163,8 @@ int copy_out_scalar(dhmc_ctx* c, const void* src, void* dst, size_t bytes, int o
 
 extern "C" {
 
-const char* dhmc_version(void) { return "dhmc_amd 0.1.0 (gfx950)"; }
+const char* dhmc_version(void) { return "dhmc_amd 0.3.0 (gfx950; detmath 2)"; }
+int dhmc_detmath_version(void) { return DHMC_DETMATH_VERSION; }
 
 const char* dhmc_last_error(const dhmc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -297,7 +298,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             std::vector<std::string> low;
             if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low))) return fail(rc);
             UserKernels K;
-            if ((rc = rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio}))) return fail(rc);
+            auto load = [&]() { return rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio}); };
+            if ((rc = load())) {      // e.g. a cached object of another build of the tool chain: compile afresh once, replacing the file
+                code.clear(); low.clear();
+                if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low, true)) || (rc = load())) return fail(rc);
+            }
             it = U.built.emplace(key, K).first;
         }
         if (cfg->metric == DHMC_METRIC_DENSE && !it->second.dense_mod) {
@@ -305,8 +310,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             std::vector<std::string> low;
             if ((rc = rtc_compile(U.source, U.name, c->NPL, true, &code, &low))) return fail(rc);
             UserKernels& K = it->second;
-            if ((rc = rtc_load(code, low, &K.dense_mod, {&K.k0, &K.k2, &K.k3, &K.run_dense, &K.search_dense, &K.probe_traj_dense, &K.probe_ratio_dense})))
-                return fail(rc);
+            auto load = [&]() { return rtc_load(code, low, &K.dense_mod, {&K.k0, &K.k2, &K.k3, &K.run_dense, &K.search_dense, &K.probe_traj_dense, &K.probe_ratio_dense}); };
+            if ((rc = load())) {
+                code.clear(); low.clear();
+                if ((rc = rtc_compile(U.source, U.name, c->NPL, true, &code, &low, true)) || (rc = load())) return fail(rc);
+            }
         }
         c->user = &it->second;
     }

@@ -66,11 +66,13 @@ def pooled_covariance(draws, allreduce=None):
     `allreduce(array)` adds a float64 numpy array over the ranks in place (None: one rank).  The protocol's reference for the
     tests; the device path uses the same two collectives."""
     x = np.asarray(draws, np.float64).reshape(-1, np.shape(draws)[-1])
-    buf = np.concatenate([x.sum(0), [float(x.shape[0])]])
+    buf = np.concatenate([x.sum(0), [float(x.shape[0]), 0.0]])      # column sums, row count, error slot (include/dhmc.h)
     if allreduce is not None:
         allreduce(buf)
-    J = buf[-1]
-    mean = buf[:-1] / J
+    if buf[-1] != 0.0:
+        raise RuntimeError("a rank of the job failed before the estimate")
+    J = buf[-2]
+    mean = buf[:-2] / J
     d = x - mean
     S = d.T @ d
     if allreduce is not None:

@@ -194,14 +194,17 @@ int dhmc_host_free(void* p);
  *     template <int NPL> __device__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const;
  *     __device__ double finish(double s) const;                          // ℓ from the wave-reduced sum when kDeferred
  * Lane l holds coordinates l, l+64, … (slot k <-> coordinate l + 64 k; pads are 0); eval fills g = ∇ℓ(q) and returns ℓ (or the
- * lane's partial sum of it).  The source is compiled with hiprtc (-O3 -ffp-contract=off, as the library itself) against the
+ * lane's partial sum of it).  A kDeferred functor's partial sum must be ±0 in every lane whose slots are all pads (lanes >= D of a
+ * chain of at most 64 coordinates): such chains are reduced over their first 16 / 32 lanes only (csrc/wave.hpp wave_allreduce), so
+ * a constant term of ℓ belongs in finish() or in a lane that holds a coordinate, never in a pad lane.  The source is compiled with hiprtc (-O3 -ffp-contract=off, as the library itself) against the
  * library's kernel templates when a context is created with target = DHMC_TARGET_USER_BASE + *target_handle; compile errors come
  * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().  dim <= 1024; diagonal
  * metric (the wave-per-chain kernels) or the shared dense metric (a second module, compiled when the first dense context of the
  * functor is created: the GEMM round engine's kernels around the functor, and the wave-per-chain dense kernels for small batches).
  * dhmc_check_target_source compiles only (no device needed) the kernels of `metric` for `dim` coordinates and returns the log.
  * Environment DHMC_RTC_CACHE=<directory>: compiled modules are kept there (keyed by source, functor name, chain width, metric,
- * library and hiprtc version) and loaded instead of compiled by later processes; an unreadable file is ignored and replaced. */
+ * GPU architecture, library and hiprtc version) and loaded instead of compiled by later processes; an unreadable file, or one
+ * whose module does not load on this device, is ignored and replaced. */
 int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle);
 int dhmc_check_target_source(const char* hip_source, const char* functor_name, int32_t dim, int32_t metric, char* log, uint64_t log_bytes);
 const char* dhmc_target_source_log(void);   /* the log of the last run-time compilation in this process */
@@ -213,6 +216,10 @@ int dhmc_destroy(dhmc_ctx* ctx);
 int dhmc_set_stream(dhmc_ctx* ctx, void* hip_stream);
 const char* dhmc_last_error(const dhmc_ctx* ctx);
 const char* dhmc_version(void);
+/* DHMC_DETMATH_VERSION of the library (include/dhmc_detmath.h): the numerical contract — host code compiled against another version of
+ * that header disagrees with the device in the last bits; dhmc_export_state stamps it into the blob and dhmc_import_state refuses a
+ * blob of another version. */
+int dhmc_detmath_version(void);
 
 /* ---- warmup state: WarmupState(Q, κ, ϵ) per chain (mcmc.jl:72-79) -------------------- */
 /* initialize_warmup_state (mcmc.jl:129-132): q0 [C][D], or NULL for random_position
@@ -381,14 +388,17 @@ int dhmc_summarize_tree_statistics(int32_t device, void* stream, const double* p
  * Without this, dhmc_update_metric_dense pools the draws of the chains of ONE context — one GPU's block — so a job sharded over
  * 8 ranks adapts eight different matrices where one GPU holding all chains would adapt one.  With an all-reduce installed the
  * estimate is job-wide: (1) every rank sums its rows per coordinate (sequentially in chain-major row order, as before) and the
- * D sums plus the row count are added over the ranks; mean = sum / J_total; (2) every rank forms Σ_j (x_j - mean)(x_j - mean)ᵀ
+ * D sums, the row count and an error slot (D + 2 doubles) are added over the ranks; mean = sum / J_total; (2) every rank forms Σ_j (x_j - mean)(x_j - mean)ᵀ
  * over ITS rows (the same k-ordered fp64-MFMA chain as before) and the Dpad² sums are added over the ranks; then regularisation
  * with J_total and the factorisation as before — every rank ends with the same matrix.  The callback must add `count` doubles at
  * `device_buf` (device memory) over all ranks IN PLACE, ordered on `hip_stream` (RCCL: ncclAllReduce on that stream; from Python
  * torch.distributed.all_reduce — dynamichmc.jl_amd.sharding.TorchAllReduce), and return 0.  A collective's summation order is its
  * own: the result of N ranks agrees with one rank holding all chains to rounding (tests: rtol 1e-12), and is bit-identical to
  * dhmc_update_metric_dense without a callback when there is one rank.  Shared dense metric only (per-chain metrics need no
- * pooling); fn == NULL removes it. */
+ * pooling); fn == NULL removes it.  Failure is job-wide: every rank makes both collective calls or none after the first — a rank
+ * that cannot stage its draws or allocate its buffers still takes part in the first all-reduce (zeros and a raised error slot),
+ * and all ranks then return DHMC_ERR_HIP together; too few rows in the whole job: DHMC_ERR_INVALID_ARGUMENT on every rank.  (A
+ * callback that itself fails on one rank cannot be repaired here: the collective library's own error handling applies.) */
 typedef int (*dhmc_allreduce_fn)(void* user, double* device_buf, int64_t count, void* hip_stream);
 int dhmc_set_metric_allreduce(dhmc_ctx* ctx, dhmc_allreduce_fn fn, void* user);
 

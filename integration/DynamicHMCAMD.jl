@@ -268,17 +268,19 @@ function DynamicHMC.warmup(sl::SamplingLogDensityAMD, tuning::TuningNUTS{M}, war
     (; N, stepsize_adaptation, λ) = tuning
     ctx = sl.ctx
     M ≡ Diagonal && metric_window_begin!(ctx)
+    window_open = M ≡ Diagonal
     results, mcmc_reporter = try
-        run_reported!(sl, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing,
-                      currently_warmup = true, tuning = M ≡ Nothing ? "stepsize" : "stepsize and $(M) metric")   # mcmc.jl:268-280
-    catch
-        M ≡ Diagonal && metric_window_end!(ctx)
-        rethrow()
-    end
-    if M ≡ Diagonal
-        update_metric_window!(ctx, λ)                                                                 # mcmc.jl:209,281-284
-    elseif M ≡ Symmetric
-        update_metric_dense!(ctx, results.posterior_matrix, λ)                                        # mcmc.jl:210,218-222 (pooled)
+        r = run_reported!(sl, N; da = stepsize_adaptation isa DualAveraging ? stepsize_adaptation : nothing,
+                          currently_warmup = true, tuning = M ≡ Nothing ? "stepsize" : "stepsize and $(M) metric")   # mcmc.jl:268-280
+        if M ≡ Diagonal
+            update_metric_window!(ctx, λ)                                                             # mcmc.jl:209,281-284 (closes the window)
+            window_open = false
+        elseif M ≡ Symmetric
+            update_metric_dense!(ctx, r[1].posterior_matrix, λ)                                       # mcmc.jl:210,218-222 (pooled)
+        end
+        r
+    finally
+        window_open && metric_window_end!(ctx)        # whatever threw — the run or the update — no window stays open on the context
     end
     M ≢ Nothing && report(mcmc_reporter, "adaptation finished", adapted_kinetic_energy = kinetic_energy(ctx))
     results, current_warmup_state(ctx)
