@@ -793,6 +793,8 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         levels = std::max(0, std::min(levels, std::max(0, P.max_depth - 1)));
         while (levels > 0 && pk::lds_bytes_per_wave(L, cpl, P.max_depth, levels) > pk::kMaxLdsPerWave) levels -= 1;
         P.pk_cpl = cpl;
+        P.pk_lds_levels = levels;
+        P.pk_align = c->pk_align;
     }
     if (c->win_n >= 0) {       // an open metric window: every transition's draw joins the running moments (capi_metric.hip)
         P.win_mean = c->d_win; P.win_m2 = c->d_win + (size_t)C * c->Dpad; P.win_n0 = c->win_n;

@@ -1,6 +1,6 @@
 """Extracts the NUMERIC test inputs (μ, d, C / Σ literals) of the reference's statistical tests
-(/root/reference/test/sample-correctness_tests.jl:27-98) into tests/golden/reference_mvn_cases.json and
-reference_mixture_case.json.
+(/root/reference/test/sample-correctness_tests.jl:27-118) into tests/golden/reference_mvn_cases.json,
+reference_mixture_case.json and reference_tail_cases.json.
 Only data is kept — each case becomes {name, mu, L} with x = μ + L z, z ~ N(0, I) (the reference's
 multivariate_normal(μ, L), test/utilities.jl:64-67); no source text is copied.  Run in the build container
 (the reference is not present on the GPU box)."""
@@ -59,6 +59,23 @@ def main():
     with open(os.path.join(HERE, "reference_mixture_case.json"), "w") as fh:
         json.dump(mix, fh, indent=0)
     print(mix["name"], "alpha", alpha, "tau_alert", tau_alert, "p_alert", p_alert)
+    # --- heavier tails and skewness (:100-118): the numbers of the three calls — K, the elongation exponent, the shift, the mixture
+    # weight, N and each call's alert / fail levels.  (What elongate / shift / funnel MEAN is LogDensityTestSuite's, which is not
+    # under /root/reference: the tests that replay these cases write their own definitions down.)
+    sec = src[src.index('@testset "NUTS tests with heavier tails and skewness"'):]
+    K = int(re.search(r"K = (\d+)", sec).group(1))
+    calls = re.findall(r'NUTS_tests\(RNG, ℓ, "([^"]+)",\s*(\d+);([^)]*)\)', sec)
+    tails = []
+    for title, N, kw in calls:
+        levels = {k: float(v) for k, v in re.findall(r"(\S+) = ([0-9.e-]+)", kw)}
+        tails.append(dict(name=title, N=int(N), levels=levels))
+    ks = [float(x) for x in re.findall(r"elongate\(([0-9.]+)\)", sec)]
+    assert len(set(ks)) == 1
+    out = dict(K=K, elongate=ks[0], shift=[1.0] * K if "shift(ones(K))" in sec else None,
+               funnel_mix_alpha=float(re.search(r"mix\(([0-9.]+), funnel\(\)", sec).group(1)), calls=tails)
+    with open(os.path.join(HERE, "reference_tail_cases.json"), "w") as fh:
+        json.dump(out, fh, indent=0, ensure_ascii=False)
+    print(out)
     for c in cases:
         print(c["name"], len(c["mu"]))
 

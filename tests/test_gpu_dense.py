@@ -339,7 +339,7 @@ def test_metric_pooled_over_ranks_with_one_rank_is_the_plain_update(pkg):
         ctx.update_metric_dense(draws, 0.05)
     Ma, Wa = a.metric_dense(); Mb, Wb = b.metric_dense()
     assert np.array_equal(Ma, Mb) and np.array_equal(Wa, Wb)
-    assert calls == [D + 1, 64 * 64]                                       # column sums + count, then the padded scatter matrix
+    assert calls == [D + 2, 64 * 64]                                       # column sums + count + error slot, then the padded scatter matrix
     S, _, J = pkg.sharding.pooled_covariance(draws)
     want = 0.95 * S + 0.05 * np.diag(np.diag(S))
     assert J == C * N and np.allclose(Mb, want, rtol=1e-11, atol=1e-13)

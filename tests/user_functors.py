@@ -128,3 +128,82 @@ struct Mixture3 {
 };
 }
 """
+
+
+# The reference's "heavier tails and skewness" cases (test/sample-correctness_tests.jl:100-118) transform a standard normal with
+# LogDensityTestSuite's elongate / shift / funnel, whose source is not under /root/reference ("parity unpinned").  The definitions
+# used HERE, written down so that the exact samplers of the tests and these densities agree:
+#   shift(b)      x ↦ x + b
+#   elongate(k)   x ↦ x ‖x‖^(k-1)          (‖y‖ = ‖x‖^k: k > 1 stretches the tails; Jacobian determinant k ‖x‖^((k-1) D))
+#   funnel()      x ↦ (x₀, e^{x₀/2} x₁, …)  (Neal's funnel with a unit-variance neck coordinate)
+#   mix(α, ℓ₁, ℓ₂) = log(α e^{ℓ₁} + (1-α) e^{ℓ₂}) of normalised densities
+# ELONGATED:  y = elongate(k)(x + b), x ~ N(0, I):  with s = ‖y‖, a = 1/k - 1, u = y s^a (= x + b):
+#   ℓ(y) = -½ ‖u - b‖² - ((k-1) D / k) log s - log k,   ∇ℓ = -[s^a (u-b) + a s^(a-2) y (y·(u-b))] - ((k-1) D / k) y / s²
+# Parameters: [k, b₀ … b_{D-1}].  D <= 64 (one slot per lane).
+ELONGATED = r"""
+namespace dhmc {
+struct Elongated {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
+    static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kBigDims = false;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = false;
+    double k;
+    const double* b;
+    __device__ explicit Elongated(const TargetParams& p) : k(p.a[0]), b(p.a + 1) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        static_assert(NPL == 1, "Elongated: at most 64 coordinates");
+        const double y = q[0];
+        const double be = lane < D ? b[lane] : 0.0;
+        const double s2 = wave_allreduce1(y * y);
+        const double a = 1.0 / k - 1.0, c1 = (k - 1.0) * (double)D / k;
+        const double ls = 0.5 * det_log(s2);                       // log s
+        const double sa = det_exp(a * ls);                         // s^a
+        const double d = y * sa - be;                              // u - b
+        double r[2] = {d * d, y * d};
+        wave_allreduce<2>(r);
+        g[0] = -(sa * d + a * (sa / s2) * y * r[1]) - c1 * y / s2;
+        if (lane >= D) g[0] = 0.0;
+        return -0.5 * r[0] - c1 * ls - det_log(k);
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+}
+"""
+
+# FUNNEL_MIX:  mix(α, funnel()(N(0, I_D)), N(0, I_D)), parameters [α]; with S = Σ_{i>=1} y_i² (the shared -D/2 log 2π dropped):
+#   ℓ_f = -½ y₀² - ½ e^{-y₀} S - ((D-1)/2) y₀,   ℓ_n = -½ (y₀² + S),   ℓ = logaddexp(log α + ℓ_f, log(1-α) + ℓ_n)
+FUNNEL_MIX = r"""
+namespace dhmc {
+struct FunnelMix {
+    static constexpr bool kDeferred = false;
+    static constexpr bool kElementwise = false;
+    static constexpr bool kPointwiseGrad = false;
+    static constexpr bool kRecomputeGrad = true;
+    static constexpr bool kBigDims = false;
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    static constexpr bool kFiniteLqImpliesFiniteGrad = false;
+    double la, lb;
+    __device__ explicit FunnelMix(const TargetParams& p) : la(det_log(p.a[0])), lb(det_log(1.0 - p.a[0])) {}
+    template <int NPL>
+    __device__ __forceinline__ double eval(const double (&q)[NPL], double (&g)[NPL], int lane, int D) const {
+        static_assert(NPL == 1, "FunnelMix: at most 64 coordinates");
+        const double y = q[0];
+        const double v = readlane_f64(y, 0);
+        const double S = wave_allreduce1(lane == 0 ? 0.0 : y * y);
+        const double ev = det_exp(-v), hd = 0.5 * (double)(D - 1);
+        const double lf = la + (-0.5 * v * v - 0.5 * ev * S - hd * v);
+        const double ln = lb + (-0.5 * (v * v + S));
+        const double l = det_logaddexp(lf, ln);
+        const double wf = det_exp(lf - l), wn = det_exp(ln - l);
+        const double gf = lane == 0 ? (-v + 0.5 * ev * S - hd) : -(ev * y);
+        g[0] = lane < D ? wf * gf + wn * (-y) : 0.0;
+        return l;
+    }
+    __device__ __forceinline__ double finish(double s) const { return s; }
+};
+}
+"""
