@@ -215,42 +215,55 @@ def bench_config3(args, pkg, torch):
     ctx.init(np.random.default_rng(5).normal(size=(C, Dd)) * sig)
     ctx.find_initial_stepsize()
     ctx.run_into(40, {}, da={})
-    out = {"draws": torch.empty((C, T, Dd), dtype=torch.float64, device="cuda"),
-           "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
-           "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
-           "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
-    for _ in range(args.warmup):
-        ctx.run_into(T, out)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); lf = 0; rounds = 0; kms = []
-    for _ in range(K):
-        ctx.run_into(T, out)
-        lf += ctx.last_run_leapfrogs(); rounds += ctx.last_run_rounds(); kms.append(ctx.last_run_kernel_ms())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     nprod = ctx.dense_products()                          # 1: u′ = ∇ℓq′·M⁻¹ only (default); 2: the reference's M⁻¹pₘ and M⁻¹p′
-    flops = rounds * nprod * 2.0 * C * 1024 * 1024        # [C×1024]·[1024×1024] contractions per round
     peak = 78.6                                           # MI355X fp64 matrix peak, TFLOP/s
-    ach = flops / (sum(kms) * 1e-3) / 1e12
-    q = out["draws"]
-    return ({
+
+    def measure(T, K, W):
+        out = {"draws": torch.empty((C, T, Dd), dtype=torch.float64, device="cuda"),
+               "steps": torch.empty((C, T), dtype=torch.int64, device="cuda"),
+               "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
+               "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
+        for _ in range(W):
+            ctx.run_into(T, out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); lf = 0; rounds = 0; kms = []
+        for _ in range(K):
+            ctx.run_into(T, out)
+            lf += ctx.last_run_leapfrogs(); rounds += ctx.last_run_rounds(); kms.append(ctx.last_run_kernel_ms())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # 2·D² flops per M⁻¹ product and chain; the kernels multiply padded rows (Dpad = 1024), kept as a second figure
+        ach = rounds * nprod * 2.0 * C * Dd * Dd / (sum(kms) * 1e-3) / 1e12
+        ach_pad = rounds * nprod * 2.0 * C * 1024 * 1024 / (sum(kms) * 1e-3) / 1e12
+        q = out["draws"]
+        res = {"value": lf / dt, "ms_per_step": 1e3 * dt / K, "steps": K, "transitions_per_step": T,
+               "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
+                        "mean_acceptance": float(out["acceptance_rate"].mean()),
+                        "scaled_draw_var": float((q / torch.tensor(sig, device="cuda")).var())},
+               "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                            "kernel": "gemm_rows_f64_kernel (v_mfma_f64_16x16x4_f64), share of whole round time",
+                            "algorithmic_flops_per_leapfrog": nprod * 2.0 * Dd * Dd,
+                            "padded": {"achieved": ach_pad, "frac": ach_pad / peak, "flops_per_leapfrog": nprod * 2.0 * 1024 * 1024},
+                            "note": f"flops of the {nprod} M^-1 contraction(s) per leapfrog round (2·D² each, SURVEY.md §8d; `padded`: the 2·Dpad² "
+                                    "the kernels execute; one-product recurrence: include/dhmc.h dhmc_set_dense_products) / total kernel time "
+                                    "of the rounds (tree-logic kernels included); the GEMM launches alone reach ~50 TFLOP/s (profiles/)",
+                            "rounds": rounds}}
+        del out, q
+        torch.cuda.empty_cache()
+        return res
+    m = measure(args.transitions, args.steps, args.warmup)
+    line = {
         "metric": "leapfrog-steps/sec (all chains), 1000-dim correlated MVN, dense M^-1, @4096 chains",
-        "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": m["value"], "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": m["steps"], "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "1000-dim correlated MVN (rho=0.5, sigma log-spaced 0.1..10), dense M^-1 = Sigma shared, "
-                               f"{C} chains (BASELINE.json configs[2])", "transitions_per_step": T, "chains_per_gpu": C,
+                               f"{C} chains (BASELINE.json configs[2])", "transitions_per_step": args.transitions, "chains_per_gpu": C,
                    "dense_products_per_leapfrog": nprod},
-        "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
-                 "mean_acceptance": float(out["acceptance_rate"].mean()),
-                 "scaled_draw_var": float((q / torch.tensor(sig, device="cuda")).var())},
-        "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                     "kernel": "gemm_rows_f64_kernel (v_mfma_f64_16x16x4_f64), share of whole round time",
-                     "algorithmic_flops_per_leapfrog": nprod * 2.0 * 1024 * 1024,
-                     "note": f"flops of the {nprod} M^-1 contraction(s) per leapfrog round (2·Dpad² each; one-product recurrence: "
-                             "include/dhmc.h dhmc_set_dense_products) / total kernel time of the rounds "
-                             "(tree-logic kernels included); the GEMM launches alone reach ~50 TFLOP/s (profiles/)",
-                     "rounds": rounds}})
+        "tree": m["tree"], "roofline": m["roofline"]}
+    if getattr(args, "config_n", 0):                      # the config's own N (1000 draws) in one call, beside the short steps
+        line["at_config_n"] = measure(args.config_n, 1, 0)
+    return line
 
 
 def bench_config45(args, pkg, torch):
@@ -280,49 +293,63 @@ def bench_config45(args, pkg, torch):
         ctx.metric_window_begin(); ctx.run_into(20, {}, da={}); ctx.update_metric_diag_window(); ctx.run_into(15, {}, da={})
         name = f"logistic regression N=1e5 p=256, diagonal metric, {C} chains" + (" = one GPU's share of 8192" if C == 1024 else " (all of them on this GPU)" if C == 8192 else "") + " (BASELINE.json configs[4])"
         flops_per_leapfrog = 4.0 * 100032 * 256      # two GEMM passes over X per gradient
-    out = {"steps": torch.empty((C, T), dtype=torch.int64, device="cuda"), "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
-           "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
-    for _ in range(args.warmup):
-        ctx.run_into(T, out)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); lf = 0; kms = []
-    for _ in range(K):
-        ctx.run_into(T, out)
-        lf += ctx.last_run_leapfrogs(); kms.append(ctx.last_run_kernel_ms())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if flops_per_leapfrog:
-        ach = lf * flops_per_leapfrog / (sum(kms) * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
-                "kernel": "gemm_rows_f64_kernel (fp64 MFMA; Q'·Xᵀ over the active rows, R·X split over blocks of observations), share of whole round time",
-                "note": "4·N·p flops per leapfrog of the chains that took it / total kernel time of the rounds"}
-    else:
-        ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                "kernel": "nuts_run_kernel<FunnelT,1>", "note": "48·D algorithmic bytes per leapfrog; a 30-dim chain is latency-, not bandwidth-bound"}
-    return ({
-        "metric": "leapfrog-steps/sec (all chains)", "value": lf / dt, "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": K,
-        "warmup": args.warmup, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic", "config": {"workload": name, "transitions_per_step": T, "chains_per_gpu": C},
-        "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
-                 "mean_acceptance": float(out["acceptance_rate"].mean())},
-        "roofline": roof})
+    def measure(T, K, W):
+        out = {"steps": torch.empty((C, T), dtype=torch.int64, device="cuda"), "depth": torch.empty((C, T), dtype=torch.int32, device="cuda"),
+               "acceptance_rate": torch.empty((C, T), dtype=torch.float64, device="cuda")}
+        for _ in range(W):
+            ctx.run_into(T, out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); lf = 0; kms = []
+        for _ in range(K):
+            ctx.run_into(T, out)
+            lf += ctx.last_run_leapfrogs(); kms.append(ctx.last_run_kernel_ms())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        work = out["steps"].sum(dim=1).double()           # the last step's leapfrogs per chain: a call ends with its slowest chain
+        if flops_per_leapfrog:
+            ach = lf * flops_per_leapfrog / (sum(kms) * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+                    "kernel": "gemm_rows_f64_kernel (fp64 MFMA; Q'·Xᵀ over the active rows, R·X split over blocks of observations), share of whole round time",
+                    "note": "4·N·p flops per leapfrog of the chains that took it / total kernel time of the rounds"}
+        else:
+            ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                    "kernel": "nuts_run_packed_kernel / nuts_run_kernel<FunnelT,1> (chosen per launch from the previous launch's work: dhmc_run)",
+                    "note": "48·D algorithmic bytes per leapfrog; a 30-dim chain is latency-, not bandwidth-bound: the call ends with its slowest "
+                            "chain, whose leapfrogs are sequential (slowest_chain_leapfrogs × the kernel's latency per leapfrog ≈ the call's time)"}
+        return {"value": lf / dt, "ms_per_step": 1e3 * dt / K, "steps": K, "transitions_per_step": T,
+                "tree": {"mean_depth": float(out["depth"].double().mean()), "mean_leapfrogs_per_transition": float(out["steps"].double().mean()),
+                         "mean_acceptance": float(out["acceptance_rate"].mean()),
+                         "slowest_chain_leapfrogs": float(work.max()), "mean_chain_leapfrogs": float(work.mean())},
+                "roofline": roof}
+    m = measure(args.transitions, args.steps, args.warmup)
+    line = {
+        "metric": "leapfrog-steps/sec (all chains)", "value": m["value"], "unit": "leapfrog-steps/s", "n_gpus": 1, "steps": m["steps"],
+        "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "config": {"workload": name, "transitions_per_step": args.transitions, "chains_per_gpu": C},
+        "tree": m["tree"], "roofline": m["roofline"]}
+    if getattr(args, "config_n", 0):                      # the config's own N (funnel 1000 draws, logistic 200) in one call
+        line["at_config_n"] = measure(args.config_n, 1, 0)
+    return line
 
 
 def other_configs(args, pkg, torch):
     """Short measurements of BASELINE.json configs[2], [3] (one GPU's share) and [4] (one GPU's share) for the default line:
-    the same code paths as --config 3 / 4 / 5, two timed steps of 20 transitions after one warm-up step each."""
+    the same code paths as --config 3 / 4 / 5, two timed steps of 20 transitions after one warm-up step each, and then ONE call of
+    the config's own N (1000 draws for the dense normal and the funnel, 200 for the logistic regression) as
+    `at_config_n` — a call ends with its slowest chain, and a 20-transition call of a model with a heavy-tailed tree size (the funnel,
+    the logistic regression) is mostly that wait."""
     import copy
     res = {}
-    for cfg, key, fn in ((3, "c3", bench_config3), (4, "c4", bench_config45), (5, "c5", bench_config45)):
+    for cfg, key, fn, config_n in ((3, "c3", bench_config3, 1000), (4, "c4", bench_config45, 1000), (5, "c5", bench_config45, 200)):
         a = copy.copy(args)
-        a.config, a.transitions, a.steps, a.warmup, a.chains = cfg, 20, 2, 1, CHAINS_PER_GPU
+        a.config, a.transitions, a.steps, a.warmup, a.chains, a.config_n = cfg, 20, 2, 1, CHAINS_PER_GPU, config_n
         t0 = time.perf_counter()
         try:
             line = fn(a, pkg, torch)
             res[key] = {"workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
                         "steps": line["steps"], "transitions_per_step": 20, "tree": line["tree"], "roofline": line["roofline"],
-                        "seconds_with_setup": None}
+                        "at_config_n": line.get("at_config_n"), "seconds_with_setup": None}
         except Exception as e:      # noqa: the headline line is what must come out
             res[key] = {"error": repr(e)}
         torch.cuda.synchronize()
@@ -356,6 +383,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--transitions", type=int, default=None, help="NUTS transitions per chain per step (default 1000 for config 2, 20 otherwise)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--config-n", type=int, default=0, help="--config 3 / 4 / 5: after the timed steps, one more call of this many transitions "
+                                                            "(the config's own N), reported as at_config_n")
     ap.add_argument("--warmup-draws", action="store_true", help="A/B: the metric windows' draws stored and re-read (dhmc_update_metric_diag) "
                                                                  "instead of accumulated by the kernel (dhmc_metric_window_begin)")
     ap.add_argument("--short-warmup", action="store_true", help="65-transition adaptive setup instead of the reference's 900")

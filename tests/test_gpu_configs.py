@@ -287,6 +287,8 @@ def test_bench_default_line_carries_the_other_configs_and_a_live_traffic_figure(
     for k, floor in (("c3", 1e6), ("c4", 1e7), ("c5", 1e4)):
         assert "error" not in oc[k], oc[k]
         assert oc[k]["value"] > floor and oc[k]["steps"] == 2 and 0 < oc[k]["roofline"]["frac"] < 1.5
+        n = oc[k]["at_config_n"]                        # one call of the config's own N beside the 20-transition steps
+        assert n["value"] > floor and n["steps"] == 1 and n["transitions_per_step"] == (200 if k == "c5" else 1000)
     if shutil.which("rocprofv3"):
         assert d["roofline"]["traffic_source"] == "live", d["roofline"]["traffic_source"]
         per_leapfrog = d["roofline"]["traffic"] / d["roofline"]["leapfrogs_per_launch"]
