@@ -290,7 +290,16 @@ def bench_config45(args, pkg, torch):
         ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_LOGISTIC, target_params=pkg.LogisticRegression(X, y).params(),
                                 seed=args.seed, stream=_work_stream(torch))
         ctx.init(); ctx.set_stepsize(0.02)
-        ctx.metric_window_begin(); ctx.run_into(20, {}, da={}); ctx.update_metric_diag_window(); ctx.run_into(15, {}, da={})
+        # A shortened default warmup (mcmc.jl:415-425: step-size stage, doubling metric windows, final step-size stage; 200 transitions,
+        # ≈ 9 s).  Rounds 1-4 ran 20 + 15 transitions here, which left the chains at step sizes 5 × too small and ragged (0.05 … 0.37
+        # against 0.35 ± 0.05 adapted): 49 leapfrogs per transition instead of 15, the slowest chain at 2.7 × the mean's work, so that
+        # 63 % of the rows of the round engine's products idled (tools/experiments/c5_warmup_probe.py, profiles/r05_config5_*).
+        for n, metric in ((40, False), (40, True), (80, True), (40, False)):
+            if metric:
+                ctx.metric_window_begin()
+            ctx.run_into(n, {}, da={})
+            if metric:
+                ctx.update_metric_diag_window()
         name = f"logistic regression N=1e5 p=256, diagonal metric, {C} chains" + (" = one GPU's share of 8192" if C == 1024 else " (all of them on this GPU)" if C == 8192 else "") + " (BASELINE.json configs[4])"
         flops_per_leapfrog = 4.0 * 100032 * 256      # two GEMM passes over X per gradient
     def measure(T, K, W):

@@ -204,7 +204,11 @@ struct PackedTarget<DHMC_TARGET_FUNNEL> {
     template <int CPL, class Grp, class Pol>
     PK_FN double eval(const double (&q)[CPL], double (&g)[CPL], int e0, int D) const {
         const double v = Grp::first(q[0]);
+#ifdef PK_ABL_NO_EXP
+        const double ev = 1.0 - v;
+#else
         const double ev = det_exp_t<Pol>(-v);
+#endif
         double t[CPL];
         PK_UNROLL
         for (int k = 0; k < CPL; ++k) {
