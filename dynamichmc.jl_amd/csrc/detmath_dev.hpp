@@ -1,6 +1,6 @@
 // Device policies of the ABI's scalar math (include/dhmc_detmath.h).  One chain per wavefront means every scalar operation
 // of the tree logic costs a full vector issue slot, and a lone wave per SIMD is bound by the NUMBER of instructions it issues
-//  — so these policies keep every IEEE operation and its order (same bits as the oracle's dm_generic
+// (docs/DESIGN_history_rounds1-4.md §6a) — so these policies keep every IEEE operation and its order (same bits as the oracle's dm_generic
 // instantiation, checked by tests/test_gpu_detmath.py) and change only where operands live:
 //
 //   dm_uniform   the arguments are wave-uniform (logaddexp pairs of a merge, acceptance rate, step size, the funnel's exp(-v)):

@@ -87,7 +87,7 @@ __host__ __device__ constexpr int lds_extra_levels(int NPL) { return NPL == 1 ? 
 // Wide chains (16 slots per lane, kTrajInLds): M⁻¹ stays in registers and the rows are (level 0, level 1 first / last,
 // trajectory p₋ / p₊) — 40 KB per wave, four waves fill the CU's 160 KB exactly.
 // (Every target family since round 3: round 2 restricted it to coordinate-wise targets after a fault in a fuzz sweep that
-// no longer reproduces — DESIGN.md §10 — and a tridiagonal-precision normal at D = 1000 runs 2.9× faster with it.)
+// no longer reproduces — docs/DESIGN_history_rounds1-4.md §10 — and a tridiagonal-precision normal at D = 1000 runs 2.9× faster with it.)
 __host__ __device__ constexpr bool traj_in_lds(int NPL, bool l1_in_lds) { return NPL == 16 && l1_in_lds; }
 __host__ __device__ inline size_t lds_bytes(int Dpad, bool l1_in_lds, int extra_levels) {
     if (traj_in_lds(Dpad / 64, l1_in_lds)) return sizeof(double) * (size_t)Dpad * 5;

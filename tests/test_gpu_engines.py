@@ -47,7 +47,7 @@ def test_diag_kernel_lds_variants_agree(pkg):
 
 
 def test_lds_trajectory_layout_with_a_target_that_is_not_coordinate_wise(pkg):
-    """VERDICT r2 #5 / DESIGN.md §10: the layout of the wide per-draw kernel that keeps the trajectory's edge momenta in LDS
+    """VERDICT r2 #5 / docs/DESIGN_history_rounds1-4.md §10: the layout of the wide per-draw kernel that keeps the trajectory's edge momenta in LDS
     and M⁻¹ in registers was restricted to coordinate-wise targets in round 2, after a fault in a fuzz sweep with the
     tridiagonal-precision normal at D = 1000.  The fault does not reproduce (19 000 tridiagonal cases at 700 <= D <= 1024,
     the whole GPU suite and the fuzz sweep with the layout forced on for every family: tools/experiments/tpl_fault_repro.py,
