@@ -320,7 +320,8 @@ class DeviceFunctorLogDensity(_Target):
     of the built-in families (include/dhmc.h dhmc_register_target_source), compiled at run time into the
     library's own per-draw / initialisation / step-size-search kernels — no host round trip per leapfrog, as `north_star`
     asks ("the user ∇log π is supplied as a device function").  `params`: doubles handed to the functor's constructor.
-    Diagonal or shared dense metric, dimension <= 1024."""
+    Diagonal or shared dense metric; up to 1024 coordinates inside the per-draw kernels, up to 4096 evaluated for all chains between the
+    streaming round engine's kernels (only eval() is compiled then)."""
 
     def __init__(self, dimension, source, name, params=None):
         self.D = int(dimension)

@@ -76,6 +76,7 @@ struct dhmc_ctx {
     hipEvent_t ev_done[2] = {};
     int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
     const UserKernels* user = nullptr;   // target >= DHMC_TARGET_USER_BASE: the run-time compiled kernels of the caller's functor
+    hipFunction_t user_eval = nullptr;   // … beyond 1024 coordinates: its batched evaluation for the streaming round engine (user stays null)
     void* d_user_params = nullptr;
     // the per-draw kernels' launch order (nuts_kernels.hpp RunParams::launch_order): chains sorted by the leapfrog steps of the previous
     // launch, longest first, when one of them did more than a few percent above the mean (run_call)

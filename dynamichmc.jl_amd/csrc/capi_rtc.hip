@@ -24,6 +24,7 @@ uint64_t rtc_checksum(const char* p, uint64_t n) {      // FNV-1a over the code 
 }
 std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
     const std::string T = "dhmc::" + name, N = std::to_string(npl);
+    if (npl >= 32) return {"dhmc::functor_eval_kernel<" + T + ", " + N + ">"};      // beyond 1024 coordinates: the batched evaluation only
     if (!dense)
         return {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
                 "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
@@ -154,7 +155,7 @@ int rtc_load(const std::vector<char>& code, const std::vector<std::string>& low,
     *mod = m;
     return DHMC_OK;
 }
-int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : 0; }
+int npl_for_user_dim(int D) { return D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : D <= 1024 ? 16 : D <= 2048 ? 32 : D <= 4096 ? 64 : 0; }
 
 extern "C" {
 int dhmc_register_target_source(const char* hip_source, const char* functor_name, int32_t* target_handle) {

@@ -35,6 +35,7 @@ struct UserKernels {
     hipModule_t dense_mod = nullptr;
     hipFunction_t k0 = nullptr, k2 = nullptr, k3 = nullptr, run_dense = nullptr, search_dense = nullptr, probe_traj_dense = nullptr,
                   probe_ratio_dense = nullptr;
+    hipFunction_t eval = nullptr;      // 32 / 64 slots per lane (1024 < D <= 4096): functor_eval_kernel, the only kernel of `mod` then
 };
 struct UserTarget {
     std::string source, name;

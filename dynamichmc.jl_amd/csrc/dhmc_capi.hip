@@ -198,7 +198,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         if (cfg->target >= DHMC_TARGET_USER_BASE) {
             std::lock_guard<std::mutex> lock(g_user_mutex);
             if ((size_t)(cfg->target - DHMC_TARGET_USER_BASE) >= g_user_targets.size()) return DHMC_ERR_INVALID_ARGUMENT;
-            if (D > 1024 || (cfg->metric == DHMC_METRIC_DENSE && cfg->dense_per_chain)) return DHMC_ERR_UNSUPPORTED;
+            if (D > 4096 || (cfg->metric == DHMC_METRIC_DENSE && cfg->dense_per_chain)) return DHMC_ERR_UNSUPPORTED;
             if (cfg->target_params_bytes % sizeof(double) != 0 || (cfg->target_params_bytes && !cfg->target_params)) return DHMC_ERR_INVALID_ARGUMENT;
             break;
         }
@@ -218,6 +218,9 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // … and the logistic regression with a shared dense metric at ANY width: its functor re-reads X twice per gradient and chain
     // (hundreds of ms per leapfrog at N = 10⁵), the batched evaluation is two GEMMs over all chains
     if (cfg->target == DHMC_TARGET_LOGISTIC && cfg->metric == DHMC_METRIC_DENSE && !cfg->dense_per_chain) c->builtin_big = 1;
+    // … and a caller's device functor beyond 1024 coordinates: evaluated for all chains by functor_eval_kernel (compiled at run time)
+    const bool user_big = cfg->target >= DHMC_TARGET_USER_BASE && D > 1024;
+    if (user_big) c->builtin_big = 1;
     c->NPL = npl_for_dim(D, cfg->target == DHMC_TARGET_EXTERNAL || c->builtin_big);
     if (cfg->target == DHMC_TARGET_EXTERNAL)
         if (const char* e = std::getenv("DHMC_FORCE_NPL")) {       // tests: run a narrow chain through the wide kernels
@@ -293,6 +296,18 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         UserTarget& U = g_user_targets[cfg->target - DHMC_TARGET_USER_BASE];
         const auto key = std::make_pair((int)cfg->device, c->NPL);
         auto it = U.built.find(key);
+        if (it == U.built.end() && user_big) {
+            std::vector<char> code;
+            std::vector<std::string> low;
+            if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low))) return fail(rc);
+            UserKernels K;
+            auto load = [&]() { return rtc_load(code, low, &K.mod, {&K.eval}); };
+            if ((rc = load())) {
+                code.clear(); low.clear();
+                if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low, true)) || (rc = load())) return fail(rc);
+            }
+            it = U.built.emplace(key, K).first;
+        }
         if (it == U.built.end()) {
             std::vector<char> code;
             std::vector<std::string> low;
@@ -305,7 +320,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             }
             it = U.built.emplace(key, K).first;
         }
-        if (cfg->metric == DHMC_METRIC_DENSE && !it->second.dense_mod) {
+        if (cfg->metric == DHMC_METRIC_DENSE && !it->second.dense_mod && !user_big) {
             std::vector<char> code;
             std::vector<std::string> low;
             if ((rc = rtc_compile(U.source, U.name, c->NPL, true, &code, &low))) return fail(rc);
@@ -316,7 +331,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
                 if ((rc = rtc_compile(U.source, U.name, c->NPL, true, &code, &low, true)) || (rc = load())) return fail(rc);
             }
         }
-        c->user = &it->second;
+        if (user_big) c->user_eval = it->second.eval;       // the streaming engine's kernels are the library's own (ExternalT)
+        else c->user = &it->second;
     }
     if (cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL) {
         std::vector<double> a(Dp, 0.0), b(Dp, 0.0);
@@ -529,6 +545,18 @@ int external_eval(dhmc_ctx* c, const double* q, bool active) {
         launch_gemm_rows(c->d_big[0], c->tp.b, c->d_big[1], ld, c->cfg.chains, nullptr, nullptr, c->stream);      // P·d for every chain
         if (c->NPL == 32) hipLaunchKernelGGL((builtin_dense_normal_post_kernel<32>), g, b, 0, c->stream, ld, (const double*)c->d_big[0], (const double*)c->d_big[1], c->lr.S1, c->rb.tbuf);
         else hipLaunchKernelGGL((builtin_dense_normal_post_kernel<64>), g, b, 0, c->stream, ld, (const double*)c->d_big[0], (const double*)c->d_big[1], c->lr.S1, c->rb.tbuf);
+        return DHMC_OK;
+    }
+    if (c->user_eval) {       // a caller's functor beyond 1024 coordinates (nuts_kernels.hpp functor_eval_kernel)
+        TargetParams tp = c->tp;
+        int D = c->cfg.dim, ld = c->Dpad;
+        double* lq = c->lr.S1;
+        double* grad = c->rb.tbuf;
+        void* args[] = {&tp, &D, &ld, (void*)&q, &lq, &grad};
+        if (hipModuleLaunchKernel(c->user_eval, (unsigned)c->cfg.chains, 1, 1, WAVE, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) {
+            c->err = "dhmc: launch of the functor's evaluation kernel failed";
+            return DHMC_ERR_HIP;
+        }
         return DHMC_OK;
     }
     if (c->builtin_big) {

@@ -969,6 +969,26 @@ __global__ __launch_bounds__(64) void stepsize_search_kernel(SearchParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
+// ℓ and ∇ℓ of every chain's row through a functor whose chains are too wide for the register-resident kernels
+// (1024 < D <= 4096): the evaluation the streaming round engine asks for between its kernels where an external model's callback
+// stands (external_rounds.hpp; dhmc_capi.hip external_eval) — a caller's functor beyond 1024 coordinates (hamiltonian.jl:146-147,204
+// put no limit on the dimension).  One wave per chain, the functor's own arithmetic; evaluate_ℓ's rules are applied by the engine.
+// ------------------------------------------------------------------------------------------
+template <class T, int NPL>
+__global__ __launch_bounds__(64) void functor_eval_kernel(TargetParams tp, int D, int ld, const double* __restrict__ q,
+                                                          double* __restrict__ lq, double* __restrict__ grad) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    const T tgt(tp);
+    double qv[NPL], gv[NPL];
+    ldv<NPL>(q + (size_t)chain * ld, lane, qv);
+    const double lres = tgt.eval(qv, gv, lane, D);
+    double l = lres;
+    if constexpr (T::kDeferred) l = tgt.finish(wave_allreduce1(lres));
+    stv<NPL>(grad + (size_t)chain * ld, lane, gv);
+    if (lane == 0) lq[chain] = l;
+}
+
+// ------------------------------------------------------------------------------------------
 // End-of-stage metric: κ = GaussianKineticEnergy(Diagonal(var(posterior_matrix; dims=2)))
 // (mcmc.jl:209,281-284; hamiltonian.jl:80) per chain from its own draws [C][N][D].
 // Statistics.var with dims reduces sequentially over draws: mean = (Σx)/n, Σ(x-mean)²/(n-1).

@@ -103,15 +103,17 @@ extern "C" {
 #define DHMC_TARGET_EXTERNAL 7     /* the caller's own model: l and grad come from a callback evaluated for all chains at once
                                     * (dhmc_set_logdensity_callback); dim <= 4096, diagonal or shared dense metric. params: none */
 /* Dimension limits.  dim <= 1024: every family, every metric (register/LDS-resident kernels, GEMM round engines).
- * 1024 < dim <= 4096: DHMC_TARGET_EXTERNAL and every built-in family (STD / DIAG / TRIDIAG / DENSE normal, funnel, logistic
- * regression, the always-divergent test density), diagonal or shared dense metric, through the streaming round engine: the library evaluates the density of all
+ * 1024 < dim <= 4096: DHMC_TARGET_EXTERNAL, a caller's device functor (round 5: its eval() compiled into a batched evaluation kernel)
+ * and every built-in family (STD / DIAG / TRIDIAG / DENSE normal, funnel, logistic regression, the always-divergent test
+ * density), diagonal or shared dense metric, through the streaming round engine: the library evaluates the density of all
  * chains itself where the callback would stand — the normal families and the funnel in one kernel, the dense normal as one
  * product (q − μ)·P over the chains, the logistic gradient as its two GEMMs over the chains — with the families' arithmetic
  * (dhmc_set_logdensity_callback is then DHMC_ERR_INVALID_ARGUMENT).  dim > 4096 and per-chain dense metrics beyond 1024:
  * DHMC_ERR_UNSUPPORTED. */
 #define DHMC_TARGET_USER_BASE 1000  /* + the handle dhmc_register_target_source returned: the caller's own DEVICE FUNCTOR, compiled at run
                                     * time into the library's own per-draw, initialisation and step-size-search kernels — no host round
-                                    * trip per leapfrog, the same kernels the built-in families run.  Diagonal or shared dense metric, dim <= 1024.
+                                    * trip per leapfrog, the same kernels the built-in families run.  Diagonal or shared dense metric; dim <= 1024 inside the per-draw
+                                    * kernels, 1024 < dim <= 4096 evaluated for all chains between the streaming round engine's kernels.
                                     * params: any number of doubles, handed to the functor's constructor (TargetParams::a, n = count). */
 #define DHMC_TARGET_ALWAYS_DIVERGENT 5 /* the reference's fault-injection double (test/test_NUTS.jl:58-73): l = 0 at the origin, -Inf elsewhere, grad = ones. params: none */
 
@@ -198,7 +200,8 @@ int dhmc_host_free(void* p);
  * chain of at most 64 coordinates): such chains are reduced over their first 16 / 32 lanes only (csrc/wave.hpp wave_allreduce), so
  * a constant term of ℓ belongs in finish() or in a lane that holds a coordinate, never in a pad lane.  The source is compiled with hiprtc (-O3 -ffp-contract=off, as the library itself) against the
  * library's kernel templates when a context is created with target = DHMC_TARGET_USER_BASE + *target_handle; compile errors come
- * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().  dim <= 1024; diagonal
+ * back from dhmc_create as DHMC_ERR_INVALID_ARGUMENT with the compiler's log in dhmc_target_source_log().  dim <= 1024 (beyond, up to 4096: only eval() is compiled, into functor_eval_kernel, and the streaming
+ * round engine calls it where an external model's callback would stand); diagonal
  * metric (the wave-per-chain kernels) or the shared dense metric (a second module, compiled when the first dense context of the
  * functor is created: the GEMM round engine's kernels around the functor, and the wave-per-chain dense kernels for small batches).
  * dhmc_check_target_source compiles only (no device needed) the kernels of `metric` for `dim` coordinates and returns the log.

@@ -16,27 +16,45 @@ def pkg():
     return load_package()
 
 
-@pytest.mark.parametrize("D", [5, 200, 1000])
+@pytest.mark.parametrize("D", [5, 200, 1000, 1500, 2500])
 def test_user_written_diag_normal_is_bit_equal_to_the_builtin_family_and_the_oracle(pkg, D):
+    """(1500, 2500: beyond the register-resident kernels — the functor's eval() compiled into functor_eval_kernel, which the streaming
+    round engine calls where an external model's callback would stand; the reference puts no limit on the dimension,
+    hamiltonian.jl:146-147.)"""
     rng = np.random.default_rng(D)
     mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
     user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
-    C = 6
+    C = 6 if D <= 1024 else 3
+    n1, n2 = (25, 12) if D <= 1024 else (8, 5)
 
     def steps(ctx):
         out = {}
         ctx.init(); ctx.find_initial_stepsize()
         out["eps0"] = ctx.stepsize()
-        a = ctx.run(25, da={})
+        a = ctx.run(n1, da={})
         ctx.update_metric_diag(a["draws"])
         out.update({"w_" + k: v for k, v in a.items()})
-        out.update({"i_" + k: v for k, v in ctx.run(12).items()})
+        out.update({"i_" + k: v for k, v in ctx.run(n2).items()})
         q, lq, g = ctx.position()
         out.update(q=q, lq=lq, g=g)
         return out
     a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
     b = steps(pkg.DeviceContext(D, C, target=ol.TARGET_DIAG_NORMAL, target_params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3))
     o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3, threads=6))
+    if D > 1024:          # … and with the shared dense metric: the engine's products are the MFMA GEMMs, the density still the functor's
+        idx = np.arange(D)
+        S = 0.5 ** np.abs(idx[:, None] - idx[None, :]) + 0.5 * np.eye(D)
+        res = []
+        for mk in (lambda: pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=5, metric=ol.METRIC_DENSE),
+                   lambda: ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=5,
+                                     metric=ol.METRIC_DENSE, threads=6)):
+            e = mk()
+            e.set_metric_dense(S); e.init(); e.find_initial_stepsize()
+            res.append((e.stepsize(), e.run(5, da={}), e.run(3)))
+        assert np.array_equal(res[0][0], res[1][0])
+        for x, y in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
+            for k in x:
+                assert np.array_equal(x[k], y[k]), k
     for k in a:
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], o[k]), k

@@ -11,8 +11,9 @@ def pkg():
     return load_package()
 
 
-@pytest.mark.parametrize("dim", [3, 100, 1000])
+@pytest.mark.parametrize("dim", [3, 100, 1000, 1500, 4000])
 def test_user_functors_compile_into_the_kernels(pkg, dim):
+    """(beyond 1024 coordinates only the batched evaluation kernel is compiled: functor_eval_kernel, nuts_kernels.hpp)"""
     for src, name in ((uf.DIAG_NORMAL, "MyDiagNormal"), (uf.STUDENT_T, "StudentT")):
         ok, log = pkg.DeviceFunctorLogDensity.check(dim, src, name)
         assert ok, log
@@ -40,5 +41,5 @@ def test_compile_errors_come_back_with_the_log(pkg):
     assert "undeclared_thing" in log
     ok, log = pkg.DeviceFunctorLogDensity.check(10, uf.DIAG_NORMAL, "NoSuchStruct")
     assert not ok and "NoSuchStruct" in log
-    ok, _ = pkg.DeviceFunctorLogDensity.check(5000, uf.DIAG_NORMAL, "MyDiagNormal")      # beyond 1024 coordinates: unsupported
+    ok, _ = pkg.DeviceFunctorLogDensity.check(5000, uf.DIAG_NORMAL, "MyDiagNormal")      # beyond 4096 coordinates: unsupported
     assert not ok
