@@ -698,14 +698,34 @@ def mcmc(slogd, N, warmup_state):
     return dict(posterior_matrix=draws, tree_statistics=ts, logdensities=lds)
 
 
+PER_CHAIN_DENSE_AUTO_DIM = 256              # per_chain_metric=None: every chain its own Symmetric metric up to this dimension …
+PER_CHAIN_DENSE_AUTO_BYTES = 2 << 30        # … while the C pairs (M⁻¹, Wᵀ) of padded matrices stay below this
+
+
+def _per_chain_metric_default(l, chains, metric_allreduce):
+    """What `per_chain_metric=None` means for a Symmetric warmup: the reference's semantics — every chain adapts its own M⁻¹ from its
+    own draws (mcmc.jl:281-285) — whenever that is affordable: a built-in functor family (the wave-per-chain dense kernels; a caller's
+    functor and callback models run the shared dense metric only), at most 256
+    coordinates (beyond, a matvec per chain streams 8·D² bytes per leapfrog and the pooled GEMM engine is the practical choice),
+    2·C·Dpad² doubles within 2 GiB, no job-wide pooling requested.  Otherwise ONE M⁻¹ pooled over the context's chains (the batched
+    engine's design; a stated deviation from the reference)."""
+    D = l.dimension()
+    dpad = 64 * max(1, -(-D // 64))
+    return (metric_allreduce is None and l.family not in (abi.TARGET_EXTERNAL, abi.TARGET_LOGISTIC) and l.family < abi.TARGET_USER_BASE
+            and D <= PER_CHAIN_DENSE_AUTO_DIM
+            and 16 * chains * dpad * dpad <= PER_CHAIN_DENSE_AUTO_BYTES)
+
+
 def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False, per_chain_metric=False, metric_allreduce=None, _keep_warmup=True):
+                     reporter=None, device=0, on_device=False, per_chain_metric=None, metric_allreduce=None, _keep_warmup=True):
     """mcmc.jl:521-532.  `chains` independent chains run at once on one GPU.  `on_device=True` returns the
     posterior matrices and statistics as torch CUDA tensors (no PCIe copy of the draws).
-    `per_chain_metric` concerns Symmetric (dense) metrics only — a Diagonal κ is always per chain: False (default) adapts ONE
-    M⁻¹ from the pooled draws of all chains, which is what lets the leapfrog's products run as one GEMM over the batch;
-    True gives every chain its own M⁻¹ adapted from its own draws, exactly what C separate calls of the reference do
-    (mcmc.jl:281-284) — the wave-per-chain dense kernels, 2·C·D² doubles of HBM; κ.M⁻¹ then comes back as [C][D][D].
+    `per_chain_metric` concerns Symmetric (dense) metrics only — a Diagonal κ is always per chain: True gives every chain its own
+    M⁻¹ adapted from its own draws, exactly what C separate calls of the reference do (mcmc.jl:281-284) — the wave-per-chain dense
+    kernels, 2·C·D² doubles of HBM; κ.M⁻¹ then comes back as [C][D][D]; False adapts ONE M⁻¹ from the pooled draws of all chains,
+    which is what lets the leapfrog's products run as one GEMM over the batch; None (default, round 5): the reference's per-chain
+    semantics where that is affordable (`_per_chain_metric_default`: at most 256 coordinates, a functor family, ≤ 2 GiB of
+    matrices), the pooled metric otherwise.
     `metric_allreduce` (a job sharded over several GPUs, one process each, `rng.chain_offset` = the block's first chain): an
     in-place SUM over the ranks (sharding.TorchAllReduce(torch.distributed)) — the shared Symmetric M⁻¹ is then adapted from the
     draws of ALL ranks, so every rank samples with the matrix one GPU holding all chains would have adapted (to rounding)."""
@@ -717,6 +737,10 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     k0 = init.get("κ", init.get("kappa"))
     wants_dense = any(isinstance(s, TuningNUTS) and s.M == Symmetric for s in warmup_stages)
     metric = abi.METRIC_DENSE if ((k0 is not None and k0.dense) or wants_dense) else abi.METRIC_DIAG
+    if per_chain_metric is None:
+        per_chain_metric = metric == abi.METRIC_DENSE and _per_chain_metric_default(l, chains, metric_allreduce)
+        if k0 is not None and k0.dense and np.ndim(k0.Minv) == 2:
+            per_chain_metric = False               # a caller who hands over ONE matrix for all chains asks for the shared metric
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
                         chain_offset=rng.chain_offset, device=device, metric=metric,
@@ -735,7 +759,7 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
 
 
 def mcmc_with_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
-                     reporter=None, device=0, on_device=False, per_chain_metric=False, metric_allreduce=None):
+                     reporter=None, device=0, on_device=False, per_chain_metric=None, metric_allreduce=None):
     """mcmc.jl:575-584: returns posterior_matrix [C][N][D], tree_statistics, logdensities [C][N], κ, ϵ [C].
     The warmup stages' draws never leave the GPU (the reference discards them too, mcmc.jl:579-583)."""
     r = mcmc_keep_warmup(rng, l, N, chains=chains, initialization=initialization, warmup_stages=warmup_stages,

@@ -328,7 +328,7 @@ end
 # mcmc_keep_warmup / mcmc_with_warmup (mcmc.jl:521-532,575-584) with `chains` chains on one GPU
 function DynamicHMC.mcmc_keep_warmup(rng::Integer, ℓ::DeviceLogDensity, N::Integer; chains = 1, initialization = (),
                                      warmup_stages = default_warmup_stages(), algorithm = NUTS(),
-                                     reporter = default_reporter(), device = 0, chain_offset = 0, per_chain_metric = false)
+                                     reporter = default_reporter(), device = 0, chain_offset = 0, per_chain_metric = false)   # (the Python twin defaults to the reference's per-chain metric where affordable: api.py _per_chain_metric_default)
     # per_chain_metric (Symmetric κ only; a Diagonal κ is always per chain): false — one M⁻¹ adapted from the pooled draws of all
     # chains (the leapfrog's products are one GEMM); true — every chain its own, as `chains` separate calls of the reference
     dense = any(s -> s isa TuningNUTS{Symmetric}, warmup_stages) || get(initialization, :κ, nothing) isa Matrix

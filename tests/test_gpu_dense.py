@@ -113,7 +113,9 @@ def test_dense_metric_adaptation_pooled(pkg):
 
 
 def test_default_warmup_with_symmetric_metric(pkg):
-    """mcmc_with_warmup(...; warmup_stages = default_warmup_stages(; M = Symmetric)) (mcmc.jl docstring :566-569)."""
+    """mcmc_with_warmup(...; warmup_stages = default_warmup_stages(; M = Symmetric)) (mcmc.jl docstring :566-569).  Since round 5 the
+    default for a small model is the reference's own: every chain adapts ITS metric from ITS draws (mcmc.jl:281-285; api.py
+    _per_chain_metric_default); per_chain_metric=False is the pooled metric of the batched engine."""
     K = 6
     rho = 0.7
     diag = np.full(K, (1 + rho ** 2) / (1 - rho ** 2)); diag[0] = diag[-1] = 1 / (1 - rho ** 2)
@@ -121,10 +123,16 @@ def test_default_warmup_with_symmetric_metric(pkg):
     l = pkg.TridiagNormal(diag, off)
     r = pkg.mcmc_with_warmup(5, l, 1500, chains=8, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric),
                              reporter=pkg.NoProgressReport())
-    assert r["kappa"].dense and r["kappa"].Minv.shape == (K, K)
+    assert r["kappa"].dense and r["kappa"].Minv.shape == (8, K, K)                      # one Symmetric κ per chain
     P = np.diag(diag) + np.diag(off, 1) + np.diag(off, -1)
     q = r["posterior_matrix"].reshape(-1, K)
     assert np.allclose(np.cov(q.T), np.linalg.inv(P), atol=0.15, rtol=0.15)
+    assert np.allclose(r["kappa"].Minv.mean(0), np.linalg.inv(P), atol=0.3, rtol=0.3)   # each from 400 draws: their mean is close
+    assert not np.array_equal(r["kappa"].Minv[0], r["kappa"].Minv[1])
+    assert r["tree_statistics"].acceptance_rate.mean() >= 0.7
+    r = pkg.mcmc_with_warmup(5, l, 1500, chains=8, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric),
+                             reporter=pkg.NoProgressReport(), per_chain_metric=False)
+    assert r["kappa"].dense and r["kappa"].Minv.shape == (K, K)                         # the pooled metric on request
     assert np.allclose(r["kappa"].Minv, np.linalg.inv(P), atol=0.3, rtol=0.3)
     assert r["tree_statistics"].acceptance_rate.mean() >= 0.7
 
