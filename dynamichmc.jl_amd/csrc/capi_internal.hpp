@@ -89,9 +89,9 @@ struct dhmc_ctx {
     // the packed small-D engine (packed_core.hpp): several chains per wavefront for diagonal-metric chains of at most 64 coordinates
     int packed = 0;                        // the context's chains can run packed; DHMC_PACKED=0: never, =1: always, unset: by the previous launch's work
     int packed_force = 0;
-    int pair = 0;                          // the context's chains can run as integrator / tree-builder pairs (nuts_pair_kernel.hpp): launches that the
-                                           // previous launch showed to be held open by a few chains; DHMC_PAIR=0: never, =1: always
-    int pair_force = 0;
+    int pipeline = 0;                      // the context's chains can run as three-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
+                                           // previous launch showed to be held open by a few chains; DHMC_PIPELINE=0: never, =1: always
+    int pipeline_force = 0;
     int pk_align = 4;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two)
     int pk_cpl = 0;                        // DHMC_PK_CPL: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
     int pk_lds_levels = -1;                // DHMC_PK_LDS_LEVELS: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)

@@ -253,12 +253,12 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // have a packed evaluator; the same bits as the wave-per-chain kernel, which DHMC_PACKED=0 brings back.
     c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::dim_is_packed(D);
     if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = c->packed && std::atoi(e) != 0; c->packed_force = c->packed; }
-    // … and as a PAIR of wavefronts per chain (integrator ‖ tree builder, nuts_pair_kernel.hpp): the lowest latency per leapfrog of a
-    // short chain, for launches that wait for a few deep chains
-    c->pair = cfg->metric == DHMC_METRIC_DIAG && D <= 64 &&
+    // … and as a PIPELINE of three wavefronts per chain (integrator ‖ turn statistics ‖ scalars, nuts_pipeline_kernel.hpp): the lowest
+    // latency per leapfrog of a short chain, for launches that wait for a few deep chains
+    c->pipeline = cfg->metric == DHMC_METRIC_DIAG && D <= 64 &&
               (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL ||
                cfg->target == DHMC_TARGET_FUNNEL || cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_ALWAYS_DIVERGENT);
-    if (const char* e = std::getenv("DHMC_PAIR")) { c->pair = c->pair && std::atoi(e) != 0; c->pair_force = c->pair; }
+    if (const char* e = std::getenv("DHMC_PIPELINE")) { c->pipeline = c->pipeline && std::atoi(e) != 0; c->pipeline_force = c->pipeline; }
     if (const char* e = std::getenv("DHMC_PK_ALIGN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->pk_align = v; }
     if (const char* e = std::getenv("DHMC_PK_LDS_LEVELS")) c->pk_lds_levels = std::atoi(e);
     if (const char* e = std::getenv("DHMC_PK_CPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) c->pk_cpl = v; }
@@ -801,11 +801,16 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     // wave-per-chain kernel's throughput on chains of even work — but a trip of its loop costs more clocks than the other
     // kernel's leapfrog (4 300 against 3 700 at 30 coordinates), and a launch ends with its slowest chain, whose leapfrogs are
     // sequential: when the previous launch was held open by a few chains with many times the mean's work (Neal's funnel: chains in
-    // the neck run trees of the depth limit, 13 × the mean over 1000 transitions), the launch goes to the kernel with the lower
-    // latency.  The same bits either way (both kernels are checked against the oracle).  DHMC_PACKED=1 / 0: always / never.
-    const bool pair = per_draw_kernel && c->pair && !c->packed_force && (c->pair_force || c->tail_bound);
-    const bool packed = !pair && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
-    const Op run_op = pair ? Op::RunPair : packed ? Op::RunPacked : Op::Run;
+    // the neck run trees of the depth limit, 13 × the mean over 1000 transitions), the launch goes to the kernel with the lowest
+    // latency per leapfrog: the three-wave pipeline (nuts_pipeline_kernel.hpp, ≈ 2 400 clocks) where the family allows it, else the
+    // wave-per-chain kernel.  The same bits whichever runs (all are checked against the oracle).  DHMC_PACKED / DHMC_PIPELINE = 1 / 0:
+    // always / never.
+    // … and when the chains are so few that each of their three waves gets a SIMD of its own (3·C <= 4 per CU — the reference's
+    // typical handful of chains): such a launch is all latency, whatever its trees look like
+    const bool few_chains = 3LL * C <= 4LL * c->num_cus;
+    const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || c->tail_bound || few_chains);
+    const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
+    const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
     if (packed) {
         // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
         // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)

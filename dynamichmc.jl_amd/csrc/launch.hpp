@@ -16,7 +16,7 @@ struct RoundArgs {
     RoundBuffers R;
 };
 
-enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3, ProbeTrajectory, ProbeRatios, RunPacked, RunPair };
+enum class Op { Run, Init, Search, RoundStart, RoundK0, RoundK2, RoundK3, ProbeTrajectory, ProbeRatios, RunPacked, RunPipeline };
 
 // launches `op` of family T with NPL = npl slots per lane on stream s (M: the dense metric, or null)
 template <class T>

@@ -24,6 +24,7 @@ def _always_packed():
     library picks the engine per launch from the previous launch's work."""
     old = os.environ.get("DHMC_PACKED")
     os.environ["DHMC_PACKED"] = "1"
+    os.environ.pop("DHMC_PIPELINE", None)
     yield
     if old is None:
         os.environ.pop("DHMC_PACKED", None)
@@ -122,7 +123,7 @@ def test_packed_equals_wave_kernel_windows_and_launch_order(pkg):
     D, C = 30, 300
     res = []
     for packed in (1, 0):
-        with _env(DHMC_PACKED=packed, DHMC_HOST_CHUNK=7):
+        with _env(DHMC_PACKED=packed, DHMC_PIPELINE=0, DHMC_HOST_CHUNK=7):
             dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=8)
         dev.init(); dev.find_initial_stepsize()
         out = [dev.run(30, da={})]

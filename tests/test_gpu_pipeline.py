@@ -1,5 +1,5 @@
-"""GPU: the pair kernel (csrc/nuts_pair_kernel.hpp: a short chain as an integrator wavefront and a tree-builder wavefront joined by a
-ring of leaf records in LDS) against the oracle and the wave-per-chain kernel, bit for bit: every family it serves, dimensions
+"""GPU: the pipeline kernel (csrc/nuts_pipeline_kernel.hpp: a short chain as three wavefronts — integrator, turn-statistic builder,
+scalar builder — joined by a ring of leaf records in LDS) against the oracle and the wave-per-chain kernel, bit for bit: every family it serves, dimensions
 1 … 64, divergences / depth limits / −Inf densities (the integrator runs ahead of trees that end early), metric windows, launch
 order, host outputs in chunks, resumed calls, and the engine choice of dhmc_run after a launch that a few chains held open."""
 import os
@@ -19,9 +19,9 @@ def pkg():
 
 
 @pytest.fixture(autouse=True)
-def _always_pair():
-    old = {k: os.environ.get(k) for k in ("DHMC_PAIR", "DHMC_PACKED")}
-    os.environ["DHMC_PAIR"] = "1"
+def _always_pipeline():
+    old = {k: os.environ.get(k) for k in ("DHMC_PIPELINE", "DHMC_PACKED")}
+    os.environ["DHMC_PIPELINE"] = "1"
     os.environ.pop("DHMC_PACKED", None)
     yield
     for k, v in old.items():
@@ -101,11 +101,11 @@ def test_trees_that_end_early(pkg):
     assert (a["depth"] == 0).all() and (a["steps"] == 1).all()
 
 
-def test_pair_equals_wave_and_packed_kernels_over_a_warmup(pkg):
+def test_pipeline_equals_wave_and_packed_kernels_over_a_warmup(pkg):
     """300 funnel chains through the three engines: adaptation, two metric windows, launch order, host outputs in chunks."""
     D, C = 30, 300
     res = []
-    for env in (dict(DHMC_PAIR="1"), dict(DHMC_PAIR="0", DHMC_PACKED="0"), dict(DHMC_PAIR="0", DHMC_PACKED="1")):
+    for env in (dict(), dict(DHMC_PIPELINE="0", DHMC_PACKED="0"), dict(DHMC_PIPELINE="0", DHMC_PACKED="1")):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env); os.environ["DHMC_HOST_CHUNK"] = "7"
         try:
@@ -134,12 +134,12 @@ def test_pair_equals_wave_and_packed_kernels_over_a_warmup(pkg):
 
 
 def test_engine_choice_after_a_tail_bound_launch(pkg):
-    """Without DHMC_PAIR / DHMC_PACKED: packed until a launch is held open by a few chains, the pair kernel after it; the bits of
+    """Without DHMC_PIPELINE / DHMC_PACKED: packed until a launch is held open by a few chains, the pipeline kernel after it; the bits of
     the wave-per-chain kernel throughout."""
     D, C = 30, 512
     res = []
-    for env in (dict(), dict(DHMC_PAIR="0", DHMC_PACKED="0")):
-        os.environ.pop("DHMC_PAIR", None)
+    for env in (dict(), dict(DHMC_PIPELINE="0", DHMC_PACKED="0")):
+        os.environ.pop("DHMC_PIPELINE", None)
         os.environ.update(env)
         try:
             dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=31)

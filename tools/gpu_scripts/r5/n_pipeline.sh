@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 5: the pair kernel (integrator ‖ tree builder) — parity, then config 4 timing: wave vs pair
-O=gpurun_out/r5n; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_pair.py -x -q 2>&1 | tail -12 > $O/pair.log; cat $O/pair.log
-for v in "pair DHMC_PAIR=1" "wave DHMC_PAIR=0"; do
+O=gpurun_out/r5q; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_packed.py -x -q 2>&1 | tail -12 > $O/pair.log; cat $O/pair.log
+for v in "pipeline DHMC_PIPELINE=1" "wave DHMC_PIPELINE=0"; do
   set -- $v
   env $2 DHMC_PACKED=0 PH_STUCK=1 timeout 120 python tools/experiments/packed_probe.py 8 10 2>&1 | grep chains | sed "s/^/stuck $1: /"
   env $2 DHMC_PACKED=0 timeout 600 python bench.py --config 4 --transitions 1000 --steps 1 --warmup 0 2>/dev/null | tail -1 > $O/c4_T1000_$1.json
