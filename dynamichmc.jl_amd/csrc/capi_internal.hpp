@@ -89,7 +89,7 @@ struct dhmc_ctx {
     // the packed small-D engine (packed_core.hpp): several chains per wavefront for diagonal-metric chains of at most 64 coordinates
     int packed = 0;                        // the context's chains can run packed; DHMC_PACKED=0: never, =1: always, unset: by the previous launch's work
     int packed_force = 0;
-    int pipeline = 0;                      // the context's chains can run as three-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
+    int pipeline = 0;                      // the context's chains can run as four-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
                                            // previous launch showed to be held open by a few chains; DHMC_PIPELINE=0: never, =1: always
     int pipeline_force = 0;
     int pk_align = 4;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two)

@@ -253,7 +253,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // have a packed evaluator; the same bits as the wave-per-chain kernel, which DHMC_PACKED=0 brings back.
     c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::dim_is_packed(D);
     if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = c->packed && std::atoi(e) != 0; c->packed_force = c->packed; }
-    // … and as a PIPELINE of three wavefronts per chain (integrator ‖ turn statistics ‖ scalars, nuts_pipeline_kernel.hpp): the lowest
+    // … and as a PIPELINE of four wavefronts per chain (integrator ‖ turn statistics ‖ visited statistic ‖ proposals, nuts_pipeline_kernel.hpp): the lowest
     // latency per leapfrog of a short chain, for launches that wait for a few deep chains
     c->pipeline = cfg->metric == DHMC_METRIC_DIAG && D <= 64 &&
               (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL ||
@@ -802,12 +802,12 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     // kernel's leapfrog (4 300 against 3 700 at 30 coordinates), and a launch ends with its slowest chain, whose leapfrogs are
     // sequential: when the previous launch was held open by a few chains with many times the mean's work (Neal's funnel: chains in
     // the neck run trees of the depth limit, 13 × the mean over 1000 transitions), the launch goes to the kernel with the lowest
-    // latency per leapfrog: the three-wave pipeline (nuts_pipeline_kernel.hpp, ≈ 2 400 clocks) where the family allows it, else the
+    // latency per leapfrog: the four-wave pipeline (nuts_pipeline_kernel.hpp, ≈ 2 000 clocks) where the family allows it, else the
     // wave-per-chain kernel.  The same bits whichever runs (all are checked against the oracle).  DHMC_PACKED / DHMC_PIPELINE = 1 / 0:
     // always / never.
-    // … and when the chains are so few that each of their three waves gets a SIMD of its own (3·C <= 4 per CU — the reference's
+    // … and when the chains are so few that each of their four waves gets a SIMD of its own (C <= the number of CUs — the reference's
     // typical handful of chains): such a launch is all latency, whatever its trees look like
-    const bool few_chains = 3LL * C <= 4LL * c->num_cus;
+    const bool few_chains = C <= c->num_cus;
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || c->tail_bound || few_chains);
     const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;

@@ -102,7 +102,7 @@ void dispatch_op(Op op, const void* P, hipStream_t s, const DenseMetric* M) {
 template <class T>
 int dispatch_family(int npl, Op op, const void* P, hipStream_t s, const DenseMetric* M) {
     if (op == Op::RunPacked) return launch_run_packed<T>(*(const RunParams*)P, s);   // several chains per wave (packed_kernels.hpp)
-    if (op == Op::RunPipeline) return launch_run_pipeline<T>(*(const RunParams*)P, s);   // integrator ‖ turn statistics ‖ scalars (nuts_pipeline_kernel.hpp)
+    if (op == Op::RunPipeline) return launch_run_pipeline<T>(*(const RunParams*)P, s);   // integrator ‖ turn statistics ‖ visited statistic ‖ proposals (nuts_pipeline_kernel.hpp)
     switch (npl) {
     case 1: dispatch_op<T, 1>(op, P, s, M); return DHMC_OK;
     case 2: dispatch_op<T, 2>(op, P, s, M); return DHMC_OK;

@@ -1,5 +1,6 @@
-// The per-draw loop of a SHORT chain (at most 64 coordinates, diagonal metric) as a PIPELINE of three wavefronts in one workgroup:
-// an integrator, a turn-statistic builder and a scalar builder, joined by a ring of leaf records in LDS.
+// The per-draw loop of a SHORT chain (at most 64 coordinates, diagonal metric) as a PIPELINE of four wavefronts in one workgroup — a
+// CU's four SIMDs: an integrator, a turn-statistic builder, a visited-statistic builder and a proposal builder, joined by a ring of
+// leaf records in LDS.
 //
 // Why.  A launch ends with its slowest chain, and a chain's leapfrogs are sequential: Neal's funnel at 1000 transitions has a chain
 // with 13.5 × the mean's work (836 716 leapfrogs), and the call lasts exactly as long as that chain × the kernel's latency per
@@ -7,7 +8,8 @@
 // density, kinetic energy) is ≈ 40 %, the merges' vector work ≈ 25 % and their scalar work (logaddexp, picks, bookkeeping) the
 // rest.  Nothing downstream feeds the next leapfrog except the decision to stop; the turn statistics (p₋, p₊, ρ and the six dots of
 // a merge) never depend on the proposals' weights or picks, and the weights never on the statistics — only on WHETHER a merge was
-// turning.  So the three parts run as three instruction streams on three SIMDs of a CU:
+// turning; and the visited statistic (the acceptance rate's log Σ min(1, e^Δ)) depends on the leaves' Δ and on which merges happen,
+// while only the end of the transition reads it.  So the parts run as four instruction streams on the four SIMDs of a CU:
 //
 //   wave A   the integrator: samples the momentum, walks the doublings in the order of the direction bits (both trajectory edges in
 //            its registers), and for every leaf writes a record (p, q, ℓq, π, flags) into the ring; for the odd leaf of a pair it
@@ -15,20 +17,22 @@
 //            depth and stops when the tree has ended.
 //   wave B1  the turn-statistic builder: the running summary (first, Σp), the suspended stack and the trajectory's τ, every merge's
 //            dots; per leaf it publishes ONE code — which merge of the leaf's cascade was turning, if any.
-//   wave B2  the scalar builder: Δ, ω and the visited statistic (logaddexp pairs), multinomial / biased-progressive picks with the
-//            Exp(1) stream, proposal slots (it reads q from the ring), termination record, outputs, dual averaging — nuts_run_kernel's
-//            loop with "take a record and a code" where the leapfrog and the dots stood — and hands the next position and step
-//            size back through a mailbox.
+//   wave B3  the visited-statistic builder: v = v₋ ⊕ v₊ where the tree merges, the unwinding where a subtree is invalid; one result
+//            per transition (log Σ α, steps).
+//   wave B2  the proposal builder: Δ, ω = logaddexp(ω₋, ω₊), multinomial / biased-progressive picks with the Exp(1) stream, proposal
+//            slots (it reads q from the ring), termination record, outputs, dual averaging — nuts_run_kernel's loop with "take a
+//            record and a code" where the leapfrog and the dots stood — and hands the next position and step size back through a
+//            mailbox.
 //
-// All three find a tree's end by themselves (divergent leaf: π of the record; turning: B1's code; depth limit), so nobody waits for
+// All four find a tree's end by themselves (divergent leaf: π of the record; turning: B1's code; depth limit), so nobody waits for
 // a message that is not coming; leaves integrated beyond the tree's end are discarded.  Counters that a faster wave reads across a
-// transition boundary carry the transition they belong to (tail1_seq, mseq): a stale count is read as zero.  Arithmetic, random
+// transition boundary carry the transition they belong to (tail1_seq, tail3_seq, mseq, aseq): a stale count is read as zero.  Arithmetic, random
 // streams and merge order are nuts_run_kernel's: the same bits (tests/test_gpu_pipeline.py compares the kernels and the oracle).
 // Every wait is bounded: a wave that polls longer than PAIR_SPIN_LIMIT times raises DHMC_ST_KERNEL_PROTOCOL in the chain's status
 // and all waves leave (a logic error must not hang the device).  Used by dhmc_run for launches that the previous launch showed to
 // be held open by a few chains (families whose gradient is recomputed from a stored position: every built-in functor family but
 // the logistic regression).  (A two-wave form — integrator ‖ whole tree builder — was measured first: 1.22 × the wave-per-chain
-// kernel on config 4 against this form's 1.3 ×; profiles/r05_pipeline_kernel.txt.)
+// kernel on config 4, three waves (B2 and B3 as one) 1.57 ×; profiles/r05_pipeline_kernel.txt.)
 #pragma once
 #include "nuts_kernels.hpp"
 
@@ -53,27 +57,28 @@ __device__ __forceinline__ unsigned pair_peek(volatile unsigned* flag) {
     asm volatile("" ::: "memory");
     return uni_u32(v);
 }
-// all control words in one round trip (three ds_read_b128)
-struct PairCtl { unsigned w[12]; };
+// all control words in one round trip (four ds_read_b128)
+struct PairCtl { unsigned w[16]; };
 __device__ __forceinline__ PairCtl pair_load_ctl(volatile unsigned* ctl) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const volatile v4u* p4 = reinterpret_cast<const volatile v4u*>(ctl);
-    const v4u a = p4[0], b = p4[1], c = p4[2];
+    const v4u a = p4[0], b = p4[1], c = p4[2], d = p4[3];
     asm volatile("" ::: "memory");
     PairCtl r;
     r.w[0] = uni_u32(a.x); r.w[1] = uni_u32(a.y); r.w[2] = uni_u32(a.z); r.w[3] = uni_u32(a.w);
     r.w[4] = uni_u32(b.x); r.w[5] = uni_u32(b.y); r.w[6] = uni_u32(b.z); r.w[7] = uni_u32(b.w);
     r.w[8] = uni_u32(c.x); r.w[9] = uni_u32(c.y); r.w[10] = uni_u32(c.z); r.w[11] = uni_u32(c.w);
+    r.w[12] = uni_u32(d.x); r.w[13] = uni_u32(d.y); r.w[14] = uni_u32(d.z); r.w[15] = uni_u32(d.w);
     return r;
 }
 
 constexpr int PIPE_TOP = 64;      // B1's code for "the top-level merge was turning" (0 … 31: the sub-merge at that level; -1: none)
 __host__ __device__ constexpr size_t pipeline_lds_bytes() {
-    return sizeof(double) * ((size_t)WAVE * (3 + 3 * lds_extra_levels(1)) + (size_t)PAIR_RING * (2 * WAVE + 4) + PAIR_RING + WAVE + 4 + 8);
+    return sizeof(double) * ((size_t)WAVE * (3 + 3 * lds_extra_levels(1)) + (size_t)PAIR_RING * (2 * WAVE + 4) + PAIR_RING + WAVE + 4 + 8);   // mb_s[2..3]: B3's result
 }
 
 template <class T>
-__global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
+__global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     static_assert(T::kRecomputeGrad, "the integrator re-evaluates ∇ℓ at the position the builder hands back");
     constexpr int NPL = 1;
     const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
@@ -101,6 +106,9 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
     volatile unsigned* const c_tail2 = ctl + 6;      // B2: records consumed (reset before seq_b is published)
     volatile unsigned* const c_seq_b = ctl + 7;      // B2: the transition whose start is in the mailbox
     volatile unsigned* const c_quit = ctl + 8;       // B2: done (1) / anyone: protocol error (2)
+    volatile unsigned* const c_tail3 = ctl + 9;      // B3: records (and codes) consumed …
+    volatile unsigned* const c_tail3_seq = ctl + 10; //     … of this transition
+    volatile unsigned* const c_aseq = ctl + 11;      // B3: the transition whose visited statistic is in mb_s[2..3]
     if (threadIdx.x < 16) ctl[threadIdx.x] = 0u;
     __syncthreads();
 
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
     const int nl = uni_i32(reduce_lanes(NPL, D));
     const uint32_t tr0 = P.st.transition[chain];
     bool broken = false;
-    enum { W_HEAD = 0, W_SEQ_A = 1, W_TAIL1 = 2, W_TAIL1_SEQ = 3, W_MHEAD = 4, W_MSEQ = 5, W_TAIL2 = 6, W_SEQ_B = 7, W_QUIT = 8 };
+    enum { W_HEAD = 0, W_SEQ_A = 1, W_TAIL1 = 2, W_TAIL1_SEQ = 3, W_MHEAD = 4, W_MSEQ = 5, W_TAIL2 = 6, W_SEQ_B = 7, W_QUIT = 8,
+           W_TAIL3 = 9, W_TAIL3_SEQ = 10, W_ASEQ = 11 };
     PairCtl cw;                                    // the control words as of the last poll
 #ifdef DHMC_PHASE_TIMING     // tools/experiments/pipeline_stage_timing.py: the clocks each wave spends waiting, and in all
     unsigned long long pt_wait = 0;
@@ -134,6 +143,10 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PAIR_SPIN_LIMIT) { broken = true; pair_publish(c_quit, 2u, lane); return false; }
         }
+    };
+    auto uni_i64v = [](long long x) -> long long {
+        const uint32_t lo = uni_u32((uint32_t)(unsigned long long)x), hi = uni_u32((uint32_t)((unsigned long long)x >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
     };
     auto directions_of = [&](uint32_t tr) -> uint32_t {
         uint32_t w[4];
@@ -170,10 +183,12 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
             unsigned head = 1u;
             pair_publish(c_head, head, lane);
             pair_publish(c_seq_a, want, lane);
-            auto consumed = [&](const PairCtl& c) -> unsigned {          // what BOTH readers have taken of this transition's records
+            auto consumed = [&](const PairCtl& c) -> unsigned {          // what ALL readers have taken of this transition's records
                 const unsigned t2 = c.w[W_TAIL2];
                 const unsigned t1 = c.w[W_TAIL1_SEQ] == want ? c.w[W_TAIL1] : 0u;
-                return t1 < t2 ? t1 : t2;
+                const unsigned t3 = c.w[W_TAIL3_SEQ] == want ? c.w[W_TAIL3] : 0u;
+                const unsigned t = t1 < t2 ? t1 : t2;
+                return t < t3 ? t : t3;
             };
             double qe[2] = {q[0], q[0]}, pe[2] = {p[0], p[0]}, ge[2] = {g[0], g[0]};
             bool ended = false;
@@ -252,9 +267,13 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
                 const uint32_t nleaf = 1u << depth;
                 for (uint32_t j = 0; j < nleaf && !finished; ++j) {
                     if (!(avail > tail && tail - seen2 < (unsigned)PAIR_RING)) {     // (by the last poll's counts: they only advance)
-                        if (!wait_for([&](const PairCtl& c) { return c.w[W_HEAD] > tail && tail - c.w[W_TAIL2] < (unsigned)PAIR_RING; })) return;
+                        auto readers = [&](const PairCtl& c) -> unsigned {             // what both readers of the codes have taken
+                            const unsigned t3 = c.w[W_TAIL3_SEQ] == want ? c.w[W_TAIL3] : 0u;
+                            return c.w[W_TAIL2] < t3 ? c.w[W_TAIL2] : t3;
+                        };
+                        if (!wait_for([&](const PairCtl& c) { return c.w[W_HEAD] > tail && tail - readers(c) < (unsigned)PAIR_RING; })) return;
                         avail = cw.w[W_HEAD];
-                        seen2 = cw.w[W_TAIL2];
+                        seen2 = readers(cw);
                     }
                     const unsigned slot = tail % (unsigned)PAIR_RING;
                     p[0] = ring_p[slot * WAVE + lane];
@@ -355,12 +374,94 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
         return;
     }
 
+    if (wave == 2) {
+        // ===================================== B3: the visited statistic (NUTS.jl:59-89) =====================================
+        // v = (log Σ min(1, e^Δ), steps) of every subtree, merged where the tree merges (trees.jl:249,294) and unwound where a subtree
+        // is invalid (trees.jl:244,249-250): it depends on the leaves' Δ and on WHICH merges happen — the records' π and B1's codes —
+        // and on nothing else; the acceptance rate of the transition is its only consumer.
+        LaneArrF64 lv_vlsa;
+        LaneArrI64 lv_vsteps;
+        for (int64_t n = 0; n < P.N; ++n) {
+            const unsigned want = (unsigned)n + 1u;
+            if (!wait_for([&](const PairCtl& c) { return (c.w[W_SEQ_A] == want && c.w[W_HEAD] >= 1u) || c.w[W_QUIT] != 0u; })) return;
+            if (cw.w[W_QUIT] != 0u) return;
+            const double pi0 = uni_f64(ring_s[1]);
+            unsigned tail = 1u;
+            pair_publish(c_tail3, tail, lane);
+            pair_publish(c_tail3_seq, want, lane);
+            double vtop_lsa = -dm_inf();
+            int64_t vtop_steps = 0;
+            int depth = 0;
+            bool finished = false;
+            unsigned avail = 1u;
+            while (!finished && depth < max_depth) {
+                const uint32_t nleaf = 1u << depth;
+                bool invalid = false;
+                for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
+                    if (!(avail > tail)) {
+                        if (!wait_for([&](const PairCtl& c) { return c.w[W_HEAD] > tail && c.w[W_MSEQ] == want && c.w[W_MHEAD] > tail; })) return;
+                        avail = cw.w[W_HEAD] < cw.w[W_MHEAD] ? cw.w[W_HEAD] : cw.w[W_MHEAD];
+                    }
+                    const unsigned slot = tail % (unsigned)PAIR_RING;
+                    const double pi_leaf = uni_f64(ring_s[slot * 4 + 1]);
+                    const int code = uni_i32((int)__double_as_longlong(mres[slot]));
+                    tail += 1u;
+                    if ((tail & 3u) == 0u) pair_publish(c_tail3, tail, lane);
+                    const double delta = pi_leaf - pi0;             // NUTS.jl:150
+                    double v_lsa = delta < 0.0 ? delta : 0.0;       // min(Δ, 0)   (NUTS.jl:79)
+                    int64_t v_steps = 1;
+                    int level = 0;
+                    if (delta < P.min_delta) {
+                        invalid = true;
+                    } else {
+                        for (;;) {
+                            const bool sub = ((j >> level) & 1u) != 0;
+                            const bool top = !sub && (j == nleaf - 1) && (level == depth);
+                            if (!sub && !top) break;
+                            if (sub) {
+                                v_lsa = uni_f64(det_logaddexp_u(lv_vlsa.get(level), v_lsa));      // v = v₋ ⊕ v₊ (trees.jl:249)
+                                v_steps += lv_vsteps.get(level);
+                                if (code == level) { invalid = true; level += 1; break; }          // turning (trees.jl:255)
+                                level += 1;
+                            } else {
+                                vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa));             // trees.jl:294
+                                vtop_steps += v_steps;
+                                depth += 1;
+                                if (code == PIPE_TOP) finished = true;
+                                level = -1;
+                                break;
+                            }
+                        }
+                        if (level >= 0 && !invalid) {
+                            lv_vlsa.set(level, v_lsa, lane);
+                            lv_vsteps.set(level, v_steps, lane);
+                        }
+                    }
+                    if (invalid) {
+                        for (int l2 = level; l2 < depth; ++l2) {
+                            if ((j >> l2) & 1u) {
+                                v_lsa = uni_f64(det_logaddexp_u(lv_vlsa.get(l2), v_lsa));
+                                v_steps += lv_vsteps.get(l2);
+                            }
+                        }
+                        vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa)); // trees.jl:294
+                        vtop_steps += v_steps;
+                        finished = true;                                       // trees.jl:297
+                    }
+                }
+            }
+            if (lane == 0) { mb_s[2] = vtop_lsa; mb_s[3] = __longlong_as_double((long long)vtop_steps); }
+            pair_publish(c_aseq, want, lane);
+        }
+        PIPE_PT_FLUSH(3, 0)
+        return;
+    }
+
     // ================================================== B2: the scalar builder ==================================================
     double* const ws = P.st.ws + (size_t)chain * P.nvec * Dpad;
     auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
     const int nslots = ws_nslots(max_depth);
-    LaneArrF64 lv_omega, lv_vlsa;
-    LaneArrI64 lv_vsteps;
+    LaneArrF64 lv_omega;
     LaneArrI32 lv_zeta;
     LaneArrF64 sl_lq, sl_pi;
     double q[1], g[1];
@@ -427,8 +528,6 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
         free_mask = ((nslots >= 64) ? ~0ull : ((1ull << nslots) - 1ull)) & ~(1ull << init_slot);
         int zeta_top = init_slot;
         double omega_top = 0.0;
-        double vtop_lsa = -dm_inf();
-        int64_t vtop_steps = 0;
         int depth = 0;
         int64_t i_minus = 0, i_plus = 0;
         int64_t term_left = 1, term_right = 0;  // REACHED_MAX_DEPTH
@@ -441,8 +540,6 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
             const int64_t di = fwd ? 1 : -1;
             const uint32_t nleaf = 1u << depth;
             bool invalid = false;
-            double v_lsa = 0.0;
-            int64_t v_steps = 0;
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 // the leaf's record (A) and its merge code (B1)
                 if (!(avail > tail)) {                          // records WITH their codes available at the last poll
@@ -460,8 +557,6 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
                 if (!(flags & 1u)) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
                 const double delta = pi_leaf - pi0;             // NUTS.jl:150
-                v_lsa = delta < 0.0 ? delta : 0.0;              // min(Δ, 0)   (NUTS.jl:79)
-                v_steps = 1;
                 int level = 0;
                 if (delta < P.min_delta) {                      // divergent leaf (NUTS.jl:151; trees.jl:236-237)
                     term_left = term_right = i;
@@ -475,17 +570,14 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
                         if (!sub && !top) break;
                         if (sub) {
                             const bool turning = code == level;
-                            const double wl = lv_omega.get(level);
-                            double w;
-                            logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
-                            v_steps += lv_vsteps.get(level);
-                            if (turning) {                       // trees.jl:255
+                            if (turning) {                       // trees.jl:255 (before any proposal mixing)
                                 term_left = i - di * (((int64_t)2 << level) - 1);
                                 term_right = i;
                                 invalid = true;
                                 level += 1;
                                 break;
                             }
+                            const double w = uni_f64(det_logaddexp_u(lv_omega.get(level), c_omega));   // ω = logaddexp(ω₋, ω₊) (trees.jl:145)
                             const double logprob2 = c_omega - w;
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
                             const int lz = lv_zeta.get(level);
@@ -499,9 +591,7 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
                             level += 1;
                         } else {
                             const bool turning = code == PIPE_TOP;
-                            double w;
-                            logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
-                            vtop_steps += v_steps;
+                            const double w = uni_f64(det_logaddexp_u(omega_top, c_omega));
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
                             const bool pick = logprob2 >= 0.0 || (randexp() > -logprob2);
                             if (pick) {
@@ -526,25 +616,17 @@ __global__ __launch_bounds__(192) void nuts_run_pipeline_kernel(RunParams P) {
                     if (level >= 0 && !invalid) {
                         if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
                         lv_omega.set(level, c_omega, lane);
-                        lv_vlsa.set(level, v_lsa, lane);
-                        lv_vsteps.set(level, v_steps, lane);
                         lv_zeta.set(level, c_zeta, lane);
                     }
                 }
-                if (invalid) {
-                    for (int l2 = level; l2 < depth; ++l2) {
-                        if ((j >> l2) & 1u) {
-                            v_lsa = uni_f64(det_logaddexp_u(lv_vlsa.get(l2), v_lsa));
-                            v_steps += lv_vsteps.get(l2);
-                        }
-                    }
-                    vtop_lsa = uni_f64(det_logaddexp_u(vtop_lsa, v_lsa)); // trees.jl:294
-                    vtop_steps += v_steps;
-                    finished = true;                                       // trees.jl:297
-                }
+                if (invalid) finished = true;                              // trees.jl:297 (the visited statistic's unwinding: B3)
             }
         }
         if (broken) break;
+        // the visited statistic of the transition (B3)
+        if (!wait_for([&](const PairCtl& c) { return c.w[W_ASEQ] == want; })) break;
+        const double vtop_lsa = uni_f64(mb_s[2]);
+        const int64_t vtop_steps = (int64_t)uni_i64v(__double_as_longlong(mb_s[3]));
 
         const double acc_rate = [&]() {
             double a = det_exp_u(vtop_lsa) / (double)vtop_steps;           // NUTS.jl:87
@@ -605,7 +687,7 @@ int launch_run_pipeline(const RunParams& P, hipStream_t s) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
         if (P.Dpad != WAVE) return DHMC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T>), dim3(P.C), dim3(3 * WAVE), pipeline_lds_bytes(), s, P);
+        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T>), dim3(P.C), dim3(4 * WAVE), pipeline_lds_bytes(), s, P);
         return DHMC_OK;
     }
 }

@@ -1,5 +1,5 @@
-"""GPU: the pipeline kernel (csrc/nuts_pipeline_kernel.hpp: a short chain as three wavefronts — integrator, turn-statistic builder,
-scalar builder — joined by a ring of leaf records in LDS) against the oracle and the wave-per-chain kernel, bit for bit: every family it serves, dimensions
+"""GPU: the pipeline kernel (csrc/nuts_pipeline_kernel.hpp: a short chain as four wavefronts — integrator, turn-statistic builder,
+visited-statistic builder, proposal builder — joined by a ring of leaf records in LDS) against the oracle and the wave-per-chain kernel, bit for bit: every family it serves, dimensions
 1 … 64, divergences / depth limits / −Inf densities (the integrator runs ahead of trees that end early), metric windows, launch
 order, host outputs in chunks, resumed calls, and the engine choice of dhmc_run after a launch that a few chains held open."""
 import os

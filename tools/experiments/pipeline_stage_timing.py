@@ -23,6 +23,6 @@ ph = np.zeros(16, np.uint64)
 lib.dhmc_debug_phase(ph.ctypes.data, 0)
 leaves = float(ph[14]); pipes = int(ph[15])
 print(f"chains {C} transitions {T} kernel_ms {ms:.3f} leapfrogs {lf} -> {lf / ms * 1e3:.4g} /s; pipelines {pipes}")
-for r, name in enumerate(("A  integrator", "B1 turn statistics", "B2 scalars")):
+for r, name in enumerate(("A  integrator", "B1 turn statistics", "B2 proposals", "B3 visited statistic")):
     tot, wait = float(ph[4 + r]), float(ph[r])
     print(f"  {name:20s} {tot / max(leaves, 1):8.0f} clocks per leaf, of which waiting {wait / max(leaves, 1):8.0f} ({100 * wait / max(tot, 1):5.1f} %)  -> busy {(tot - wait) / max(leaves, 1):8.0f}")

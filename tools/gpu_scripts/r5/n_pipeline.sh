@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: the pair kernel (integrator ‖ tree builder) — parity, then config 4 timing: wave vs pair
-O=gpurun_out/r5q; mkdir -p $O
+O=gpurun_out/r5r; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_packed.py -x -q 2>&1 | tail -12 > $O/pair.log; cat $O/pair.log
 for v in "pipeline DHMC_PIPELINE=1" "wave DHMC_PIPELINE=0"; do
   set -- $v
