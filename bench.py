@@ -323,7 +323,7 @@ def bench_config45(args, pkg, torch):
         else:
             ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                    "kernel": "nuts_run_packed_kernel / nuts_run_kernel<FunnelT,1> (chosen per launch from the previous launch's work: dhmc_run)",
+                    "kernel": "nuts_run_pipeline_kernel<FunnelT> / nuts_run_packed_kernel / nuts_run_kernel<FunnelT,1> (chosen per launch from the previous launch's work: dhmc_run)",
                     "note": "48·D algorithmic bytes per leapfrog; a 30-dim chain is latency-, not bandwidth-bound: the call ends with its slowest "
                             "chain, whose leapfrogs are sequential (slowest_chain_leapfrogs × the kernel's latency per leapfrog ≈ the call's time)"}
         return {"value": lf / dt, "ms_per_step": 1e3 * dt / K, "steps": K, "transitions_per_step": T,
