@@ -92,6 +92,13 @@ struct dhmc_ctx {
     int pipeline = 0;                      // the context's chains can run as four-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
                                            // previous launch showed to be held open by a few chains; DHMC_PIPELINE=0: never, =1: always
     int pipeline_force = 0;
+    // many chains with a heavy-tailed tree size (all 32768 funnel chains on one GPU): the call runs in segments, and in every segment
+    // the chains that did the most work in the segment before go through the pipeline kernel while the others run packed (dhmc_run)
+    int hybrid = 1;                        // DHMC_HYBRID=0: off
+    int hybrid_segments = 8;               // DHMC_HYBRID_SEGMENTS
+    int pk_queue = 1;                      // DHMC_PK_QUEUE=0: a packed launch starts a lane group per place (no queue of places)
+    int pk_max_waves = 0;                  // DHMC_PK_MAX_WAVES: the waves a queued packed launch starts (0: one per SIMD)
+    int tail_count = 0;                    // places at the head of the launch order whose work was far above the median's
     int pk_align = 4;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two)
     int pk_cpl = 0;                        // DHMC_PK_CPL: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
     int pk_lds_levels = -1;                // DHMC_PK_LDS_LEVELS: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)

@@ -259,6 +259,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
               (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL ||
                cfg->target == DHMC_TARGET_FUNNEL || cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_ALWAYS_DIVERGENT);
     if (const char* e = std::getenv("DHMC_PIPELINE")) { c->pipeline = c->pipeline && std::atoi(e) != 0; c->pipeline_force = c->pipeline; }
+    if (const char* e = std::getenv("DHMC_PK_QUEUE")) c->pk_queue = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_PK_MAX_WAVES")) c->pk_max_waves = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("DHMC_HYBRID")) c->hybrid = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DHMC_HYBRID_SEGMENTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->hybrid_segments = v; }
     if (const char* e = std::getenv("DHMC_PK_ALIGN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->pk_align = v; }
     if (const char* e = std::getenv("DHMC_PK_LDS_LEVELS")) c->pk_lds_levels = std::atoi(e);
     if (const char* e = std::getenv("DHMC_PK_CPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) c->pk_cpl = v; }
@@ -280,7 +284,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if ((rc = dev_alloc(c, &c->st.transition, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.status, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.ws, C * (size_t)c->nvec * Dp))) return fail(rc);
-    if ((rc = dev_alloc(c, &c->d_counter, 1))) return fail(rc);
+    if ((rc = dev_alloc(c, &c->d_counter, 2))) return fail(rc);      // [0] leapfrog steps of a call; [1] a packed launch's queue of places
     if ((rc = dev_alloc(c, &c->d_chain_work, (size_t)cfg->chains))) return fail(rc);
     if ((rc = dev_alloc(c, &c->d_launch_order, (size_t)cfg->chains))) return fail(rc);
     if (hipMemset(c->st.q, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -811,7 +815,18 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || c->tail_bound || few_chains);
     const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
-    if (packed) {
+    // HYBRID: more chains than the pipeline kernel can hold resident (it takes a CU's four SIMDs and ≈ 28 KB of LDS per chain) and a
+    // heavy-tailed tree size.  All chains in the pipeline kernel wait in line (32768 funnel chains × 1000 transitions: 2.9 s); all in
+    // the wave-per-chain kernel: 2.4 s of which the slowest chain alone is 1.25 s; packed: its trips are the longest.  So the call
+    // runs in segments of N / hybrid_segments transitions, and in every segment the chains that did the most work in the segment
+    // before (> 3 × the median, at most as many as stay resident) go through the pipeline kernel on a second stream while all
+    // others run packed: the bulk at the packed kernel's throughput, the deep chains at the pipeline's latency.  A chain's stay in
+    // the funnel's neck lasts hundreds of transitions, so the previous segment predicts it (the previous CALL — a 50-transition
+    // warmup stage — did not: profiles/r05_packed_engine.txt).  Chains are independent: which kernel runs which segment of a chain
+    // changes none of its bits.
+    const bool hybrid = per_draw_kernel && c->hybrid && c->packed && c->pipeline && !c->packed_force && !c->pipeline_force &&
+                        C > 32 * c->num_cus && N >= 8LL * c->hybrid_segments && c->d_chain_work && c->launch_order_on;
+    if (packed || hybrid) {
         // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
         // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)
         // coordinates per lane: two while that still leaves every wave a SIMD of its own (or when the row needs no more: D <= 32 is
@@ -835,6 +850,9 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         P.pk_cpl = cpl;
         P.pk_lds_levels = levels;
         P.pk_align = c->pk_align;
+        // the queue of places (packed_kernels.hpp launch_run_packed): as many waves as the GPU holds at once — one per SIMD
+        P.pk_queue = c->pk_queue ? reinterpret_cast<unsigned*>(c->d_counter + 1) : nullptr;
+        P.pk_max_waves = c->pk_max_waves > 0 ? c->pk_max_waves : 4 * c->num_cus;
     }
     if (c->win_n >= 0) {       // an open metric window: every transition's draw joins the running moments (capi_metric.hip)
         P.win_mean = c->d_win; P.win_m2 = c->d_win + (size_t)C * c->Dpad; P.win_n0 = c->win_n;
@@ -914,6 +932,46 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         return hipSuccess;
     };
     double chunk_ms = 0.0;
+    bool hybrid_ran = false;
+    // The per-draw kernels walk all transitions of a chain in one wave (group, pipeline), so a launch ends with its slowest chain: a
+    // chain whose trees are persistently deeper (a smaller adapted ϵ) and which starts in the last wave of workgroups holds the whole
+    // launch open — measured on BASELINE configs[1]: one chain of 4096 at 1.48 × the mean work, 189 ms instead of 171 ms per 1000
+    // transitions.  The next launch therefore starts its chains in the order of this one's work, longest first (results do not
+    // depend on the order); and the shape of the work decides the next launch's engine (tail_bound, tail_count: above).
+    auto refresh_order = [&](int64_t n_launch) -> hipError_t {
+        c->h_chain_work.resize(C);
+        hipError_t he = hipMemcpyAsync(c->h_chain_work.data(), c->d_chain_work, sizeof(unsigned) * C, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) return he;
+        unsigned long long sum = 0;
+        unsigned mx = 0;
+        for (unsigned w : c->h_chain_work) { sum += w; mx = std::max(mx, w); }
+        c->launch_order_valid = false;
+        c->tail_count = 0;
+        if ((double)mx * C > 1.03 * (double)sum) {
+            c->h_launch_order.resize(C);
+            for (int i = 0; i < C; ++i) c->h_launch_order[i] = i;
+            std::stable_sort(c->h_launch_order.begin(), c->h_launch_order.end(),
+                             [&](int a, int b) { return c->h_chain_work[a] > c->h_chain_work[b]; });
+            he = hipMemcpyAsync(c->d_launch_order, c->h_launch_order.data(), sizeof(int) * C, hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            c->launch_order_valid = he == hipSuccess;
+            if (c->launch_order_valid) {      // the head of the order whose work was more than 3 × the median's, at most what the pipeline kernel keeps resident
+                std::vector<unsigned> w(c->h_chain_work);
+                std::nth_element(w.begin(), w.begin() + C / 2, w.end());
+                const double med = (double)w[C / 2];
+                const int cap = std::min(C / 8, 5 * c->num_cus);
+                int k = 0;
+                while (k < cap && (double)c->h_chain_work[c->h_launch_order[k]] > 3.0 * med) ++k;
+                c->tail_count = k;
+            }
+        }
+        c->tail_bound = (double)mx * C > 3.0 * (double)sum;
+        if (std::getenv("DHMC_DEBUG_ORDER"))
+            std::fprintf(stderr, "[dhmc] launch order: N=%lld max=%u mean=%.1f valid=%d first=%d tail_bound=%d tail_count=%d\n", (long long)n_launch, mx,
+                         (double)sum / C, (int)c->launch_order_valid, c->launch_order_valid ? c->h_launch_order[0] : -1, (int)c->tail_bound, c->tail_count);
+        return he;
+    };
 
     hipError_t e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
@@ -1193,6 +1251,50 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 chunk_ms += ms;
             }
         if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+    } else if (e == hipSuccess && hybrid && nbuf == 1) {
+        hybrid_ran = true;
+        if (!c->stream2) {
+            e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+            if (e == hipSuccess && !c->ev_fork) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess && !c->ev_join) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        }
+        const int S = c->hybrid_segments;
+        const int64_t seg = (N + S - 1) / S;
+        const int64_t stride = P.out_stride ? P.out_stride : N;
+        for (int64_t n0 = 0; n0 < N && e == hipSuccess; n0 += seg) {
+            const int64_t len = std::min(seg, N - n0);
+            RunParams Q = P;
+            Q.N = len;
+            Q.out_stride = stride;
+            Q.win_n0 = P.win_n0 + n0;
+            if (da) { Q.da_init = n0 == 0 ? da->init : 0; Q.da_finalize = n0 + len >= N ? da->finalize : 0; }
+            if (Q.out.draws) Q.out.draws += (size_t)n0 * D;
+            if (Q.out.logdensities) Q.out.logdensities += n0;
+            if (Q.out.eps) Q.out.eps += n0;
+            if (Q.out.pi) Q.out.pi += n0;
+            if (Q.out.acceptance_rate) Q.out.acceptance_rate += n0;
+            if (Q.out.steps) Q.out.steps += n0;
+            if (Q.out.term_left) Q.out.term_left += n0;
+            if (Q.out.term_right) Q.out.term_right += n0;
+            if (Q.out.depth) Q.out.depth += n0;
+            if (Q.out.directions) Q.out.directions += n0;
+            Q.launch_order = c->launch_order_valid ? c->d_launch_order : nullptr;
+            const int K = Q.launch_order ? std::min(c->tail_count, C) : 0;
+            if (K > 0) {                       // the head of the order through the pipeline kernel, beside the packed launch of the rest
+                e = hipEventRecord(c->ev_fork, c->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+                RunParams T = Q;
+                T.C = K;                       // workgroup b < K takes launch_order[b]
+                if (e == hipSuccess && (rc = dispatch(c, Op::RunPipeline, &T, c->stream2, true))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
+                if (e == hipSuccess) e = hipEventRecord(c->ev_join, c->stream2);
+            }
+            RunParams B = Q;
+            B.pk_order_base = K;
+            if (e == hipSuccess && K < C && (rc = dispatch(c, Op::RunPacked, &B))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
+            if (e == hipSuccess && K > 0) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = refresh_order(len);       // (drains the stream: the next segment's partition needs this one's work)
+        }
     } else if (e == hipSuccess) {
         rc = dispatch(c, run_op, &P);
         if (rc) { cleanup(); return rc; }
@@ -1201,35 +1303,9 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
     if (e == hipSuccess && nbuf == 1 && !staged.empty()) e = d2h(0, 0, N, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-    const bool reorder = P.chain_work && N >= 32;     // (a short call's counts say little about the chains, and sorting is not free)
-    if (e == hipSuccess && reorder) {
-        c->h_chain_work.resize(C);
-        e = hipMemcpyAsync(c->h_chain_work.data(), c->d_chain_work, sizeof(unsigned) * C, hipMemcpyDeviceToHost, c->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && reorder) {
-        // One wave walks a chain's N transitions, so the launch ends with its slowest chain: a chain whose trees are persistently
-        // deeper (a smaller adapted ϵ) and which starts in the last wave of workgroups holds the whole launch open — measured on
-        // BASELINE configs[1]: one chain of 4096 at 1.48 × the mean work, 189 ms instead of 171 ms per 1000 transitions.  The next
-        // launch therefore starts its chains in the order of this one's work, longest first (results do not depend on the order).
-        unsigned long long sum = 0;
-        unsigned mx = 0;
-        for (unsigned w : c->h_chain_work) { sum += w; mx = std::max(mx, w); }
-        c->launch_order_valid = false;
-        if ((double)mx * C > 1.03 * (double)sum) {
-            c->h_launch_order.resize(C);
-            for (int i = 0; i < C; ++i) c->h_launch_order[i] = i;
-            std::stable_sort(c->h_launch_order.begin(), c->h_launch_order.end(),
-                             [&](int a, int b) { return c->h_chain_work[a] > c->h_chain_work[b]; });
-            e = hipMemcpyAsync(c->d_launch_order, c->h_launch_order.data(), sizeof(int) * C, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            c->launch_order_valid = e == hipSuccess;
-        }
-        c->tail_bound = (double)mx * C > 3.0 * (double)sum;       // (the packed engine's choice, above)
-        if (std::getenv("DHMC_DEBUG_ORDER"))
-            std::fprintf(stderr, "[dhmc] launch order: N=%lld max=%u mean=%.1f valid=%d first=%d used_this_call=%d tail_bound=%d\n", (long long)N, mx, (double)sum / C,
-                         (int)c->launch_order_valid, c->launch_order_valid ? c->h_launch_order[0] : -1, P.launch_order != nullptr, (int)c->tail_bound);
-    }
+    const bool reorder = P.chain_work && N >= 32 && !hybrid_ran;     // (a short call's counts say little about the chains, and sorting is not free)
+    if (e == hipSuccess && reorder) e = refresh_order(N);
+    else if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) {
         float ms = 0.f;
         e = hipEventElapsedTime(&ms, c->ev0, c->ev1);

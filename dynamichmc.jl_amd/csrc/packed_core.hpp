@@ -29,9 +29,11 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #define PK_FN __device__ __forceinline__
 #define PK_UNROLL _Pragma("unroll")
+#define PK_LAMBDA_INLINE __attribute__((always_inline))   // a lambda of the body called from two places: its captures must stay in registers
 #else
 #define PK_FN inline
 #define PK_UNROLL
+#define PK_LAMBDA_INLINE
 #endif
 
 namespace dhmc {

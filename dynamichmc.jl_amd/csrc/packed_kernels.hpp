@@ -50,6 +50,7 @@ struct PackedGroup {
         sum_n<1>(v);
         return v[0];
     }
+    static __device__ __forceinline__ int first_i(int x) { return __shfl(x, (int)(threadIdx.x & 63u & ~(unsigned)(L - 1))); }
     static __device__ __forceinline__ double first(double x) {
         if constexpr (L == 1) return x;
         else if constexpr (L == 2) return dpp_f64<0xA0>(x);                   // quad_perm [0,0,2,2]
@@ -106,8 +107,7 @@ __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
     constexpr int GPW = 64 / L;
     const int sub = (int)(threadIdx.x & (L - 1));
     const int grp = (int)(threadIdx.x / L);
-    const int place = (int)blockIdx.x * GPW + grp;
-    const int chain = place < P.C ? (P.launch_order ? P.launch_order[place] : place) : P.C;
+    const int place = P.pk_order_base + (int)blockIdx.x * GPW + grp;
     extern __shared__ double pk_lds[];
     double* const lds_cold = pk_lds;
     double* const lds_rows = pk_lds + (size_t)6 * 64 * CPL;
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
     typedef PackedGroup<L> Grp;
     typedef dm_vector Pol;
 #define PK_ATOMIC_ADD_ULL(ptr, v) atomicAdd((ptr), (v))
+#define PK_QUEUE_NEXT(ptr) atomicAdd((ptr), 1u)
 #include "packed_body.inc"
+#undef PK_QUEUE_NEXT
 #undef PK_ATOMIC_ADD_ULL
 }
 
@@ -129,7 +131,19 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
         const int L = pk::lanes_per_chain(P.D, cpl);
         if (L == 0 || (cpl != 2 && cpl != 4)) return DHMC_ERR_UNSUPPORTED;
         const int gpw = 64 / L;
-        const dim3 grid((unsigned)((P.C + gpw - 1) / gpw)), block(64);
+        // More places than the lane groups of pk_max_waves waves: that many waves start (the GPU holds them all at once) and the
+        // rest of the launch order waits in the queue — a group takes the next place when its chain is done, so that the lanes of
+        // chains with little work do not idle behind the longest chain of their wave.
+        const int places = P.C - P.pk_order_base;
+        int waves = (places + gpw - 1) / gpw;
+        RunParams Q = P;
+        if (Q.pk_queue && Q.pk_max_waves > 0 && waves > Q.pk_max_waves) {
+            waves = Q.pk_max_waves;
+            if (hipMemsetD32Async((hipDeviceptr_t)Q.pk_queue, P.pk_order_base + waves * gpw, 1, s) != hipSuccess) return DHMC_ERR_HIP;
+        } else {
+            Q.pk_queue = nullptr;
+        }
+        const dim3 grid((unsigned)waves), block(64);
         const size_t lds = pk::lds_bytes_per_wave(L, cpl, P.max_depth, P.pk_lds_levels);
 #define DHMC_PK_LAUNCH(LL, CC)                                                                                                 \
     if (L == LL && cpl == CC) {                                                                                                \
@@ -138,7 +152,7 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
             return true;                                                                                                       \
         }();                                                                                                                   \
         (void)once;                                                                                                            \
-        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL, CC>), grid, block, lds, s, P);                                     \
+        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL, CC>), grid, block, lds, s, Q);                                     \
         return DHMC_OK;                                                                                                        \
     }
         DHMC_PK_LAUNCH(1, 2) DHMC_PK_LAUNCH(2, 2) DHMC_PK_LAUNCH(4, 2) DHMC_PK_LAUNCH(8, 2) DHMC_PK_LAUNCH(16, 2)

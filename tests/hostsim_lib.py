@@ -37,7 +37,9 @@ class RunParams(C.Structure):      # csrc/run_params.hpp, field for field
                 ("st", ChainArrays), ("adapt", C.c_int), ("da_init", C.c_int), ("da_finalize", C.c_int), ("t0", C.c_int),
                 ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("out", DeviceOutputs), ("tp", TargetParams),
                 ("leapfrog_counter", P), ("win_mean", P), ("win_m2", P), ("win_n0", C.c_int64), ("chain_work", P), ("launch_order", P),
-                ("pk_lds_levels", C.c_int), ("pk_align", C.c_int), ("pk_cpl", C.c_int), ("pk_pad_", C.c_int)]
+                ("pk_lds_levels", C.c_int), ("pk_align", C.c_int), ("pk_cpl", C.c_int), ("pk_order_base", C.c_int),
+                ("pk_queue", C.c_void_p), ("pk_max_waves", C.c_int),
+                ("prog", P), ("pk_budget", C.c_uint64), ("pk_evicted", P), ("pk_evict_count", P)]
 
 
 DA_DTYPE = np.dtype([("mu", "f8"), ("Hbar", "f8"), ("logeps", "f8"), ("logeps_bar", "f8"), ("m", "i8")])
@@ -107,12 +109,13 @@ class HostSim:
         self.set_metric(var)
         self.win, self.win_n = None, -1
 
-    def run(self, N, da=None):
-        out = {k: np.zeros((self.C, N, self.D) if k == "draws" else (self.C, N), t) for k, t in self.OUT}
+    def _launch(self, out, N, N_total, da, queue, order, prog=None, budget=0, evicted=None, evict_count=None, chain_work=None,
+                leap_total=None):
+        """One launch of the simulated kernel: the places of `order` (default: every chain) up to transition N of the call."""
         R = RunParams()
-        R.D, R.Dpad, R.C, R.chain_offset, R.max_depth = self.D, 64, self.C, self.chain_offset, self.max_depth
+        R.D, R.Dpad, R.chain_offset, R.max_depth = self.D, 64, self.chain_offset, self.max_depth
         R.nvec = lib().hostsim_ws_nvec(self.max_depth)
-        R.min_delta, R.seed, R.N, R.out_stride = self.min_delta, self.seed, N, 0
+        R.min_delta, R.seed, R.N, R.out_stride = self.min_delta, self.seed, N, N_total
         for k, a in (("q", self.q), ("g", self.g), ("lq", self.lq), ("minv", self.minv), ("W", self.W), ("eps", self.eps), ("da", self.da),
                      ("transition", self.transition), ("status", self.status)):
             setattr(R.st, k, _p(a))
@@ -124,13 +127,61 @@ class HostSim:
         for k, _ in self.OUT:
             setattr(R.out, k, _p(out[k]))
         R.tp.a, R.tp.b, R.tp.Dpad = _p(self.params[0]), _p(self.params[1]), 64
-        self.leapfrogs[:] = 0
         R.leapfrog_counter = _p(self.leapfrogs)
         if self.win is not None:
             R.win_mean, R.win_m2, R.win_n0 = _p(self.win[0]), _p(self.win[1]), self.win_n
         R.pk_lds_levels, R.pk_align = self.lds_levels, self.align
-        rc = lib().hostsim_packed_run(self.target, C.byref(R))
+        R.C = self.C
+        if order is not None:
+            order = np.ascontiguousarray(order, np.int32)
+            R.launch_order = _p(order)
+            R.C = len(order)                 # the launch's places
+        if prog is not None:
+            R.prog, R.pk_budget = _p(prog), budget
+            R.pk_evicted, R.pk_evict_count, R.chain_work = _p(evicted), _p(evict_count), _p(chain_work)
+        rc = lib().hostsim_packed_run(self.target, C.byref(R), int(queue), self.C)
         assert rc == 0, rc
+
+    def _outputs(self, N):
+        return {k: np.zeros((self.C, N, self.D) if k == "draws" else (self.C, N), t) for k, t in self.OUT}
+
+    def run(self, N, da=None, queue=False, order=None):
+        """One launch of N transitions per chain.  queue: through the kernel's queue of places (one lane group walks every chain);
+        order: the launch order (a permutation of the chains)."""
+        out = self._outputs(N)
+        self.leapfrogs[:] = 0
+        self._launch(out, N, 0, da, queue, order)
         if self.win is not None:
             self.win_n += N
         return out
+
+    def run_rounds(self, N, da=None, rounds=4, budget=50, queue=True):
+        """The call as dhmc_run's hybrid makes it: rounds with rising targets; a chain that takes more than `budget` leapfrog steps
+        in a launch is given up at a transition boundary and continues in a later launch (here: without a budget — the device hands
+        it to the pipeline kernel).  Returns the outputs and the number of chains that were given up."""
+        out = self._outputs(N)
+        self.leapfrogs[:] = 0
+        prog = np.zeros(self.C, np.int32)
+        work = np.zeros(self.C, np.uint32)
+        evicted, count = np.zeros(self.C, np.int32), np.zeros(1, np.uint32)
+        seg = (N + rounds - 1) // rounds
+        given_up = 0
+        behind = np.zeros(0, np.int32)
+        for T in list(range(seg, N, seg)) + [N]:
+            d = None if da is None else dict(da, finalize=(da.get("finalize", 1) if T == N else 0))
+            if len(behind):               # the chains the round before gave up: no budget
+                self._launch(out, T, N, d, queue, behind, prog, 0, evicted, count, work)
+            rest = np.setdiff1d(np.arange(self.C, dtype=np.int32), behind)[::-1].copy()
+            count[:] = 0
+            if len(rest):
+                self._launch(out, T, N, d, queue, rest, prog, budget, evicted, count, work)
+            behind = np.sort(evicted[:int(count[0])]).astype(np.int32)
+            assert (prog[behind] < T).all() and (np.delete(prog, behind) == T).all()
+            given_up += len(behind)
+        if len(behind):
+            self._launch(out, N, N, da, queue, behind, prog, 0, evicted, count, work)
+        assert (prog == N).all()
+        assert int(work.sum()) == int(self.leapfrogs[0]) == int(out["steps"].sum())
+        if self.win is not None:
+            self.win_n += N
+        return out, given_up

@@ -185,3 +185,24 @@ def test_chain_offset_is_the_rng_key(pkg):
     a, b = whole.run(25, da={}), part.run(25, da={})
     for k in a:
         assert np.array_equal(a[k][40:], b[k]), k
+
+
+@pytest.mark.parametrize("cpl", [2, 4])
+@pytest.mark.parametrize("D,C,waves", [(30, 41, 1), (7, 300, 2), (2, 500, 3), (64, 23, 4)])
+def test_queue_of_places_matches_oracle(pkg, D, C, cpl, waves):
+    """A launch of fewer waves than the chains need (DHMC_PK_MAX_WAVES): the groups take chain after chain from the launch's queue of
+    places — every chain the bits of its own launch, in any launch order (the second and later calls run in the order of the
+    previous call's work)."""
+    with _env(DHMC_PK_CPL=cpl, DHMC_PK_MAX_WAVES=waves, DHMC_PK_QUEUE=1):
+        dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=300 + D)
+    ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=300 + D, threads=8)
+    rng = np.random.default_rng(D)
+    q0 = rng.normal(size=(C, D)) * 0.3
+    q0[:, 0] = np.linspace(-4.0, 2.0, C)          # trees of very different sizes
+    for e in (dev, ora):
+        e.init(q0); e.set_stepsize(0.3)
+    for i, (N, da) in enumerate([(40, dict()), (40, None), (33, dict(init=0, finalize=1))]):
+        _same(dev.run(N, da=da), ora.run(N, da=da), f"queue D={D} C={C} stage {i}")
+    assert np.array_equal(dev.status(), ora.status())
+    for x, y in zip(dev.position(), ora.position()):
+        assert np.array_equal(x, y)

@@ -152,3 +152,41 @@ def test_engine_choice_after_a_tail_bound_launch(pkg):
         _same(a, b, "engine choice")
     work = res[0][1]["steps"].sum(axis=1)
     assert work.max() > 3 * work.mean()
+
+
+def test_hybrid_segments_change_no_result(pkg):
+    """More chains than the pipeline kernel keeps resident (> 32 per CU): dhmc_run runs the call in segments, the deepest chains of
+    the segment before through the pipeline kernel beside the packed launch of the others.  With DHMC_HYBRID=0 (one launch of one
+    kernel) the same bits; 24 chains against the oracle; metric windows and dual averaging across the segments."""
+    D, C = 30, 8448
+    for k in ("DHMC_PIPELINE", "DHMC_PACKED"):
+        os.environ.pop(k, None)
+    res = []
+    for env in (dict(DHMC_HYBRID="1", DHMC_HYBRID_SEGMENTS="4"), dict(DHMC_HYBRID="0")):
+        os.environ.update(env)
+        try:
+            dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=13)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        dev.init(); dev.find_initial_stepsize()
+        f = ["logdensities", "eps", "pi", "acceptance_rate", "steps", "term_left", "term_right", "depth", "directions"]
+        out = [dev.run(40, da={}, fields=f)]
+        dev.metric_window_begin()
+        out.append(dev.run(48, da={}, fields=f))
+        dev.update_metric_diag_window()
+        out.append(dev.run(64, fields=f + ["draws"]))
+        res.append((out, dev.metric_diag(), dev.stepsize(), dev.position()))
+    for a, b in zip(res[0][0], res[1][0]):
+        _same(a, b, "hybrid vs one launch")
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    for x, y in zip(res[0][3], res[1][3]):
+        assert np.array_equal(x, y)
+    ora = ol.Oracle(D, 24, target=ol.TARGET_FUNNEL, seed=13, threads=8)
+    ora.init(); ora.find_initial_stepsize()
+    b0 = ora.run(40, da={})
+    ora.metric_window_begin(); b1 = ora.run(48, da={}); ora.update_metric_diag_window()
+    b2 = ora.run(64)
+    for a, b in zip(res[0][0], (b0, b1, b2)):
+        for k in a:
+            assert np.array_equal(a[k][:24], b[k]), k

@@ -89,3 +89,40 @@ def test_always_divergent_matches_oracle():
     a, b = sim.run(6), ora.run(6)
     _same(a, b, "always divergent")
     assert (a["depth"] == 0).all() and (a["steps"] == 1).all() and (a["acceptance_rate"] == 0).all()
+
+
+@pytest.mark.parametrize("target,D", [(ol.TARGET_FUNNEL, 30), (ol.TARGET_STD_NORMAL, 7)])
+def test_queue_of_places_changes_no_result(target, D):
+    # a lane group that takes chain after chain from the launch's queue (any order) gives every chain the result of its own launch
+    C = 9
+    rng = np.random.default_rng(11)
+    q0 = rng.normal(size=(C, D)) * 0.3
+    ora, sim = _pair(D, C, target, seed=21, eps=0.3, q0=q0)
+    order = rng.permutation(C)
+    for stage, da in enumerate((dict(), dict(init=0), None)):
+        _same(sim.run(15, da=da, queue=True, order=order), ora.run(15, da=da), f"stage {stage}")
+    assert np.array_equal(sim.status, ora.status())
+    assert np.array_equal(sim.transition, np.full(C, 45, np.uint32))
+
+
+@pytest.mark.parametrize("queue", [False, True])
+def test_rounds_with_a_leapfrog_budget_change_no_result(queue):
+    # a call in rounds (RunParams::prog): chains given up mid-round for their work and continued by a later launch, dual averaging and
+    # a metric window across the rounds — every chain the bits of one launch of N transitions
+    D, C, N = 30, 12, 37
+    rng = np.random.default_rng(5)
+    q0 = rng.normal(size=(C, D)) * 0.1
+    q0[:, 0] = np.linspace(-5.0, 2.0, C)
+    ora, sim = _pair(D, C, ol.TARGET_FUNNEL, seed=77, eps=0.25, q0=q0)
+    total = 0
+    for stage, da in enumerate((dict(), dict(init=0), None)):
+        if stage == 1:
+            ora.metric_window_begin(); sim.window_begin()
+        a, given_up = sim.run_rounds(N, da=da, rounds=4, budget=60, queue=queue)
+        _same(a, ora.run(N, da=da), f"stage {stage}")
+        total += given_up
+        if stage == 1:
+            ora.update_metric_diag_window(); sim.window_update_metric()
+    assert total > 0                      # the budget was exercised
+    assert np.array_equal(sim.status, ora.status())
+    assert np.array_equal(sim.eps, ora.stepsize())
