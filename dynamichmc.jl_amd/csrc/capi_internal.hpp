@@ -92,14 +92,29 @@ struct dhmc_ctx {
     int pipeline = 0;                      // the context's chains can run as four-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
                                            // previous launch showed to be held open by a few chains; DHMC_PIPELINE=0: never, =1: always
     int pipeline_force = 0;
-    // many chains with a heavy-tailed tree size (all 32768 funnel chains on one GPU): the call runs in segments, and in every segment
-    // the chains that did the most work in the segment before go through the pipeline kernel while the others run packed (dhmc_run)
-    int hybrid = 1;                        // DHMC_HYBRID=0: off
+    // many chains with a heavy-tailed tree size (all 32768 funnel chains on one GPU): the call in rounds — the chains packed, those
+    // with the deepest trees of the round before (and those the packed launch gave up for their work) through the pipeline kernel
+    // on CUs of their own (dhmc_run).  Measured no better than one packed launch with its queue of places: off unless asked for.
+    int hybrid = 0;                        // DHMC_HYBRID=1: on
     int hybrid_segments = 8;               // DHMC_HYBRID_SEGMENTS
+    double hybrid_budget = 0.0;            // DHMC_HYBRID_BUDGET: a round's leapfrog budget of a packed chain in mean works (0: chains per lane group)
+    int hybrid_deep_cap = 2;               // DHMC_HYBRID_DEEP_CAP: at most this × CUs chains go through the pipeline kernel in a round
+    int hybrid_deep_cus = 64;              // DHMC_HYBRID_DEEP_CUS: CUs set aside for the pipeline blocks of a call in rounds (0: no CU masks)
+    hipStream_t stream_deep = nullptr, stream_bulk = nullptr;   // … the streams with the two CU masks
+    int deep_cus = 0;
+    hipEvent_t ev_round[4] = {nullptr, nullptr, nullptr, nullptr};   // a round's two launches, timed (DHMC_DEBUG_ORDER prints them)
+    hipEvent_t ev_join2 = nullptr;
+    double hybrid_promote = 4.0;           // DHMC_HYBRID_PROMOTE: … of the chains whose leapfrog steps per transition were above this × the mean
+    int hybrid_min_chains = 0;             // DHMC_HYBRID_MIN_CHAINS: a call runs in rounds from this many chains on (0: 32 × CUs)
+    double mean_leapfrogs_per_transition = 0.0;   // of the previous call
+    int* d_prog = nullptr;                 // [C] a call in rounds: transitions of the call a chain has behind it
+    int* d_list_packed = nullptr;          // [C] … the round's chains of the packed launch, of the pipeline launch, and those the
+    int* d_list_deep = nullptr;            //     packed launch gave up
+    int* d_evicted = nullptr;
     int pk_queue = 1;                      // DHMC_PK_QUEUE=0: a packed launch starts a lane group per place (no queue of places)
     int pk_max_waves = 0;                  // DHMC_PK_MAX_WAVES: the waves a queued packed launch starts (0: one per SIMD)
     int tail_count = 0;                    // places at the head of the launch order whose work was far above the median's
-    int pk_align = 4;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two)
+    int pk_align = 0;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two; 0: from the tree sizes)
     int pk_cpl = 0;                        // DHMC_PK_CPL: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
     int pk_lds_levels = -1;                // DHMC_PK_LDS_LEVELS: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)
     int num_cus = 256;

@@ -263,6 +263,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_PK_MAX_WAVES")) c->pk_max_waves = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("DHMC_HYBRID")) c->hybrid = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_HYBRID_SEGMENTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->hybrid_segments = v; }
+    if (const char* e = std::getenv("DHMC_HYBRID_BUDGET")) c->hybrid_budget = std::atof(e);
+    if (const char* e = std::getenv("DHMC_HYBRID_DEEP_CAP")) c->hybrid_deep_cap = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("DHMC_HYBRID_PROMOTE")) c->hybrid_promote = std::atof(e);
+    if (const char* e = std::getenv("DHMC_HYBRID_DEEP_CUS")) c->hybrid_deep_cus = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("DHMC_HYBRID_MIN_CHAINS")) c->hybrid_min_chains = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("DHMC_PK_ALIGN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->pk_align = v; }
     if (const char* e = std::getenv("DHMC_PK_LDS_LEVELS")) c->pk_lds_levels = std::atoi(e);
     if (const char* e = std::getenv("DHMC_PK_CPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) c->pk_cpl = v; }
@@ -284,7 +289,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if ((rc = dev_alloc(c, &c->st.transition, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.status, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.ws, C * (size_t)c->nvec * Dp))) return fail(rc);
-    if ((rc = dev_alloc(c, &c->d_counter, 2))) return fail(rc);      // [0] leapfrog steps of a call; [1] a packed launch's queue of places
+    if ((rc = dev_alloc(c, &c->d_counter, 3))) return fail(rc);      // [0] leapfrog steps of a call; [1] a packed launch's queue of places; [2] the chains it gave up
     if ((rc = dev_alloc(c, &c->d_chain_work, (size_t)cfg->chains))) return fail(rc);
     if ((rc = dev_alloc(c, &c->d_launch_order, (size_t)cfg->chains))) return fail(rc);
     if (hipMemset(c->st.q, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -495,6 +500,8 @@ int dhmc_destroy(dhmc_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    for (hipStream_t st : {c->stream_deep, c->stream_bulk}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t ev : {c->ev_round[0], c->ev_round[1], c->ev_round[2], c->ev_round[3], c->ev_join2}) if (ev) (void)hipEventDestroy(ev);
     for (int i = 2; i < 4; ++i)
         if (c->streams[i]) { (void)hipStreamSynchronize(c->streams[i]); (void)hipStreamDestroy(c->streams[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -811,21 +818,22 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     // always / never.
     // … and when the chains are so few that each of their four waves gets a SIMD of its own (C <= the number of CUs — the reference's
     // typical handful of chains): such a launch is all latency, whatever its trees look like
-    const bool few_chains = C <= c->num_cus;
-    const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || c->tail_bound || few_chains);
-    const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound);
+    // … but not when there are so many chains that the launch is bound by throughput again (more than 64 per CU; the pipeline kernel
+    // gives a chain four waves): the packed kernel with its queue of places then.  One call of 1000 transitions of the funnel,
+    // leapfrog steps/s: 4096 chains pipeline 3.5e8, wave 2.0e8, packed 1.7e8; 8192: 4.9e8, 4.0e8, -; 16384: 6.4e8, 6.6e8, 5.4e8;
+    // 32768: 7.0e8, 8.7e8, 9.5e8 (profiles/r05_packed_queue_rounds.txt).
+    const bool few_chains = C <= c->num_cus, many_chains = C > 64 * c->num_cus;
+    const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || (c->tail_bound && !many_chains) || few_chains);
+    const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound || many_chains);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
-    // HYBRID: more chains than the pipeline kernel can hold resident (it takes a CU's four SIMDs and ≈ 28 KB of LDS per chain) and a
-    // heavy-tailed tree size.  All chains in the pipeline kernel wait in line (32768 funnel chains × 1000 transitions: 2.9 s); all in
-    // the wave-per-chain kernel: 2.4 s of which the slowest chain alone is 1.25 s; packed: its trips are the longest.  So the call
-    // runs in segments of N / hybrid_segments transitions, and in every segment the chains that did the most work in the segment
-    // before (> 3 × the median, at most as many as stay resident) go through the pipeline kernel on a second stream while all
-    // others run packed: the bulk at the packed kernel's throughput, the deep chains at the pipeline's latency.  A chain's stay in
-    // the funnel's neck lasts hundreds of transitions, so the previous segment predicts it (the previous CALL — a 50-transition
-    // warmup stage — did not: profiles/r05_packed_engine.txt).  Chains are independent: which kernel runs which segment of a chain
-    // changes none of its bits.
+    // ROUNDS (DHMC_HYBRID=1; off by default): the call in rounds, the bulk packed and the deepest chains in the pipeline kernel beside
+    // it on CUs of their own (below, where the rounds are launched).  Chains are independent: which kernel runs which part of a
+    // chain changes none of its bits.  Measured at 32768 funnel chains: 9.7e8 against 9.5e8 for one packed launch — the funnel
+    // keeps hundreds of chains at the depth limit at any time, more than the pipeline kernel can serve at its latency, and a round
+    // of the packed kernel then still ends with such a chain.
     const bool hybrid = per_draw_kernel && c->hybrid && c->packed && c->pipeline && !c->packed_force && !c->pipeline_force &&
-                        C > 32 * c->num_cus && N >= 8LL * c->hybrid_segments && c->d_chain_work && c->launch_order_on;
+                        c->tail_bound && C > (c->hybrid_min_chains > 0 ? c->hybrid_min_chains : 32 * c->num_cus) && N >= 8LL * c->hybrid_segments &&
+                        c->d_chain_work && c->launch_order_on;
     if (packed || hybrid) {
         // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
         // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)
@@ -849,7 +857,11 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         while (levels > 0 && pk::lds_bytes_per_wave(L, cpl, P.max_depth, levels) > pk::kMaxLdsPerWave) levels -= 1;
         P.pk_cpl = cpl;
         P.pk_lds_levels = levels;
-        P.pk_align = c->pk_align;
+        // the gate: chains whose transitions start on trips ≡ 0 mod A run the merges below level log2 A on the same trips (a wave pays
+        // for a merge level when any of its chains is at it), and wait A/2 trips per transition for it: worth 16 when the trees
+        // are large (32768 funnel chains with the depth limit at 5: 2.29e9 leapfrogs/s at A = 16, 1.84e9 at 4, 1.29e9 at 1 —
+        // profiles/r05_packed_queue_rounds.txt), 4 when they have a dozen leaves.  From the previous call's mean tree size.
+        P.pk_align = c->pk_align > 0 ? c->pk_align : c->mean_leapfrogs_per_transition >= 48.0 ? 16 : c->mean_leapfrogs_per_transition >= 24.0 ? 8 : 4;
         // the queue of places (packed_kernels.hpp launch_run_packed): as many waves as the GPU holds at once — one per SIMD
         P.pk_queue = c->pk_queue ? reinterpret_cast<unsigned*>(c->d_counter + 1) : nullptr;
         P.pk_max_waves = c->pk_max_waves > 0 ? c->pk_max_waves : 4 * c->num_cus;
@@ -1252,48 +1264,172 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
             }
         if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
     } else if (e == hipSuccess && hybrid && nbuf == 1) {
+        // The call in ROUNDS of N / hybrid_segments transitions (RunParams::prog).  In every round the chains run packed, in the
+        // order of their work in the round before, through the queue of places — and a chain that has taken more than the round's
+        // budget of leapfrog steps is given up at its next transition boundary (pk_budget) and, with the chains that were deep in
+        // the round before, continues through the pipeline kernel, whose blocks are launched first on a second stream: the bulk at
+        // the packed kernel's throughput, the deep chains at the pipeline's latency, and no chain has to be predicted deep before
+        // it is.  Budget: the work after which a chain alone would hold the packed launch open — (chains per lane group) × the
+        // mean work of a chain in a round.
         hybrid_ran = true;
         if (!c->stream2) {
             e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
             if (e == hipSuccess && !c->ev_fork) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
             if (e == hipSuccess && !c->ev_join) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
         }
+        // The two kernels on disjoint sets of CUs (DHMC_HYBRID_DEEP_CUS of them for the pipeline blocks): a block of four waves that
+        // has to find room between the packed kernel's waves starts when those drain, and one that shares its SIMDs with them is
+        // no longer the kernel with the lowest latency.
+        if (e == hipSuccess && c->hybrid_deep_cus > 0 && !c->stream_bulk) {
+            const int words = (c->num_cus + 31) / 32;
+            std::vector<uint32_t> deep_mask(words, 0u), bulk_mask(words, 0u);
+            const int deep_cus = std::min(c->hybrid_deep_cus, c->num_cus / 2);
+            int taken = 0;
+            for (int i = 0; i < c->num_cus; ++i) {     // every (num_cus / deep_cus)-th CU: spread over the XCDs and shader engines
+                const bool deep = (long long)(i + 1) * deep_cus / c->num_cus > (long long)i * deep_cus / c->num_cus;
+                (deep ? deep_mask : bulk_mask)[i / 32] |= 1u << (i % 32);
+                taken += deep;
+            }
+            hipStream_t sd = nullptr, sb = nullptr;
+            if (hipExtStreamCreateWithCUMask(&sd, (uint32_t)words, deep_mask.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&sb, (uint32_t)words, bulk_mask.data()) == hipSuccess) {
+                c->stream_deep = sd; c->stream_bulk = sb; c->deep_cus = taken;
+            } else {
+                (void)hipGetLastError();
+                if (sd) (void)hipStreamDestroy(sd);
+                c->hybrid_deep_cus = 0;            // no masks on this runtime: the kernels share the GPU
+            }
+        }
+        if (e == hipSuccess && !c->ev_round[0]) for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_round[i]);
+        if (e == hipSuccess && !c->ev_join2) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
+        hipStream_t const s_deep = c->stream_deep ? c->stream_deep : c->stream2, s_bulk = c->stream_bulk ? c->stream_bulk : c->stream;
+        const int bulk_cus = c->stream_bulk ? c->num_cus - c->deep_cus : c->num_cus;
+        if (e == hipSuccess && !c->d_prog) {
+            if ((rc = dev_alloc(c, &c->d_prog, (size_t)C)) || (rc = dev_alloc(c, &c->d_list_packed, (size_t)C)) ||
+                (rc = dev_alloc(c, &c->d_list_deep, (size_t)C)) || (rc = dev_alloc(c, &c->d_evicted, (size_t)C))) { cleanup(); return rc; }
+        }
         const int S = c->hybrid_segments;
         const int64_t seg = (N + S - 1) / S;
-        const int64_t stride = P.out_stride ? P.out_stride : N;
-        for (int64_t n0 = 0; n0 < N && e == hipSuccess; n0 += seg) {
-            const int64_t len = std::min(seg, N - n0);
-            RunParams Q = P;
-            Q.N = len;
-            Q.out_stride = stride;
-            Q.win_n0 = P.win_n0 + n0;
-            if (da) { Q.da_init = n0 == 0 ? da->init : 0; Q.da_finalize = n0 + len >= N ? da->finalize : 0; }
-            if (Q.out.draws) Q.out.draws += (size_t)n0 * D;
-            if (Q.out.logdensities) Q.out.logdensities += n0;
-            if (Q.out.eps) Q.out.eps += n0;
-            if (Q.out.pi) Q.out.pi += n0;
-            if (Q.out.acceptance_rate) Q.out.acceptance_rate += n0;
-            if (Q.out.steps) Q.out.steps += n0;
-            if (Q.out.term_left) Q.out.term_left += n0;
-            if (Q.out.term_right) Q.out.term_right += n0;
-            if (Q.out.depth) Q.out.depth += n0;
-            if (Q.out.directions) Q.out.directions += n0;
-            Q.launch_order = c->launch_order_valid ? c->d_launch_order : nullptr;
-            const int K = Q.launch_order ? std::min(c->tail_count, C) : 0;
-            if (K > 0) {                       // the head of the order through the pipeline kernel, beside the packed launch of the rest
-                e = hipEventRecord(c->ev_fork, c->stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+        const int Lp = pk::lanes_per_chain(D, P.pk_cpl);
+        const int bulk_waves = c->pk_max_waves > 0 ? c->pk_max_waves : 4 * bulk_cus;
+        const double groups = (double)bulk_waves * (64 / Lp);
+        const double factor = c->hybrid_budget > 0.0 ? c->hybrid_budget : std::max(2.0, (double)C / groups);
+        const size_t deep_cap = (size_t)std::max(1, c->hybrid_deep_cap) * (size_t)(c->stream_deep ? c->deep_cus : c->num_cus);
+        unsigned* const d_evict_count = reinterpret_cast<unsigned*>(c->d_counter + 2);
+        std::vector<int> list_packed(C), list_deep, evicted;
+        if (c->launch_order_valid) list_packed = c->h_launch_order;
+        else for (int i = 0; i < C; ++i) list_packed[i] = i;
+        std::vector<unsigned> work_before(C, 0u), work_round(C, 0u);
+        std::vector<int> prog_now(C, 0), prog_before(C, 0);
+        std::vector<float> rate(C, 0.f);
+        double mean_tr = c->mean_leapfrogs_per_transition;        // of the previous call (0: unknown — the first round has no budget)
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_prog, 0, sizeof(int) * C, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_chain_work, 0, sizeof(unsigned) * C, c->stream);
+        RunParams Q = P;
+        Q.out_stride = P.out_stride ? P.out_stride : N;
+        Q.prog = c->d_prog;
+        Q.chain_work = c->d_chain_work;
+        // one pair of launches: the deep list through the pipeline kernel (first: its blocks take their CUs before the packed grid
+        // fills the GPU), the packed list beside it
+        bool ran_deep = false, ran_bulk = false;
+        auto launch_pair = [&](int64_t target, unsigned long long budget) -> int {
+            Q.N = target;
+            if (da) { Q.da_init = da->init; Q.da_finalize = target >= N ? da->finalize : 0; }
+            ran_deep = !list_deep.empty(); ran_bulk = !list_packed.empty();
+            if (ran_deep) e = hipMemcpyAsync(c->d_list_deep, list_deep.data(), sizeof(int) * list_deep.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && ran_bulk) e = hipMemcpyAsync(c->d_list_packed, list_packed.data(), sizeof(int) * list_packed.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && ran_bulk) e = hipMemsetAsync(d_evict_count, 0, sizeof(unsigned), c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
+            if (e != hipSuccess) return 0;
+            if (ran_deep) {
+                e = hipStreamWaitEvent(s_deep, c->ev_fork, 0);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_round[0], s_deep);
+                if (e != hipSuccess) return 0;
                 RunParams T = Q;
-                T.C = K;                       // workgroup b < K takes launch_order[b]
-                if (e == hipSuccess && (rc = dispatch(c, Op::RunPipeline, &T, c->stream2, true))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
-                if (e == hipSuccess) e = hipEventRecord(c->ev_join, c->stream2);
+                T.C = (int)list_deep.size();
+                T.launch_order = c->d_list_deep;
+                if (int r = dispatch(c, Op::RunPipeline, &T, s_deep, true)) return r;
+                e = hipEventRecord(c->ev_round[1], s_deep);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_join, s_deep);
+                if (e != hipSuccess) return 0;
             }
-            RunParams B = Q;
-            B.pk_order_base = K;
-            if (e == hipSuccess && K < C && (rc = dispatch(c, Op::RunPacked, &B))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
-            if (e == hipSuccess && K > 0) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            if (ran_bulk) {
+                if (s_bulk != c->stream) e = hipStreamWaitEvent(s_bulk, c->ev_fork, 0);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_round[2], s_bulk);
+                if (e != hipSuccess) return 0;
+                RunParams B = Q;
+                B.C = (int)list_packed.size();
+                B.launch_order = c->d_list_packed;
+                B.pk_order_base = 0;
+                B.pk_max_waves = bulk_waves;
+                B.pk_budget = budget;
+                B.pk_evicted = c->d_evicted;
+                B.pk_evict_count = d_evict_count;
+                if (int r = dispatch(c, Op::RunPacked, &B, s_bulk, true)) return r;
+                e = hipEventRecord(c->ev_round[3], s_bulk);
+                if (e == hipSuccess && s_bulk != c->stream) {
+                    e = hipEventRecord(c->ev_join2, s_bulk);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
+                }
+                if (e != hipSuccess) return 0;
+            }
+            if (ran_deep) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = refresh_order(len);       // (drains the stream: the next segment's partition needs this one's work)
+            return 0;
+        };
+        int64_t done_to = 0;
+        for (int round = 0; done_to < N && e == hipSuccess; ++round) {
+            const int64_t target = std::min(N, done_to + seg), len = target - done_to;
+            const unsigned long long budget = mean_tr > 0.0 ? (unsigned long long)std::max(64.0, factor * mean_tr * (double)len) : 0ull;
+            if ((rc = launch_pair(target, budget))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
+            // the round's work per chain and the chains the packed launch gave up: the next round's two lists
+            unsigned n_evicted = 0;
+            c->h_chain_work.resize(C);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_chain_work.data(), c->d_chain_work, sizeof(unsigned) * C, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(prog_now.data(), c->d_prog, sizeof(int) * C, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && !list_packed.empty()) e = hipMemcpyAsync(&n_evicted, d_evict_count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) break;
+            evicted.resize(n_evicted);
+            if (n_evicted) e = hipMemcpy(evicted.data(), c->d_evicted, sizeof(int) * n_evicted, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) break;
+            unsigned long long sum = 0;
+            for (int i = 0; i < C; ++i) { work_round[i] = c->h_chain_work[i] - work_before[i]; work_before[i] = c->h_chain_work[i]; sum += work_round[i]; }
+            mean_tr = (double)sum / ((double)C * (double)len);
+            // the next round's lists: by the chains' leapfrog steps per transition in this round (a chain that was given up stopped
+            // early, one that was behind did more than the round's transitions), the deepest go through the pipeline kernel — as many
+            // as its CUs hold at once (× hybrid_deep_cap), if they are well above the mean — and the others packed, deepest first
+            for (int i = 0; i < C; ++i) {
+                const int did = prog_now[i] - prog_before[i];
+                rate[i] = (float)((double)work_round[i] / (double)(did > 0 ? did : 1));
+                prog_before[i] = prog_now[i];
+            }
+            list_deep.clear();
+            list_packed.resize(C);
+            for (int i = 0; i < C; ++i) list_packed[i] = i;
+            std::stable_sort(list_packed.begin(), list_packed.end(), [&](int a, int b) { return rate[a] > rate[b]; });
+            if (target < N) {
+                size_t k = 0;
+                while (k < deep_cap && k < (size_t)C && (double)rate[list_packed[k]] > c->hybrid_promote * mean_tr) ++k;
+                list_deep.assign(list_packed.begin(), list_packed.begin() + k);
+                list_packed.erase(list_packed.begin(), list_packed.begin() + k);
+            } else {
+                list_packed.clear();
+                list_deep = evicted;        // the clean-up: only the chains that are behind are left
+                std::stable_sort(list_deep.begin(), list_deep.end(), [&](int a, int b) { return rate[a] > rate[b]; });
+            }
+            if (std::getenv("DHMC_DEBUG_ORDER")) {
+                float ms_deep = 0.f, ms_bulk = 0.f;
+                if (ran_deep) (void)hipEventElapsedTime(&ms_deep, c->ev_round[0], c->ev_round[1]);
+                if (ran_bulk) (void)hipEventElapsedTime(&ms_bulk, c->ev_round[2], c->ev_round[3]);
+                std::fprintf(stderr, "[dhmc] round %d to %lld: budget %llu, given up %u, next deep %zu, mean per transition %.1f; pipeline %.1f ms, packed %.1f ms\n",
+                             round, (long long)target, budget, n_evicted, list_deep.size(), mean_tr, ms_deep, ms_bulk);
+            }
+            done_to = target;
+        }
+        // the chains the last round gave up: to the end through the pipeline kernel
+        if (e == hipSuccess && !list_deep.empty()) {
+            if ((rc = launch_pair(N, 0ull))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
         }
     } else if (e == hipSuccess) {
         rc = dispatch(c, run_op, &P);
@@ -1303,9 +1439,11 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
     if (e == hipSuccess && nbuf == 1 && !staged.empty()) e = d2h(0, 0, N, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-    const bool reorder = P.chain_work && N >= 32 && !hybrid_ran;     // (a short call's counts say little about the chains, and sorting is not free)
+    (void)hybrid_ran;                                                // (a call in rounds leaves the whole call's work per chain in chain_work)
+    const bool reorder = P.chain_work && N >= 32;                    // (a short call's counts say little about the chains, and sorting is not free)
     if (e == hipSuccess && reorder) e = refresh_order(N);
     else if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && N > 0) c->mean_leapfrogs_per_transition = (double)c->last_leapfrogs / ((double)C * (double)N);
     if (e == hipSuccess) {
         float ms = 0.f;
         e = hipEventElapsedTime(&ms, c->ev0, c->ev1);

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     volatile unsigned* const c_tail3 = ctl + 9;      // B3: records (and codes) consumed …
     volatile unsigned* const c_tail3_seq = ctl + 10; //     … of this transition
     volatile unsigned* const c_aseq = ctl + 11;      // B3: the transition whose visited statistic is in mb_s[2..3]
+    // (a call in rounds runs these blocks beside the packed kernel's waves, one of which may share the SIMD: the chain here is the one
+    // the round waits for, so its instructions go first)
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < 16) ctl[threadIdx.x] = 0u;
     __syncthreads();
 
@@ -118,6 +121,10 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     const int max_depth = P.max_depth;
     const int nl = uni_i32(reduce_lanes(NPL, D));
     const uint32_t tr0 = P.st.transition[chain];
+    // a call in rounds (RunParams::prog): the chain has n_done transitions of the call behind it and NN to go to the round's target;
+    // the loops below count the launch's transitions (so do the waves' sequence numbers), records and window counts the call's
+    const int64_t n_done = P.prog ? (int64_t)P.prog[chain] : 0;
+    const int64_t NN = P.N > n_done ? P.N - n_done : 0;
     bool broken = false;
     enum { W_HEAD = 0, W_SEQ_A = 1, W_TAIL1 = 2, W_TAIL1_SEQ = 3, W_MHEAD = 4, W_MSEQ = 5, W_TAIL2 = 6, W_SEQ_B = 7, W_QUIT = 8,
            W_TAIL3 = 9, W_TAIL3_SEQ = 10, W_ASEQ = 11 };
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         auto mk = [&](int) -> double { return mreg; };
         const double* const Wrow = P.st.W + row;
         double q[1], p[1], g[1], cf[1], cr[1];
-        for (int64_t n = 0; n < P.N; ++n) {
+        for (int64_t n = 0; n < NN; ++n) {
             const unsigned want = (unsigned)n + 1u;
             if (!wait_for([&](const PairCtl& c) { return c.w[W_SEQ_B] == want || c.w[W_QUIT] != 0u; })) return;
             if (cw.w[W_QUIT] != 0u) return;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
         double p[1], cf[1], cr[1], tpm[1], tpp[1], trho[1];
         cf[0] = 0.0; cr[0] = 0.0;
-        for (int64_t n = 0; n < P.N; ++n) {
+        for (int64_t n = 0; n < NN; ++n) {
             const unsigned want = (unsigned)n + 1u;
             if (!wait_for([&](const PairCtl& c) { return (c.w[W_SEQ_A] == want && c.w[W_HEAD] >= 1u) || c.w[W_QUIT] != 0u; })) return;
             if (cw.w[W_QUIT] != 0u) return;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         // and on nothing else; the acceptance rate of the transition is its only consumer.
         LaneArrF64 lv_vlsa;
         LaneArrI64 lv_vsteps;
-        for (int64_t n = 0; n < P.N; ++n) {
+        for (int64_t n = 0; n < NN; ++n) {
             const unsigned want = (unsigned)n + 1u;
             if (!wait_for([&](const PairCtl& c) { return (c.w[W_SEQ_A] == want && c.w[W_HEAD] >= 1u) || c.w[W_QUIT] != 0u; })) return;
             if (cw.w[W_QUIT] != 0u) return;
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     DAState da = P.st.da[chain];
     uint32_t status = P.st.status[chain];
     unsigned long long total_steps = 0;
-    if (P.adapt && P.da_init) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
+    if (P.adapt && P.da_init && n_done == 0) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
         double le = det_log_u(eps_fixed);
         da.mu = det_log_u(10.0) + le;
         da.m = 1;
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         return s;
     };
     int64_t n = 0;
-    for (; n < P.N; ++n) {
+    for (; n < NN; ++n) {
         const uint32_t tr = tr0 + (uint32_t)n;
         const unsigned want = (unsigned)n + 1u;
         const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
@@ -637,12 +644,12 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
         lq_cur = sl_lq.get(init_slot);
         const double pi_stat = sl_pi.get(init_slot);
-        const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + n;
+        const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + (size_t)(n_done + n);
         if (P.out.draws) {
             double* drow = P.out.draws + o * D;
             if (lane < D) drow[lane] = q[0];
         }
-        window_accumulate<NPL>(P, (size_t)chain * P.Dpad, lane, q, n);
+        window_accumulate<NPL>(P, (size_t)chain * P.Dpad, lane, q, n_done + n);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
             if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273
@@ -676,8 +683,12 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         }
         P.st.transition[chain] = tr0 + (uint32_t)n;
         P.st.status[chain] = status;
+        if (P.prog) P.prog[chain] = (int)(n_done + n);
         if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
-        if (P.chain_work) P.chain_work[chain] = (unsigned)(total_steps > 0xffffffffull ? 0xffffffffull : total_steps);
+        if (P.chain_work) {
+            const unsigned long long w = total_steps + (P.prog ? (unsigned long long)P.chain_work[chain] : 0ull);
+            P.chain_work[chain] = (unsigned)(w > 0xffffffffull ? 0xffffffffull : w);
+        }
     }
 }
 
