@@ -255,7 +255,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = c->packed && std::atoi(e) != 0; c->packed_force = c->packed; }
     // … and as a PIPELINE of four wavefronts per chain (integrator ‖ turn statistics ‖ visited statistic ‖ proposals, nuts_pipeline_kernel.hpp): the lowest
     // latency per leapfrog of a short chain, for launches that wait for a few deep chains
-    c->pipeline = cfg->metric == DHMC_METRIC_DIAG && D <= 64 &&
+    c->pipeline = cfg->metric == DHMC_METRIC_DIAG && D <= 256 &&          // (rows of 64, 128 or 256 doubles: one, two or four slots per lane)
               (cfg->target == DHMC_TARGET_STD_NORMAL || cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL ||
                cfg->target == DHMC_TARGET_FUNNEL || cfg->target == DHMC_TARGET_DENSE_NORMAL || cfg->target == DHMC_TARGET_ALWAYS_DIVERGENT);
     if (const char* e = std::getenv("DHMC_PIPELINE")) { c->pipeline = c->pipeline && std::atoi(e) != 0; c->pipeline_force = c->pipeline; }
@@ -822,7 +822,10 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     // gives a chain four waves): the packed kernel with its queue of places then.  One call of 1000 transitions of the funnel,
     // leapfrog steps/s: 4096 chains pipeline 3.5e8, wave 2.0e8, packed 1.7e8; 8192: 4.9e8, 4.0e8, -; 16384: 6.4e8, 6.6e8, 5.4e8;
     // 32768: 7.0e8, 8.7e8, 9.5e8 (profiles/r05_packed_queue_rounds.txt).
-    const bool few_chains = C <= c->num_cus, many_chains = C > 64 * c->num_cus;
+    // … and only when the trees are large: the four waves fill and drain once per transition (≈ 2.5 µs), so 4 chains of a 100-dim
+    // standard normal (7 leapfrogs per transition) take 2.1 µs per leapfrog here against 1.5 in the wave kernel, the same chains on
+    // a 100-dim funnel (66 per transition) 1.6 against 2.6 (profiles/r05_pipeline_kernel.txt).  From the previous call's mean.
+    const bool few_chains = C <= c->num_cus && c->mean_leapfrogs_per_transition >= 24.0, many_chains = C > 13 * (int)((size_t)160 * 1024 / pipeline_lds_bytes(c->NPL <= 4 ? c->NPL : 4)) * c->num_cus;   // (5, 2 or 1 blocks per CU)
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || (c->tail_bound && !many_chains) || few_chains);
     const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound || many_chains);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;

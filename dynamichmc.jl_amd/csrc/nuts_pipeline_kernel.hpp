@@ -38,8 +38,7 @@
 
 namespace dhmc {
 
-constexpr int PAIR_RING = 16;                    // leaf records in flight (heavy cascades of B1 and B2 fall on the same leaves: a deeper ring lets the
-                                                 // others run on while one works through a long cascade)
+// (PAIR_RING, PIPE_NXL, pipeline_lds_bytes: run_params.hpp)
 constexpr unsigned PAIR_SPIN_LIMIT = 1u << 24;   // polls of one wait (≈ 64 clocks each plus the poll itself: ≈ 1 s)
 constexpr uint32_t DHMC_ST_KERNEL_PROTOCOL = 0x40000000u;   // internal: the pair kernel's handshake timed out (a bug, never a model's fault)
 
@@ -73,29 +72,35 @@ __device__ __forceinline__ PairCtl pair_load_ctl(volatile unsigned* ctl) {
 }
 
 constexpr int PIPE_TOP = 64;      // B1's code for "the top-level merge was turning" (0 … 31: the sub-merge at that level; -1: none)
-__host__ __device__ constexpr size_t pipeline_lds_bytes() {
-    return sizeof(double) * ((size_t)WAVE * (3 + 3 * lds_extra_levels(1)) + (size_t)PAIR_RING * (2 * WAVE + 4) + PAIR_RING + WAVE + 4 + 8);   // mb_s[2..3]: B3's result
-}
 
-template <class T>
+template <class T, int NPL>
 __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     static_assert(T::kRecomputeGrad, "the integrator re-evaluates ∇ℓ at the position the builder hands back");
-    constexpr int NPL = 1;
+    constexpr int DP = WAVE * NPL;
     const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int D = P.D, Dpad = P.Dpad;
     extern __shared__ double lds[];
-    constexpr int NXL = lds_extra_levels(1);
+    constexpr int NXL = PIPE_NXL;
     double* const l0_lds = lds;
-    double* const l1f_lds = lds + WAVE;
-    double* const l1l_lds = lds + 2 * WAVE;
-    double* const xl_lds = lds + 3 * WAVE;
-    double* const ring_p = lds + (size_t)WAVE * (3 + 3 * NXL);            // [RING][64]
-    double* const ring_q = ring_p + (size_t)PAIR_RING * WAVE;             // [RING][64]
-    double* const ring_s = ring_q + (size_t)PAIR_RING * WAVE;             // [RING][4]: ℓq, π, flags, -
+    double* const l1f_lds = lds + DP;
+    double* const l1l_lds = lds + 2 * DP;
+    double* const xl_lds = lds + 3 * DP;
+    double* const ring_p = lds + (size_t)DP * (3 + 3 * NXL);              // [RING][DP]
+    double* const ring_q = ring_p + (size_t)PAIR_RING * DP;               // [RING][DP]
+    double* const ring_s = ring_q + (size_t)PAIR_RING * DP;               // [RING][4]: ℓq, π, flags, -
     double* const mres = ring_s + (size_t)PAIR_RING * 4;                  // [RING]: B1's code of the leaf (an integer in a double's bits)
-    double* const mb_q = mres + PAIR_RING;                                // [64]
-    double* const mb_s = mb_q + WAVE;                                     // [4]: ℓq, ϵ
+    double* const mb_q = mres + PAIR_RING;                                // [DP]
+    double* const mb_s = mb_q + DP;                                       // [4]: ℓq, ϵ
+    // a row of a chain in LDS: lane l holds elements l, l + 64, … (the wave kernel's slot layout)
+    auto ld_row = [&](const double* rowp, double (&v)[NPL]) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) v[k] = rowp[lane + WAVE * k];
+    };
+    auto st_row = [&](double* rowp, const double (&v)[NPL]) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) rowp[lane + WAVE * k] = v[k];
+    };
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(mb_s + 4);
     volatile unsigned* const c_head = ctl + 0;       // A   (the order of these words is the enum W_* below)
     volatile unsigned* const c_seq_a = ctl + 1;      // A
@@ -163,16 +168,17 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
 
     if (wave == 0) {
         // ================================================= A: the integrator =================================================
-        const double mreg = P.st.minv[row + lane];
-        auto mk = [&](int) -> double { return mreg; };
+        double mreg[NPL];
+        ldv<NPL>(P.st.minv + row, lane, mreg);
+        auto mk = [&](int k) -> double { return mreg[k]; };
         const double* const Wrow = P.st.W + row;
-        double q[1], p[1], g[1], cf[1], cr[1];
+        double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
         for (int64_t n = 0; n < NN; ++n) {
             const unsigned want = (unsigned)n + 1u;
             if (!wait_for([&](const PairCtl& c) { return c.w[W_SEQ_B] == want || c.w[W_QUIT] != 0u; })) return;
             if (cw.w[W_QUIT] != 0u) return;
             const uint32_t tr = tr0 + (uint32_t)n;
-            q[0] = mb_q[lane];
+            ld_row(mb_q, q);
             const double lq_cur = uni_f64(mb_s[0]);
             const double eps = uni_f64(mb_s[1]);
             (void)tgt.eval(q, g, lane, D);
@@ -181,11 +187,12 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
             double pi0;
             {
                 LaneAcc<1, NPL> kacc;
-                kacc.add(0, 0, p[0], mk(0) * p[0]);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], mk(k) * p[k]);
                 pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0), nl) / 2.0));
             }
-            ring_p[lane] = p[0];
-            ring_q[lane] = q[0];
+            st_row(ring_p, p);
+            st_row(ring_q, q);
             if (lane == 0) { ring_s[0] = lq_cur; ring_s[1] = pi0; ring_s[2] = __longlong_as_double(1ll); }
             unsigned head = 1u;
             pair_publish(c_head, head, lane);
@@ -197,17 +204,21 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                 const unsigned t = t1 < t2 ? t1 : t2;
                 return t < t3 ? t : t3;
             };
-            double qe[2] = {q[0], q[0]}, pe[2] = {p[0], p[0]}, ge[2] = {g[0], g[0]};
+            double qm[NPL], pm[NPL], gm[NPL], qp[NPL], pp[NPL], gp[NPL];     // the trajectory's two edges (backward, forward)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) { qm[k] = q[k]; pm[k] = p[k]; gm[k] = g[k]; qp[k] = q[k]; pp[k] = p[k]; gp[k] = g[k]; }
             bool ended = false;
             unsigned seen = 0u;                                          // records both readers had consumed at the last poll
             for (int depth = 0; depth < max_depth && !ended; ++depth) {
                 const bool fwd = (dirs & 1u) != 0;
                 dirs >>= 1;
-                const int dir = fwd ? 1 : 0;
-                q[0] = qe[dir]; p[0] = pe[dir]; g[0] = ge[dir];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) { q[k] = fwd ? qp[k] : qm[k]; p[k] = fwd ? pp[k] : pm[k]; g[k] = fwd ? gp[k] : gm[k]; }
                 const double eps_s = fwd ? eps : -eps;
                 const uint32_t nleaf = 1u << depth;
-                double p_prev = 0.0;
+                double p_prev[NPL];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) p_prev[k] = 0.0;
                 for (uint32_t j = 0; j < nleaf; ++j) {
                     // room in the ring by the LAST poll's counts is room now (the readers only advance): poll when that runs out —
                     // which is also when the integrator learns that the tree has ended (at most a ring's worth of leaves late)
@@ -221,13 +232,13 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                     leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl);
                     unsigned flags = pos_finite ? 1u : 0u;
                     if (j & 1u) {
-                        const double pa = p_prev;
-                        if (merge_leaf_leaf<NPL>([&](int) { return pa; }, mk, cf, cr, p, nl)) flags |= 2u;
+                        if (merge_leaf_leaf<NPL>([&](int k) { return p_prev[k]; }, mk, cf, cr, p, nl)) flags |= 2u;
                     }
-                    p_prev = p[0];
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) p_prev[k] = p[k];
                     const unsigned slot = head % (unsigned)PAIR_RING;
-                    ring_p[slot * WAVE + lane] = p[0];
-                    ring_q[slot * WAVE + lane] = q[0];
+                    st_row(ring_p + (size_t)slot * DP, p);
+                    st_row(ring_q + (size_t)slot * DP, q);
                     if (lane == 0) {
                         ring_s[slot * 4 + 0] = lq_leaf;
                         ring_s[slot * 4 + 1] = pi_leaf;
@@ -237,7 +248,11 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                     pair_publish(c_head, head, lane);
                     if (pi_leaf - pi0 < P.min_delta) { ended = true; break; }
                 }
-                qe[dir] = q[0]; pe[dir] = p[0]; ge[dir] = g[0];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    if (fwd) { qp[k] = q[k]; pp[k] = p[k]; gp[k] = g[k]; }
+                    else { qm[k] = q[k]; pm[k] = p[k]; gm[k] = g[k]; }
+                }
             }
         }
         PIPE_PT_FLUSH(0, 0)
@@ -246,24 +261,27 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
 
     if (wave == 1) {
         // ========================================== B1: turn statistics, merge by merge ==========================================
-        const double mreg = P.st.minv[row + lane];
-        auto mk = [&](int) -> double { return mreg; };
+        double mreg[NPL];
+        ldv<NPL>(P.st.minv + row, lane, mreg);
+        auto mk = [&](int k) -> double { return mreg[k]; };
         double* const ws = P.st.ws + (size_t)chain * P.nvec * Dpad;
         auto wsv = [&](int idx) -> double* { return ws + (size_t)idx * Dpad; };
-        double p[1], cf[1], cr[1], tpm[1], tpp[1], trho[1];
-        cf[0] = 0.0; cr[0] = 0.0;
+        double p[NPL], cf[NPL], cr[NPL], tpm[NPL], tpp[NPL], trho[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { cf[k] = 0.0; cr[k] = 0.0; }
         for (int64_t n = 0; n < NN; ++n) {
             const unsigned want = (unsigned)n + 1u;
             if (!wait_for([&](const PairCtl& c) { return (c.w[W_SEQ_A] == want && c.w[W_HEAD] >= 1u) || c.w[W_QUIT] != 0u; })) return;
             if (cw.w[W_QUIT] != 0u) return;
-            p[0] = ring_p[lane];
+            ld_row(ring_p, p);
             const double pi0 = uni_f64(ring_s[1]);
             unsigned tail = 1u;
             pair_publish(c_tail1, tail, lane);
             pair_publish(c_tail1_seq, want, lane);
             pair_publish(c_mhead, tail, lane);
             pair_publish(c_mseq, want, lane);
-            tpm[0] = p[0]; tpp[0] = p[0]; trho[0] = p[0];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; trho[k] = p[k]; }
             uint32_t dirs = directions_of(tr0 + (uint32_t)n);
             int depth = 0;
             bool finished = false;
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                         seen2 = readers(cw);
                     }
                     const unsigned slot = tail % (unsigned)PAIR_RING;
-                    p[0] = ring_p[slot * WAVE + lane];
+                    ld_row(ring_p + (size_t)slot * DP, p);
                     const double pi_leaf = uni_f64(ring_s[slot * 4 + 1]);
                     const unsigned flags = uni_u32((unsigned)__double_as_longlong(ring_s[slot * 4 + 2]));
                     int code = -1, level = 0;
@@ -301,41 +319,44 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                             bool turning;
                             if (sub) {
                                 if (level == 0) {
-                                    const double pa = l0_lds[lane];
-                                    cf[0] = pa;
-                                    cr[0] = pa + p[0];
+#pragma unroll
+                                    for (int k = 0; k < NPL; ++k) {
+                                        const double pa = l0_lds[lane + WAVE * k];
+                                        cf[k] = pa;
+                                        cr[k] = pa + p[k];
+                                    }
                                     turning = (flags & 2u) != 0;
                                 } else if (level == 1) {
-                                    auto a_lf = [&](int) { return l1f_lds[lane]; };
-                                    auto a_ll = [&](int) { return l1l_lds[lane]; };
-                                    auto a_lr = [&](int) { return l1f_lds[lane] + l1l_lds[lane]; };
+                                    auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
+                                    auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
+                                    auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
                                     turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
                                                   : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                                 } else if (level < 2 + NXL) {
-                                    const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * WAVE;
-                                    const double* Ll = Lf + WAVE;
-                                    const double* Lr = Ll + WAVE;
-                                    auto a_lf = [&](int) { return Lf[lane]; };
-                                    auto a_ll = [&](int) { return Ll[lane]; };
-                                    auto a_lr = [&](int) { return Lr[lane]; };
+                                    const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * DP;
+                                    const double* Ll = Lf + DP;
+                                    const double* Lr = Ll + DP;
+                                    auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
+                                    auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
+                                    auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
                                     turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
                                                   : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                                 } else {
                                     const double* Lf = wsv(ws_stack(level, 0));
                                     const double* Ll = wsv(ws_stack(level, 1));
                                     const double* Lr = wsv(ws_stack(level, 2));
-                                    auto a_lf = [&](int) { return Lf[lane]; };
-                                    auto a_ll = [&](int) { return Ll[lane]; };
-                                    auto a_lr = [&](int) { return Lr[lane]; };
+                                    auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
+                                    auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
+                                    auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
                                     turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
                                                   : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                                 }
                                 if (turning) { code = level; invalid = true; break; }
                                 level += 1;
                             } else {
-                                auto a_tm = [&](int) { return tpm[0]; };
-                                auto a_tp = [&](int) { return tpp[0]; };
-                                auto a_tr = [&](int) { return trho[0]; };
+                                auto a_tm = [&](int k) { return tpm[k]; };
+                                auto a_tp = [&](int k) { return tpp[k]; };
+                                auto a_tr = [&](int k) { return trho[k]; };
                                 if (depth == 0) turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p, nl);
                                 else turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr, nl)
                                                    : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr, nl);
@@ -344,8 +365,11 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                                     code = PIPE_TOP;
                                     finished = true;
                                 } else if (depth < max_depth) {
-                                    if (fwd) tpp[0] = p[0]; else tpm[0] = p[0];
-                                    trho[0] = cr[0];
+#pragma unroll
+                                    for (int k = 0; k < NPL; ++k) {
+                                        if (fwd) tpp[k] = p[k]; else tpm[k] = p[k];
+                                        trho[k] = cr[k];
+                                    }
                                 }
                                 level = -1;
                                 break;
@@ -353,15 +377,15 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                         }
                         if (level >= 0 && !invalid) {             // suspend the running summary
                             if (level == 0) {
-                                l0_lds[lane] = p[0];
+                                st_row(l0_lds, p);
                             } else if (level == 1) {
-                                l1f_lds[lane] = cf[0];
-                                l1l_lds[lane] = p[0];
+                                st_row(l1f_lds, cf);
+                                st_row(l1l_lds, p);
                             } else if (level < 2 + NXL) {
-                                double* Lf = xl_lds + (size_t)(3 * (level - 2)) * WAVE;
-                                Lf[lane] = cf[0];
-                                Lf[WAVE + lane] = p[0];
-                                Lf[2 * WAVE + lane] = cr[0];
+                                double* Lf = xl_lds + (size_t)(3 * (level - 2)) * DP;
+                                st_row(Lf, cf);
+                                st_row(Lf + DP, p);
+                                st_row(Lf + 2 * DP, cr);
                             } else {
                                 stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
                                 stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     LaneArrF64 lv_omega;
     LaneArrI32 lv_zeta;
     LaneArrF64 sl_lq, sl_pi;
-    double q[1], g[1];
+    double q[NPL], g[NPL];
     ldv<NPL>(P.st.q + row, lane, q);
     double lq_cur = P.st.lq[chain];
     double eps_fixed = P.st.eps[chain];
@@ -502,7 +526,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         const uint32_t tr = tr0 + (uint32_t)n;
         const unsigned want = (unsigned)n + 1u;
         const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
-        mb_q[lane] = q[0];
+        st_row(mb_q, q);
         if (lane == 0) { mb_s[0] = lq_cur; mb_s[1] = eps; }
         unsigned tail = 0u;
         pair_publish(c_tail2, tail, lane);
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                     avail = cw.w[W_HEAD] < cw.w[W_MHEAD] ? cw.w[W_HEAD] : cw.w[W_MHEAD];
                 }
                 const unsigned slot = tail % (unsigned)PAIR_RING;
-                q[0] = ring_q[slot * WAVE + lane];
+                ld_row(ring_q + (size_t)slot * DP, q);
                 const double lq_leaf = uni_f64(ring_s[slot * 4 + 0]);
                 const double pi_leaf = uni_f64(ring_s[slot * 4 + 1]);
                 const unsigned flags = uni_u32((unsigned)__double_as_longlong(ring_s[slot * 4 + 2]));
@@ -647,7 +671,9 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + (size_t)(n_done + n);
         if (P.out.draws) {
             double* drow = P.out.draws + o * D;
-            if (lane < D) drow[lane] = q[0];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (lane + WAVE * k < D) drow[lane + WAVE * k] = q[k];
         }
         window_accumulate<NPL>(P, (size_t)chain * P.Dpad, lane, q, n_done + n);
         if (lane == 0) {
@@ -697,9 +723,19 @@ int launch_run_pipeline(const RunParams& P, hipStream_t s) {
     if constexpr (!T::kRecomputeGrad || T::kBigDims) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
-        if (P.Dpad != WAVE) return DHMC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T>), dim3(P.C), dim3(4 * WAVE), pipeline_lds_bytes(), s, P);
-        return DHMC_OK;
+#define DHMC_PIPE_LAUNCH(NPL_)                                                                                                  \
+    if (P.Dpad == WAVE * NPL_) {                                                                                                \
+        static bool once = [] {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)nuts_run_pipeline_kernel<T, NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipeline_lds_bytes(NPL_)); \
+            return true;                                                                                                        \
+        }();                                                                                                                    \
+        (void)once;                                                                                                             \
+        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T, NPL_>), dim3(P.C), dim3(4 * WAVE), pipeline_lds_bytes(NPL_), s, P);      \
+        return DHMC_OK;                                                                                                         \
+    }
+        DHMC_PIPE_LAUNCH(1) DHMC_PIPE_LAUNCH(2) DHMC_PIPE_LAUNCH(4)
+#undef DHMC_PIPE_LAUNCH
+        return DHMC_ERR_UNSUPPORTED;
     }
 }
 

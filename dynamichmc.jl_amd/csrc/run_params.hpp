@@ -104,6 +104,15 @@ struct RunParams {
     unsigned* pk_evict_count;
 };
 
+// the pipeline kernel's LDS (nuts_pipeline_kernel.hpp; the host sizes launches and engine choices with it)
+constexpr int PAIR_RING = 16;     // leaf records in flight (heavy cascades of B1 and B2 fall on the same leaves: a deeper ring lets the others run
+                                  // on while one works through a long cascade)
+constexpr int PIPE_NXL = 6;       // suspended levels 2 … 7 in LDS (first, last, ρ), deeper ones in the HBM workspace
+// a chain's rows are 64·NPL doubles wide (NPL = 1, 2, 4: up to 256 coordinates)
+DHMC_HD constexpr size_t pipeline_lds_bytes(int npl) {
+    return sizeof(double) * ((size_t)64 * npl * (3 + 3 * PIPE_NXL) + (size_t)PAIR_RING * (2 * 64 * npl + 4) + PAIR_RING + (size_t)64 * npl + 4 + 8);   // mb_s[2..3]: B3's result
+}
+
 // workspace vector indices (units of Dpad doubles inside one chain's block)
 DHMC_HD int ws_p0() { return 0; }
 DHMC_HD int ws_edge(int dir, int which) { return 1 + 3 * dir + which; }  // which: 0 q, 1 p, 2 g

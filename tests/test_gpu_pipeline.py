@@ -78,6 +78,33 @@ def test_normal_families_match_oracle(pkg, family):
     _stages(dev, ora, family)
 
 
+@pytest.mark.parametrize("D,C", [(65, 6), (100, 4), (128, 9), (129, 5), (200, 7), (256, 5)])
+def test_wider_chains_match_oracle(pkg, D, C):
+    """Rows of 128 and 256 doubles (two and four slots per lane): the funnel (deep trees, suspended levels in LDS and in the HBM
+    workspace), a diagonal normal under a per-chain metric with a metric window, and the reference's own case — 100 dimensions, 4 chains."""
+    rng = np.random.default_rng(D)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=400 + D)
+    ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=400 + D, threads=8)
+    q0 = rng.normal(size=(C, D)) * 0.2
+    q0[:, 0] = np.linspace(-3.0, 1.5, C)
+    for e in (dev, ora):
+        e.init(q0); e.set_stepsize(0.15)
+    _stages(dev, ora, f"funnel D={D}")
+    tgt = ol.TARGET_DIAG_NORMAL
+    params = ol.target_params_blob(tgt, D, mu=rng.normal(size=D), prec=rng.uniform(0.2, 5.0, size=D))
+    dev = pkg.DeviceContext(D, C, target=tgt, target_params=params, seed=7)
+    ora = ol.Oracle(D, C, target=tgt, params=params, seed=7, threads=8)
+    minv = rng.uniform(0.3, 3.0, size=(C, D))
+    for e in (dev, ora):
+        e.init(); e.set_metric_diag(minv); e.find_initial_stepsize()
+        e.metric_window_begin()
+    _same(dev.run(30, da={}), ora.run(30, da={}), "diag normal, window")
+    for e in (dev, ora):
+        e.update_metric_diag_window()
+    assert np.array_equal(dev.metric_diag(), ora.metric_diag())
+    _stages(dev, ora, f"diag normal D={D}")
+
+
 def test_trees_that_end_early(pkg):
     """Divergent leaves, turning subtrees, depth limits, −Inf densities: the integrator has run ahead when the builder stops."""
     D, C = 30, 24
