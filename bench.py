@@ -350,9 +350,11 @@ def other_configs(args, pkg, torch):
     the logistic regression) is mostly that wait."""
     import copy
     res = {}
-    for cfg, key, fn, config_n in ((3, "c3", bench_config3, 1000), (4, "c4", bench_config45, 1000), (5, "c5", bench_config45, 200)):
+    # (c4_32768: ALL of configs[3]'s chains on this one GPU — what the packed kernel's queue of places is for)
+    for cfg, key, fn, config_n, chains in ((3, "c3", bench_config3, 1000, CHAINS_PER_GPU), (4, "c4", bench_config45, 1000, CHAINS_PER_GPU),
+                                           (4, "c4_32768", bench_config45, 1000, 32768), (5, "c5", bench_config45, 200, CHAINS_PER_GPU)):
         a = copy.copy(args)
-        a.config, a.transitions, a.steps, a.warmup, a.chains, a.config_n = cfg, 20, 2, 1, CHAINS_PER_GPU, config_n
+        a.config, a.transitions, a.steps, a.warmup, a.chains, a.config_n = cfg, 20, 2, 1, chains, config_n
         t0 = time.perf_counter()
         try:
             line = fn(a, pkg, torch)

@@ -283,8 +283,8 @@ def test_bench_default_line_carries_the_other_configs_and_a_live_traffic_figure(
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e7
     oc = d["other_configs"]
-    assert set(oc) == {"c3", "c4", "c5"}
-    for k, floor in (("c3", 1e6), ("c4", 1e7), ("c5", 1e4)):
+    assert set(oc) == {"c3", "c4", "c4_32768", "c5"}
+    for k, floor in (("c3", 1e6), ("c4", 1e7), ("c4_32768", 1e8), ("c5", 1e4)):
         assert "error" not in oc[k], oc[k]
         assert oc[k]["value"] > floor and oc[k]["steps"] == 2 and 0 < oc[k]["roofline"]["frac"] < 1.5
         n = oc[k]["at_config_n"]                        # one call of the config's own N beside the 20-transition steps
