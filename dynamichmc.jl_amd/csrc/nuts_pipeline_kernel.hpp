@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     volatile unsigned* const c_tail3_seq = ctl + 10; //     … of this transition
     volatile unsigned* const c_aseq = ctl + 11;      // B3: the transition whose visited statistic is in mb_s[2..3]
     // (a call in rounds runs these blocks beside the packed kernel's waves, one of which may share the SIMD: the chain here is the one
-    // the round waits for, so its instructions go first)
-    __builtin_amdgcn_s_setprio(3);
+    // the round waits for, so its instructions go first.  Only then: priorities between the four roles change nothing — each has its
+    // SIMD — and an unconditional s_setprio here cost 2.5 % of the kernel's latency, whatever the level)
+    if (P.prog) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < 16) ctl[threadIdx.x] = 0u;
     __syncthreads();
 
