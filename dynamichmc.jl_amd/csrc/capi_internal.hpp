@@ -105,6 +105,7 @@ struct dhmc_ctx {
     hipEvent_t ev_round[4] = {nullptr, nullptr, nullptr, nullptr};   // a round's two launches, timed (DHMC_DEBUG_ORDER prints them)
     hipEvent_t ev_join2 = nullptr;
     double hybrid_promote = 4.0;           // DHMC_HYBRID_PROMOTE: … of the chains whose leapfrog steps per transition were above this × the mean
+    int hybrid_deep_wave = 0;              // DHMC_HYBRID_DEEP=wave: the deep chains through the wave-per-chain kernel (1.5 µs per leapfrog, any number resident)
     int hybrid_min_chains = 0;             // DHMC_HYBRID_MIN_CHAINS: a call runs in rounds from this many chains on (0: 32 × CUs)
     double mean_leapfrogs_per_transition = 0.0;   // of the previous call
     int* d_prog = nullptr;                 // [C] a call in rounds: transitions of the call a chain has behind it

@@ -265,6 +265,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_HYBRID_SEGMENTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->hybrid_segments = v; }
     if (const char* e = std::getenv("DHMC_HYBRID_BUDGET")) c->hybrid_budget = std::atof(e);
     if (const char* e = std::getenv("DHMC_HYBRID_DEEP_CAP")) c->hybrid_deep_cap = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("DHMC_HYBRID_DEEP")) c->hybrid_deep_wave = std::string(e) == "wave";
     if (const char* e = std::getenv("DHMC_HYBRID_PROMOTE")) c->hybrid_promote = std::atof(e);
     if (const char* e = std::getenv("DHMC_HYBRID_DEEP_CUS")) c->hybrid_deep_cus = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("DHMC_HYBRID_MIN_CHAINS")) c->hybrid_min_chains = std::max(1, std::atoi(e));
@@ -1351,7 +1352,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
                 RunParams T = Q;
                 T.C = (int)list_deep.size();
                 T.launch_order = c->d_list_deep;
-                if (int r = dispatch(c, Op::RunPipeline, &T, s_deep, true)) return r;
+                if (int r = dispatch(c, c->hybrid_deep_wave ? Op::Run : Op::RunPipeline, &T, s_deep, true)) return r;      // (the wave kernel: a wave per chain, resident beside the packed waves)
                 e = hipEventRecord(c->ev_round[1], s_deep);
                 if (e == hipSuccess) e = hipEventRecord(c->ev_join, s_deep);
                 if (e != hipSuccess) return 0;

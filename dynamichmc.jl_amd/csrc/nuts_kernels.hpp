@@ -442,8 +442,13 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     uint32_t status = P.st.status[chain];
     const uint32_t tr0 = P.st.transition[chain];
     unsigned long long total_steps = 0;
+    // a call in rounds (RunParams::prog; short chains only — the wide instantiations are not disturbed): the chain has n_done
+    // transitions of the call behind it and runs to the round's target N; records and window counts count from the call's start
+    int64_t n_done = 0;
+    if constexpr (NPL == 1) n_done = P.prog ? (int64_t)P.prog[chain] : 0;
+    const int64_t NN = NPL == 1 ? (P.N > n_done ? P.N - n_done : 0) : P.N;
 
-    if (P.adapt && P.da_init) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
+    if (P.adapt && P.da_init && n_done == 0) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
         double le = det_log_u(eps_fixed);
         da.mu = det_log_u(10.0) + le;
         da.m = 1;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     };
 
     PH_DECL
-    for (int64_t n = 0; n < P.N; ++n) {
+    for (int64_t n = 0; n < NN; ++n) {
         PH(1)   // momentum refresh + transition setup
         const uint32_t tr = tr0 + (uint32_t)n;
         const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
@@ -786,11 +791,11 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         lq_cur = sl_lq.get(init_slot);
         const double pi_stat = sl_pi.get(init_slot);
 
-        const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + n;
+        const size_t o = (size_t)chain * (P.out_stride ? P.out_stride : P.N) + (size_t)(n_done + n);
         // (tried in round 4: the draw stored after the NEXT transition's momentum refresh, so that the proposal slot's round trip
         // runs under it — 3.10e8 against 3.16e8 leapfrog-steps/s on one box, the loads kept in flight across the loop's back edge
         // cost more in waits at the loop head than the round trip they hide)
-        store_draw(n);
+        store_draw(n_done + n);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
             if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273
@@ -823,9 +828,15 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             P.st.da[chain] = da;
             if (P.da_finalize) P.st.eps[chain] = det_exp_u(da.logeps_bar); // final_ϵ (stepsize.jl:170; mcmc.jl:285)
         }
-        P.st.transition[chain] = tr0 + (uint32_t)P.N;
+        P.st.transition[chain] = tr0 + (uint32_t)NN;
         P.st.status[chain] = status;
         if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
+        if constexpr (NPL == 1) {
+            if (P.prog) {
+                P.prog[chain] = (int)(n_done + NN);
+                total_steps += P.chain_work ? (unsigned long long)P.chain_work[chain] : 0ull;    // (a call in rounds adds to the chain's count)
+            }
+        }
         if (P.chain_work) P.chain_work[chain] = (unsigned)(total_steps > 0xffffffffull ? 0xffffffffull : total_steps);
     }
 }

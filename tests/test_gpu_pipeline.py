@@ -183,7 +183,9 @@ def test_engine_choice_after_a_tail_bound_launch(pkg):
 
 @pytest.mark.parametrize("C,env", [(8448, dict(DHMC_HYBRID_SEGMENTS="4")),
                                    (8448, dict(DHMC_HYBRID_SEGMENTS="4", DHMC_HYBRID_BUDGET="0.4", DHMC_HYBRID_DEEP_CAP="1")),
-                                   (700, dict(DHMC_HYBRID_SEGMENTS="3", DHMC_HYBRID_MIN_CHAINS="1", DHMC_HYBRID_BUDGET="0.7", DHMC_PK_MAX_WAVES="8"))])
+                                   (700, dict(DHMC_HYBRID_SEGMENTS="3", DHMC_HYBRID_MIN_CHAINS="1", DHMC_HYBRID_BUDGET="0.7", DHMC_PK_MAX_WAVES="8")),
+                                   (8448, dict(DHMC_HYBRID_SEGMENTS="4", DHMC_HYBRID_BUDGET="0.5", DHMC_HYBRID_DEEP="wave", DHMC_HYBRID_DEEP_CUS="0",
+                                               DHMC_HYBRID_DEEP_CAP="4", DHMC_HYBRID_PROMOTE="1.5"))])
 def test_hybrid_rounds_change_no_result(pkg, capfd, C, env):
     """Many chains and a heavy-tailed tree size: dhmc_run runs the call in rounds — the chains packed through the queue of places, those
     that exceed the round's leapfrog budget given up and continued by the pipeline kernel beside the next round's packed launch.
