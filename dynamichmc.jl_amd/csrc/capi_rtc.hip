@@ -25,10 +25,13 @@ uint64_t rtc_checksum(const char* p, uint64_t n) {      // FNV-1a over the code 
 std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
     const std::string T = "dhmc::" + name, N = std::to_string(npl);
     if (npl >= 32) return {"dhmc::functor_eval_kernel<" + T + ", " + N + ">"};      // beyond 1024 coordinates: the batched evaluation only
-    if (!dense)
-        return {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
-                "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
-                "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
+    if (!dense) {
+        std::vector<std::string> names = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
+                                          "dhmc::init_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_kernel<" + T + ", " + N + ">",
+                                          "dhmc::probe_kernel<" + T + ", " + N + ", false, 0>", "dhmc::probe_kernel<" + T + ", " + N + ", false, 1>"};
+        if (npl <= 2) names.push_back("dhmc::nuts_run_pipeline_kernel<" + T + ", " + N + ">");     // four wavefronts per chain (D <= 128)
+        return names;
+    }
     return {"dhmc::rounds_k0_kernel<" + T + ", " + N + ">", "dhmc::rounds_k2_kernel<" + T + ", " + N + ">",
             (npl >= 8 ? "dhmc::rounds_k3b_kernel<" : "dhmc::rounds_k3_kernel<") + T + ", " + N + ">",
             "dhmc::nuts_run_dense_kernel<" + T + ", " + N + ">", "dhmc::stepsize_search_dense_kernel<" + T + ", " + N + ">",
@@ -41,7 +44,8 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     src += dhmc_rtc_headers;
     src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
     src += source;
-    src += "\n";
+    // the functor's traits for the host (dhmc_create reads the symbol: which kernels may run it)
+    src += "\nextern \"C\" __device__ __attribute__((used)) int dhmc_user_traits = (dhmc::" + name + "::kRecomputeGrad ? 1 : 0) | (dhmc::" + name + "::kBigDims ? 2 : 0);\n";
     const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
     // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
     // whatever device it will run beside them on)

@@ -70,6 +70,13 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
             return launch(R.l1_in_lds ? U.run_lds : U.run, WAVE,
                           (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0)), args);
         }
+        case Op::RunPipeline: {
+            const RunParams& R = *(const RunParams*)P;
+            if (M || !U.pipeline || c->NPL > 2) return DHMC_ERR_UNSUPPORTED;
+            grid = (unsigned)R.C;
+            void* args[] = {const_cast<void*>(P)};
+            return launch(U.pipeline, 4 * WAVE, (unsigned)pipeline_lds_bytes(c->NPL), args);
+        }
         case Op::Init: { grid = (unsigned)((const InitParams*)P)->C; void* args[] = {const_cast<void*>(P)}; return launch(U.init, WAVE, 0, args); }
         case Op::Search: {
             grid = (unsigned)((const SearchParams*)P)->C;
@@ -329,10 +336,21 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
             std::vector<std::string> low;
             if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low))) return fail(rc);
             UserKernels K;
-            auto load = [&]() { return rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio}); };
+            auto load = [&]() {
+                return c->NPL <= 2 ? rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio, &K.pipeline})
+                                   : rtc_load(code, low, &K.mod, {&K.run_lds, &K.run, &K.init, &K.search, &K.probe_traj, &K.probe_ratio});
+            };
             if ((rc = load())) {      // e.g. a cached object of another build of the tool chain: compile afresh once, replacing the file
                 code.clear(); low.clear();
                 if ((rc = rtc_compile(U.source, U.name, c->NPL, false, &code, &low, true)) || (rc = load())) return fail(rc);
+            }
+            {
+                hipDeviceptr_t sym = nullptr;
+                size_t bytes = 0;
+                if (hipModuleGetGlobal(&sym, &bytes, K.mod, "dhmc_user_traits") == hipSuccess && bytes == sizeof(int))
+                    (void)hipMemcpyDtoH(&K.traits, sym, sizeof(int));
+                else
+                    (void)hipGetLastError();
             }
             it = U.built.emplace(key, K).first;
         }
@@ -349,6 +367,11 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         }
         if (user_big) c->user_eval = it->second.eval;       // the streaming engine's kernels are the library's own (ExternalT)
         else c->user = &it->second;
+        // the pipeline kernel for a functor whose gradient is recomputed from a stored position, up to two slots per lane
+        if (c->user && c->user->pipeline && (c->user->traits & 1) && cfg->metric == DHMC_METRIC_DIAG && c->NPL <= 2) {
+            c->pipeline = true;
+            if (const char* e = std::getenv("DHMC_PIPELINE")) { c->pipeline = std::atoi(e) != 0; c->pipeline_force = c->pipeline; }
+        }
     }
     if (cfg->target == DHMC_TARGET_DIAG_NORMAL || cfg->target == DHMC_TARGET_TRIDIAG_NORMAL) {
         std::vector<double> a(Dp, 0.0), b(Dp, 0.0);
@@ -830,6 +853,8 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || (c->tail_bound && !many_chains) || few_chains);
     const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound || many_chains);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
+    if (per_draw_kernel && std::getenv("DHMC_DEBUG_ORDER"))
+        std::fprintf(stderr, "[dhmc] engine: %s (N=%lld, chains %d)\n", pipeline ? "pipeline" : packed ? "packed" : "wave", (long long)N, C);
     // ROUNDS (DHMC_HYBRID=1; off by default): the call in rounds, the bulk packed and the deepest chains in the pipeline kernel beside
     // it on CUs of their own (below, where the rounds are launched).  Chains are independent: which kernel runs which part of a
     // chain changes none of its bits.  Measured at 32768 funnel chains: 9.7e8 against 9.5e8 for one packed launch — the funnel

@@ -75,7 +75,9 @@ constexpr int PIPE_TOP = 64;      // B1's code for "the top-level merge was turn
 
 template <class T, int NPL>
 __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
-    static_assert(T::kRecomputeGrad, "the integrator re-evaluates ∇ℓ at the position the builder hands back");
+    // the integrator re-evaluates ∇ℓ at the position the builder hands back: families that store gradients with their proposals
+    // (T::kRecomputeGrad false) are not launched here (launch_run_pipeline; a caller's functor: dhmc_create reads its traits)
+    if (!T::kRecomputeGrad) return;
     constexpr int DP = WAVE * NPL;
     const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     }
 }
 
+#ifndef __HIPCC_RTC__      // (the host side; a caller's functor is compiled with hiprtc: kernels only)
 template <class T>
 int launch_run_pipeline(const RunParams& P, hipStream_t s) {
     if constexpr (!T::kRecomputeGrad || T::kBigDims) {
@@ -740,4 +743,5 @@ int launch_run_pipeline(const RunParams& P, hipStream_t s) {
     }
 }
 
+#endif
 }  // namespace dhmc

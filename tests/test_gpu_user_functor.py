@@ -180,3 +180,38 @@ def test_code_objects_are_reused_from_the_disk_cache(pkg, tmp_path, monkeypatch)
     assert "loaded from" not in log_c and np.array_equal(a, c)
     d, log_d, _ = run()
     assert "loaded from" in log_d and np.array_equal(a, d)
+
+
+@pytest.mark.parametrize("D", [5, 64, 100, 128])
+def test_user_functor_through_the_pipeline_kernel(pkg, D, monkeypatch, capfd):
+    """A caller's functor (kRecomputeGrad: the gradient is recomputed from a stored position) through the four-wavefront pipeline kernel
+    (DHMC_PIPELINE=1; rows of 64 and 128 doubles): the bits of the wave-per-chain kernel and of the oracle."""
+    rng = np.random.default_rng(D)
+    mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
+    user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
+    C = 5
+
+    def steps(ctx):
+        out = {}
+        ctx.init(); ctx.set_stepsize(0.05)            # small steps: trees of 31 … 255 leapfrogs
+        out["eps0"] = ctx.stepsize()
+        ctx.metric_window_begin()
+        a = ctx.run(25, da={})
+        ctx.update_metric_diag_window()
+        out.update({"w_" + k: v for k, v in a.items()})
+        out.update({"i_" + k: v for k, v in ctx.run(12).items()})
+        q, lq, g = ctx.position()
+        out.update(q=q, lq=lq, g=g, minv=ctx.metric_diag())
+        return out
+    monkeypatch.setenv("DHMC_DEBUG_ORDER", "1")
+    monkeypatch.setenv("DHMC_PIPELINE", "1")
+    a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
+    assert "engine: pipeline" in capfd.readouterr().err
+    monkeypatch.setenv("DHMC_PIPELINE", "0")
+    b = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
+    assert "engine: wave" in capfd.readouterr().err
+    o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3, threads=5))
+    assert a["w_steps"].max() >= 31
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], o[k]), k
