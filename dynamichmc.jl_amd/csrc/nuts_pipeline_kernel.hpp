@@ -727,14 +727,16 @@ int launch_run_pipeline(const RunParams& P, hipStream_t s) {
     if constexpr (!T::kRecomputeGrad || T::kBigDims) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
+        // DHMC_PIPE_LDS_PAD (bytes, timing runs): more LDS per block = fewer chains resident per CU
+        static const size_t pad = [] { const char* e = std::getenv("DHMC_PIPE_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
 #define DHMC_PIPE_LAUNCH(NPL_)                                                                                                  \
     if (P.Dpad == WAVE * NPL_) {                                                                                                \
         static bool once = [] {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)nuts_run_pipeline_kernel<T, NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipeline_lds_bytes(NPL_)); \
+            (void)hipFuncSetAttribute((const void*)nuts_run_pipeline_kernel<T, NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pipeline_lds_bytes(NPL_) + pad)); \
             return true;                                                                                                        \
         }();                                                                                                                    \
         (void)once;                                                                                                             \
-        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T, NPL_>), dim3(P.C), dim3(4 * WAVE), pipeline_lds_bytes(NPL_), s, P);      \
+        hipLaunchKernelGGL((nuts_run_pipeline_kernel<T, NPL_>), dim3(P.C), dim3(4 * WAVE), pipeline_lds_bytes(NPL_) + pad, s, P); \
         return DHMC_OK;                                                                                                         \
     }
         DHMC_PIPE_LAUNCH(1) DHMC_PIPE_LAUNCH(2) DHMC_PIPE_LAUNCH(4)
