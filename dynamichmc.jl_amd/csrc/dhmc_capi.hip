@@ -1309,7 +1309,7 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         // The two kernels on disjoint sets of CUs (DHMC_HYBRID_DEEP_CUS of them for the pipeline blocks): a block of four waves that
         // has to find room between the packed kernel's waves starts when those drain, and one that shares its SIMDs with them is
         // no longer the kernel with the lowest latency.
-        if (e == hipSuccess && c->hybrid_deep_cus > 0 && !c->stream_bulk) {
+        if (e == hipSuccess && c->hybrid_deep_cus > 0 && !c->hybrid_deep_wave && !c->stream_bulk) {      // (the wave kernel as the deep engine sits beside the packed waves)
             const int words = (c->num_cus + 31) / 32;
             std::vector<uint32_t> deep_mask(words, 0u), bulk_mask(words, 0u);
             const int deep_cus = std::min(c->hybrid_deep_cus, c->num_cus / 2);
