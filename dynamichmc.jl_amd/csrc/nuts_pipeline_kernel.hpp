@@ -142,11 +142,18 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     const unsigned long long pt_start = __builtin_readcyclecounter();
 #define PIPE_PT_WAIT_BEGIN const unsigned long long pt_t0 = __builtin_readcyclecounter();
 #define PIPE_PT_WAIT_END pt_wait += __builtin_readcyclecounter() - pt_t0;
+    unsigned long long pt_b2[4] = {0ull, 0ull, 0ull, 0ull}, pt_mark = 0ull;   // B2's leaf loop: record read / cascade / suspension / rest
+#define PIPE_B2_BEGIN pt_mark = __builtin_readcyclecounter();
+#define PIPE_B2_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pt_b2[i] += t_ - pt_mark; pt_mark = t_; }
+#define PIPE_B2_FLUSH if (lane == 0) { atomicAdd(&g_phase[8], pt_b2[0]); atomicAdd(&g_phase[9], pt_b2[1]); atomicAdd(&g_phase[10], pt_b2[2]); atomicAdd(&g_phase[11], pt_b2[3]); }
 #define PIPE_PT_FLUSH(role, leaves) if (lane == 0) { atomicAdd(&g_phase[role], pt_wait); atomicAdd(&g_phase[4 + role], __builtin_readcyclecounter() - pt_start); if (role == 2) { atomicAdd(&g_phase[14], (unsigned long long)(leaves)); atomicAdd(&g_phase[15], 1ull); } }
 #else
 #define PIPE_PT_WAIT_BEGIN
 #define PIPE_PT_WAIT_END
 #define PIPE_PT_FLUSH(role, leaves)
+#define PIPE_B2_BEGIN
+#define PIPE_B2_MARK(i)
+#define PIPE_B2_FLUSH
 #endif
     auto wait_for = [&](auto cond) -> bool {       // bounded spin over one load of all control words per poll; false: give up
         unsigned spins = 0;
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
             bool invalid = false;
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 // the leaf's record (A) and its merge code (B1)
+                PIPE_B2_BEGIN
                 if (!(avail > tail)) {                          // records WITH their codes available at the last poll
                     if (!wait_for([&](const PairCtl& c) { return c.w[W_HEAD] > tail && c.w[W_MSEQ] == want && c.w[W_MHEAD] > tail; })) { finished = true; break; }
                     avail = cw.w[W_HEAD] < cw.w[W_MHEAD] ? cw.w[W_HEAD] : cw.w[W_MHEAD];
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                 i += di;
                 const double delta = pi_leaf - pi0;             // NUTS.jl:150
                 int level = 0;
+                PIPE_B2_MARK(0)
                 if (delta < P.min_delta) {                      // divergent leaf (NUTS.jl:151; trees.jl:236-237)
                     term_left = term_right = i;
                     invalid = true;
@@ -647,11 +656,13 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
                             break;
                         }
                     }
+                    PIPE_B2_MARK(1)
                     if (level >= 0 && !invalid) {
                         if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
                         lv_omega.set(level, c_omega, lane);
                         lv_zeta.set(level, c_zeta, lane);
                     }
+                    PIPE_B2_MARK(2)
                 }
                 if (invalid) finished = true;                              // trees.jl:297 (the visited statistic's unwinding: B3)
             }
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
     if (broken) status |= DHMC_ST_KERNEL_PROTOCOL;
     pair_publish(c_quit, broken ? 2u : 1u, lane);
     PIPE_PT_FLUSH(2, total_steps)
+    PIPE_B2_FLUSH
     stv<NPL>(P.st.q + row, lane, q);
     (void)tgt.eval(q, g, lane, D);
     stv<NPL>(P.st.g + row, lane, g);

@@ -26,3 +26,5 @@ print(f"chains {C} transitions {T} kernel_ms {ms:.3f} leapfrogs {lf} -> {lf / ms
 for r, name in enumerate(("A  integrator", "B1 turn statistics", "B2 proposals", "B3 visited statistic")):
     tot, wait = float(ph[4 + r]), float(ph[r])
     print(f"  {name:20s} {tot / max(leaves, 1):8.0f} clocks per leaf, of which waiting {wait / max(leaves, 1):8.0f} ({100 * wait / max(tot, 1):5.1f} %)  -> busy {(tot - wait) / max(leaves, 1):8.0f}")
+print("  B2's leaf loop, clocks per leaf: record read and bookkeeping %.0f, merge cascade (logaddexp, picks) %.0f, suspension (slot store, level scalars) %.0f"
+      % tuple(float(ph[8 + i]) / max(leaves, 1) for i in range(3)))
