@@ -112,6 +112,8 @@ struct dhmc_ctx {
     int* d_list_packed = nullptr;          // [C] … the round's chains of the packed launch, of the pipeline launch, and those the
     int* d_list_deep = nullptr;            //     packed launch gave up
     int* d_evicted = nullptr;
+    int pk_handover = -1;                  // DHMC_PK_HANDOVER: the end game of a tail-bound packed launch starts at this many live lane groups (0: off; -1: what the pipeline kernel keeps resident)
+    int many_chains_min = 0;               // DHMC_MANY_CHAINS
     int pk_queue = 1;                      // DHMC_PK_QUEUE=0: a packed launch starts a lane group per place (no queue of places)
     int pk_max_waves = 0;                  // DHMC_PK_MAX_WAVES: the waves a queued packed launch starts (0: one per SIMD)
     int tail_count = 0;                    // places at the head of the launch order whose work was far above the median's

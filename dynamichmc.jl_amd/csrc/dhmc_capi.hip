@@ -268,6 +268,8 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if (const char* e = std::getenv("DHMC_PIPELINE")) { c->pipeline = c->pipeline && std::atoi(e) != 0; c->pipeline_force = c->pipeline; }
     if (const char* e = std::getenv("DHMC_PK_QUEUE")) c->pk_queue = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_PK_MAX_WAVES")) c->pk_max_waves = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("DHMC_MANY_CHAINS")) c->many_chains_min = std::max(0, std::atoi(e));     // (tests: the chain count from which a launch counts as throughput-bound)
+    if (const char* e = std::getenv("DHMC_PK_HANDOVER")) c->pk_handover = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("DHMC_HYBRID")) c->hybrid = std::atoi(e) != 0;
     if (const char* e = std::getenv("DHMC_HYBRID_SEGMENTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->hybrid_segments = v; }
     if (const char* e = std::getenv("DHMC_HYBRID_BUDGET")) c->hybrid_budget = std::atof(e);
@@ -297,7 +299,7 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     if ((rc = dev_alloc(c, &c->st.transition, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.status, C))) return fail(rc);
     if ((rc = dev_alloc(c, &c->st.ws, C * (size_t)c->nvec * Dp))) return fail(rc);
-    if ((rc = dev_alloc(c, &c->d_counter, 3))) return fail(rc);      // [0] leapfrog steps of a call; [1] a packed launch's queue of places; [2] the chains it gave up
+    if ((rc = dev_alloc(c, &c->d_counter, 4))) return fail(rc);      // [0] leapfrog steps of a call; [1] a packed launch's queue of places; [2] the chains it gave up; [3] its lane groups that still have a chain
     if ((rc = dev_alloc(c, &c->d_chain_work, (size_t)cfg->chains))) return fail(rc);
     if ((rc = dev_alloc(c, &c->d_launch_order, (size_t)cfg->chains))) return fail(rc);
     if (hipMemset(c->st.q, 0, C * Dp * sizeof(double)) != hipSuccess) return fail(DHMC_ERR_HIP);
@@ -842,14 +844,16 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     // always / never.
     // … and when the chains are so few that each of their four waves gets a SIMD of its own (C <= the number of CUs — the reference's
     // typical handful of chains): such a launch is all latency, whatever its trees look like
-    // … but not when there are so many chains that the launch is bound by throughput again (more than 64 per CU; the pipeline kernel
-    // gives a chain four waves): the packed kernel with its queue of places then.  One call of 1000 transitions of the funnel,
-    // leapfrog steps/s: 4096 chains pipeline 3.5e8, wave 2.0e8, packed 1.7e8; 8192: 4.9e8, 4.0e8, -; 16384: 6.4e8, 6.6e8, 5.4e8;
-    // 32768: 7.0e8, 8.7e8, 9.5e8 (profiles/r05_packed_queue_rounds.txt).
+    // … but not when there are so many chains that throughput counts again (the pipeline kernel gives a chain four waves): the packed
+    // kernel with its queue of places then, and the pipeline kernel for its END GAME (below).  One call of 1000 transitions of the
+    // funnel, leapfrog steps/s: 4096 chains pipeline 3.5e8, packed + end game 3.4e8, wave 2.0e8; 8192: 5.1e8, 5.9e8, 4.0e8; 16384:
+    // 6.4e8, 9.5e8, 6.6e8; 32768: 7.0e8, 1.49e9, 8.7e8 (packed alone 9.5e8) (profiles/r05_packed_queue_rounds.txt): from 24
+    // chains per CU on.  A family without a packed evaluator keeps the wave kernel from 13 chains per pipeline block slot on.
     // … and only when the trees are large: the four waves fill and drain once per transition (≈ 2.5 µs), so 4 chains of a 100-dim
     // standard normal (7 leapfrogs per transition) take 2.1 µs per leapfrog here against 1.5 in the wave kernel, the same chains on
     // a 100-dim funnel (66 per transition) 1.6 against 2.6 (profiles/r05_pipeline_kernel.txt).  From the previous call's mean.
-    const bool few_chains = C <= c->num_cus && c->mean_leapfrogs_per_transition >= 24.0, many_chains = C > 13 * (int)((size_t)160 * 1024 / pipeline_lds_bytes(c->NPL <= 4 ? c->NPL : 4)) * c->num_cus;   // (5, 2 or 1 blocks per CU)
+    const bool few_chains = C <= c->num_cus && c->mean_leapfrogs_per_transition >= 24.0, many_chains = C > (c->many_chains_min > 0 ? c->many_chains_min : c->packed && c->pk_handover != 0 ? 24 * c->num_cus
+                                              : 13 * (int)((size_t)160 * 1024 / pipeline_lds_bytes(c->NPL <= 4 ? c->NPL : 4)) * c->num_cus);   // (5, 2 or 1 blocks per CU)
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || (c->tail_bound && !many_chains) || few_chains);
     const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound || many_chains);
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
@@ -863,6 +867,12 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
     const bool hybrid = per_draw_kernel && c->hybrid && c->packed && c->pipeline && !c->packed_force && !c->pipeline_force &&
                         c->tail_bound && C > (c->hybrid_min_chains > 0 ? c->hybrid_min_chains : 32 * c->num_cus) && N >= 8LL * c->hybrid_segments &&
                         c->d_chain_work && c->launch_order_on;
+    // END GAME of a tail-bound packed launch (many chains: the rule above): once few lane groups still have a chain — no more than the
+    // pipeline kernel keeps resident — the packed kernel gives those chains up at their next transition boundary and the pipeline
+    // kernel finishes them at a third of the latency per leapfrog: the launch's deepest chains, which would otherwise run on alone
+    // at 2.5 µs per trip (RunParams::pk_live, pk_handover_below; DHMC_PK_HANDOVER = the threshold, 0: off).
+    const bool endgame = packed && !hybrid && !c->packed_force && c->pipeline && c->tail_bound && many_chains && c->pk_handover != 0 &&
+                         c->d_chain_work && c->launch_order_on && N >= 32;
     if (packed || hybrid) {
         // LDS: as many suspended levels as the launch's occupancy leaves room for (the kernel runs one wave per SIMD, four per CU;
         // a launch of few waves — one GPU's share of 4096 30-dim chains is 512 — has half of the CU's 160 KB to itself)
@@ -1460,6 +1470,35 @@ int run_call(dhmc_ctx* c, int64_t N, const dhmc_dual_averaging* da, const dhmc_o
         if (e == hipSuccess && !list_deep.empty()) {
             if ((rc = launch_pair(N, 0ull))) { (void)hipDeviceSynchronize(); cleanup(); return rc; }
         }
+    } else if (e == hipSuccess && endgame && nbuf == 1) {
+        if (!c->d_prog) {
+            if ((rc = dev_alloc(c, &c->d_prog, (size_t)C)) || (rc = dev_alloc(c, &c->d_list_packed, (size_t)C)) ||
+                (rc = dev_alloc(c, &c->d_list_deep, (size_t)C)) || (rc = dev_alloc(c, &c->d_evicted, (size_t)C))) { cleanup(); return rc; }
+        }
+        unsigned* const d_evict_count = reinterpret_cast<unsigned*>(c->d_counter + 2);
+        e = hipMemsetAsync(c->d_prog, 0, sizeof(int) * C, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_chain_work, 0, sizeof(unsigned) * C, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_evict_count, 0, sizeof(unsigned), c->stream);
+        RunParams B = P;
+        B.prog = c->d_prog;
+        B.pk_evicted = c->d_evicted;
+        B.pk_evict_count = d_evict_count;
+        B.pk_live = reinterpret_cast<unsigned*>(c->d_counter + 3);
+        // (what the pipeline kernel keeps resident, twice that below 64 chains per CU: 8192 chains 5.9e8 against 5.6e8, 32768 1.43e9 against 1.49e9)
+        B.pk_handover_below = c->pk_handover > 0 ? c->pk_handover : (C >= 64 * c->num_cus ? 5 : 10) * c->num_cus;
+        if (e == hipSuccess && (rc = dispatch(c, Op::RunPacked, &B))) { cleanup(); return rc; }
+        unsigned n_given_up = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_given_up, d_evict_count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && n_given_up > 0) {          // the chains the packed launch gave up, in the order it gave them up
+            RunParams T = B;
+            T.C = (int)n_given_up;
+            T.launch_order = c->d_evicted;
+            T.pk_live = nullptr; T.pk_handover_below = 0;
+            if ((rc = dispatch(c, Op::RunPipeline, &T))) { cleanup(); return rc; }
+        }
+        if (std::getenv("DHMC_DEBUG_ORDER")) std::fprintf(stderr, "[dhmc] end game: %u chains handed to the pipeline kernel\n", n_given_up);
+        if (e == hipSuccess) e = hipGetLastError();
     } else if (e == hipSuccess) {
         rc = dispatch(c, run_op, &P);
         if (rc) { cleanup(); return rc; }

@@ -116,7 +116,11 @@ __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
     typedef dm_vector Pol;
 #define PK_ATOMIC_ADD_ULL(ptr, v) atomicAdd((ptr), (v))
 #define PK_QUEUE_NEXT(ptr) atomicAdd((ptr), 1u)
+#define PK_LOAD_UINT(ptr) __atomic_load_n((ptr), __ATOMIC_RELAXED)
+#define PK_ATOMIC_DEC_UINT(ptr) atomicSub((ptr), 1u)
 #include "packed_body.inc"
+#undef PK_ATOMIC_DEC_UINT
+#undef PK_LOAD_UINT
 #undef PK_QUEUE_NEXT
 #undef PK_ATOMIC_ADD_ULL
 }
@@ -143,6 +147,7 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
         } else {
             Q.pk_queue = nullptr;
         }
+        if (Q.pk_live && hipMemsetD32Async((hipDeviceptr_t)Q.pk_live, waves * gpw, 1, s) != hipSuccess) return DHMC_ERR_HIP;   // every group of the launch
         const dim3 grid((unsigned)waves), block(64);
         const size_t lds = pk::lds_bytes_per_wave(L, cpl, P.max_depth, P.pk_lds_levels);
 #define DHMC_PK_LAUNCH(LL, CC)                                                                                                 \

@@ -102,6 +102,12 @@ struct RunParams {
     unsigned long long pk_budget;
     int* pk_evicted;
     unsigned* pk_evict_count;
+    // The end game of a packed launch: pk_live counts the lane groups that still have a chain (the host sets it to the groups the
+    // launch starts; a group that finds no place left takes itself off).  Once it is at or below pk_handover_below (0: never),
+    // every group gives its chain up at the next transition boundary (through pk_evicted, like the budget), and the host finishes
+    // those chains — the launch's deepest, by then — with the pipeline kernel at a third of the latency per leapfrog.
+    unsigned* pk_live;
+    int pk_handover_below;
 };
 
 // the pipeline kernel's LDS (nuts_pipeline_kernel.hpp; the host sizes launches and engine choices with it)

@@ -32,10 +32,14 @@ static void run_chain(const RunParams& P, int place, double* lds_cold, double* l
     typedef dm_generic Pol;
 #define PK_ATOMIC_ADD_ULL(ptr, v) (*(ptr) += (v))
 #define PK_QUEUE_NEXT(ptr) ((*(ptr))++)
+#define PK_LOAD_UINT(ptr) (*(ptr))
+#define PK_ATOMIC_DEC_UINT(ptr) ((*(ptr))--)
 #define PK_PH_DECL
 #define PK_PH_END(i)
 #define PK_PH_FLUSH(t)
 #include "../../dynamichmc.jl_amd/csrc/packed_body.inc"
+#undef PK_ATOMIC_DEC_UINT
+#undef PK_LOAD_UINT
 #undef PK_QUEUE_NEXT
 #undef PK_ATOMIC_ADD_ULL
 }

@@ -39,7 +39,8 @@ class RunParams(C.Structure):      # csrc/run_params.hpp, field for field
                 ("leapfrog_counter", P), ("win_mean", P), ("win_m2", P), ("win_n0", C.c_int64), ("chain_work", P), ("launch_order", P),
                 ("pk_lds_levels", C.c_int), ("pk_align", C.c_int), ("pk_cpl", C.c_int), ("pk_order_base", C.c_int),
                 ("pk_queue", C.c_void_p), ("pk_max_waves", C.c_int),
-                ("prog", P), ("pk_budget", C.c_uint64), ("pk_evicted", P), ("pk_evict_count", P)]
+                ("prog", P), ("pk_budget", C.c_uint64), ("pk_evicted", P), ("pk_evict_count", P),
+                ("pk_live", P), ("pk_handover_below", C.c_int)]
 
 
 DA_DTYPE = np.dtype([("mu", "f8"), ("Hbar", "f8"), ("logeps", "f8"), ("logeps_bar", "f8"), ("m", "i8")])
@@ -110,7 +111,7 @@ class HostSim:
         self.win, self.win_n = None, -1
 
     def _launch(self, out, N, N_total, da, queue, order, prog=None, budget=0, evicted=None, evict_count=None, chain_work=None,
-                leap_total=None):
+                leap_total=None, live=None, handover_below=0):
         """One launch of the simulated kernel: the places of `order` (default: every chain) up to transition N of the call."""
         R = RunParams()
         R.D, R.Dpad, R.chain_offset, R.max_depth = self.D, 64, self.chain_offset, self.max_depth
@@ -139,6 +140,7 @@ class HostSim:
         if prog is not None:
             R.prog, R.pk_budget = _p(prog), budget
             R.pk_evicted, R.pk_evict_count, R.chain_work = _p(evicted), _p(evict_count), _p(chain_work)
+            R.pk_live, R.pk_handover_below = _p(live), handover_below
         rc = lib().hostsim_packed_run(self.target, C.byref(R), int(queue), self.C)
         assert rc == 0, rc
 
@@ -185,3 +187,26 @@ class HostSim:
         if self.win is not None:
             self.win_n += N
         return out, given_up
+
+    def run_handover(self, N, da=None):
+        """The end game of a packed launch (RunParams::pk_live, pk_handover_below) at its extreme: one lane group, hand-over threshold
+        one — every launch gives a chain up after one transition, and the call is N launches over the chains that are left (the
+        device hands the chains it gives up to the pipeline kernel).  Returns the outputs and the number of launches."""
+        out = self._outputs(N)
+        self.leapfrogs[:] = 0
+        prog = np.zeros(self.C, np.int32)
+        work = np.zeros(self.C, np.uint32)
+        evicted, count, live = np.zeros(self.C, np.int32), np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+        left = np.arange(self.C, dtype=np.int32)[::-1].copy()
+        launches = 0
+        while len(left):
+            count[:] = 0
+            live[:] = 1
+            self._launch(out, N, N, da, True, left, prog, 0, evicted, count, work, live=live, handover_below=1)
+            left = np.sort(evicted[:int(count[0])]).astype(np.int32)
+            launches += 1
+            assert launches <= N + 1
+        assert (prog == N).all() and int(work.sum()) == int(self.leapfrogs[0]) == int(out["steps"].sum())
+        if self.win is not None:
+            self.win_n += N
+        return out, launches

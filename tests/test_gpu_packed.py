@@ -206,3 +206,41 @@ def test_queue_of_places_matches_oracle(pkg, D, C, cpl, waves):
     assert np.array_equal(dev.status(), ora.status())
     for x, y in zip(dev.position(), ora.position()):
         assert np.array_equal(x, y)
+
+
+def test_end_game_of_a_tail_bound_packed_launch(pkg, capfd):
+    """Many chains, a heavy-tailed tree size: the packed launch gives up the chains that are still running when few lane groups have
+    one left, and the pipeline kernel finishes them (dhmc_run, RunParams::pk_live).  Thresholds lowered so that 600 chains do it; the
+    bits of a context without the hand-over and of the oracle."""
+    D, C = 30, 600
+    os.environ.pop("DHMC_PACKED", None)
+    res = []
+    for env in (dict(DHMC_MANY_CHAINS=100, DHMC_PK_HANDOVER=60, DHMC_PK_MAX_WAVES=24, DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000),
+                dict(DHMC_MANY_CHAINS=100, DHMC_PK_HANDOVER=0, DHMC_PK_MAX_WAVES=24, DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000)):
+        with _env(**env):
+            dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=17)
+            dev.init(); dev.find_initial_stepsize()
+            out = [dev.run(40, da={})]
+            dev.metric_window_begin()
+            out.append(dev.run(48, da={}))
+            dev.update_metric_diag_window()
+            out.append(dev.run(64))
+            out.append(dev.run(35, da=dict(init=0, finalize=1)))
+        res.append((out, dev.metric_diag(), dev.stepsize(), dev.position(), capfd.readouterr().err))
+    handed = [int(l.split("end game: ")[1].split()[0]) for l in res[0][4].splitlines() if "end game:" in l]
+    assert handed and max(handed) > 0, res[0][4][-600:]
+    assert "end game:" not in res[1][4] and "engine: packed" in res[1][4]
+    for a, b in zip(res[0][0], res[1][0]):
+        _same(a, b, "hand-over vs one kernel")
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    for x, y in zip(res[0][3], res[1][3]):
+        assert np.array_equal(x, y)
+    ora = ol.Oracle(D, 24, target=ol.TARGET_FUNNEL, seed=17, threads=8)
+    ora.init(); ora.find_initial_stepsize()
+    b0 = ora.run(40, da={})
+    ora.metric_window_begin(); b1 = ora.run(48, da={}); ora.update_metric_diag_window()
+    b2 = ora.run(64)
+    b3 = ora.run(35, da=dict(init=0, finalize=1))
+    for a, b in zip(res[0][0], (b0, b1, b2, b3)):
+        for k in a:
+            assert np.array_equal(a[k][:24], b[k]), k
