@@ -128,12 +128,13 @@ def test_rounds_with_a_leapfrog_budget_change_no_result(queue):
     assert np.array_equal(sim.eps, ora.stepsize())
 
 
-def test_end_game_hand_over_changes_no_result():
+@pytest.mark.parametrize("target,D", [(ol.TARGET_FUNNEL, 30), (ol.TARGET_STD_NORMAL, 7)])
+def test_end_game_hand_over_changes_no_result(target, D):
     # a launch that gives its chains up once few lane groups still have one (here: always), continued by later launches
-    D, C, N = 30, 7, 23
+    C, N = 7, 23
     rng = np.random.default_rng(8)
     q0 = rng.normal(size=(C, D)) * 0.2
-    ora, sim = _pair(D, C, ol.TARGET_FUNNEL, seed=31, eps=0.3, q0=q0)
+    ora, sim = _pair(D, C, target, seed=31, eps=0.3, q0=q0)
     for stage, da in enumerate((dict(), None)):
         a, launches = sim.run_handover(N, da=da)
         _same(a, ora.run(N, da=da), f"stage {stage}")
