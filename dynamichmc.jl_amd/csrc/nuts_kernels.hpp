@@ -124,7 +124,7 @@ __device__ __forceinline__ double demote_lq(double lq, bool pos_finite, bool gra
 // (four values instead of two, one reduction latency instead of two; the suspended row's LDS round trip runs under the
 // leapfrog's arithmetic).  Same operations on the same operands, value by value, so the same bits as the separate merge; if the
 // leaf turns out divergent the merge's result is simply not looked at (cf / cr are dead then).
-template <class T, int NPL, class MK, class PA0>
+template <class T, int NPL, bool XL = false, class MK, class PA0>
 __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, int D,
                                                 double (&q)[NPL], double (&p)[NPL], double (&g)[NPL],
                                                 double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl,
@@ -147,6 +147,9 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
     for (int k = 0; k < NPL; ++k) {
         p[k] = p[k] + h * g[k];                      // :280
         double ps = mk_(k) * p[k];                   // p♯ = M⁻¹ p'
+#ifdef DHMC_OPAQUE_PS
+        asm volatile("" : "+v"(ps));                 // not kept for the merge that may follow (an AGPR round trip costs more than the product)
+#endif
         kacc.add(0, k, p[k], ps);
         DHMC_BLOCK_FENCE(k);
     }
@@ -166,25 +169,25 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
         }
         if constexpr (T::kDeferred) {
             double r[4] = {lres, kacc.fold(0), A.fold(0), A.fold(1)};
-            wave_allreduce<4>(r, nl);
+            wave_totals<4, XL>(r, nl);
             lq = tgt.finish(r[0]);
             K = r[1] / 2.0;
             turning0 = r[2] < 0 || r[3] < 0;
         } else {
             double r[3] = {kacc.fold(0), A.fold(0), A.fold(1)};
-            wave_allreduce<3>(r, nl);
+            wave_totals<3, XL>(r, nl);
             lq = lres;
             K = r[0] / 2.0;
             turning0 = r[1] < 0 || r[2] < 0;
         }
     } else if constexpr (T::kDeferred) {
         double r[2] = {lres, kacc.fold(0)};
-        wave_allreduce<2>(r, nl);
+        wave_totals<2, XL>(r, nl);
         lq = tgt.finish(r[0]);
         K = r[1] / 2.0;
     } else {
         lq = lres;
-        K = wave_allreduce1(kacc.fold(0), nl) / 2.0;
+        K = wave_total1<XL>(kacc.fold(0), nl) / 2.0;
     }
     // evaluate_ℓ's checks (hamiltonian.jl:203-211).  Every shipped family has "ℓq finite =>
     // all q finite" (kFiniteLqImpliesFiniteQ), so the coordinate scan runs only on the rare
@@ -206,6 +209,12 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
 // Measured (round 4, D = 1000 × 4096 chains, same box): 3.19e8 leapfrog-steps/s without the fusion, 3.01e8 with it — the merge's
 // rows live through the density evaluation and the allocator pays in AGPR moves (the leaf region +650 clocks per leapfrog, the
 // merges −315): bit-exact, slower, off.  -DDHMC_FUSE_LEAF_MERGE0 builds it.
+// The permuted wave of wave.hpp ("the same tree on a permuted wave") for coordinate-wise targets of 128+ coordinates; -DDHMC_XL=0
+// builds the plain lane order (A/B timing).
+#ifndef DHMC_XL
+#define DHMC_XL 1
+#endif
+constexpr bool kXlLanes = DHMC_XL != 0;
 #ifdef DHMC_FUSE_LEAF_MERGE0
 constexpr bool kFuseLeafMerge0 = true;
 #else
@@ -218,7 +227,7 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
                                                 double eps, double& lq_out, double& pi_out, bool& pos_finite, int nl = 64) {
     double cf_[NPL], cr_[NPL];
     bool t0;
-    leapfrog_leaf_m<T, NPL>(tgt, mk_, lane, D, q, p, g, eps, lq_out, pi_out, pos_finite, nl, false, [](int) { return 0.0; }, cf_, cr_, t0);
+    leapfrog_leaf_m<T, NPL, false>(tgt, mk_, lane, D, q, p, g, eps, lq_out, pi_out, pos_finite, nl, false, [](int) { return 0.0; }, cf_, cr_, t0);
 }
 
 // M⁻¹ staged in LDS (or any lane-strided row)
@@ -233,7 +242,7 @@ __device__ __forceinline__ void leapfrog_leaf(const T& tgt, const double* __rest
 // (trees.jl:135-141): x = earlier in time, y = later, each given as accessors k -> slot k of
 // its (p₋, p₊, ρ).  nf(k) is what becomes the merged summary's build-order first momentum.
 // On return cf = nf, cr = ρ of the merge.  Returns turning.
-template <int NPL, class XM, class XP, class XR, class YM, class YP, class YR, class NF, class MK>
+template <int NPL, bool XL = false, class XM, class XP, class XR, class YM, class YP, class YR, class NF, class MK>
 __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp_, YR yr_, NF nf_, MK mk_,
                                            double (&cf)[NPL], double (&cr)[NPL], int nl = 64) {
     LaneAcc<6, NPL> A;
@@ -262,8 +271,14 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
     }
     double acc[6];
     A.fold_all(acc);
-    wave_allreduce<6>(acc, nl);
-    return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
+    if constexpr (XL) {                  // only the signs are asked for: no total leaves the vector unit (wave.hpp)
+        double u[2];
+        xl_reduce<6>(acc, u);
+        return xl_any_negative<6>(u);
+    } else {
+        wave_allreduce<6>(acc, nl);
+        return acc[0] < 0 || acc[1] < 0 || acc[2] < 0 || acc[3] < 0 || acc[4] < 0 || acc[5] < 0;
+    }
 }
 
 // The same merge when BOTH subtrees are single leaves with momenta pa (suspended) and pb
@@ -271,7 +286,7 @@ __device__ __forceinline__ bool merge_core(XM xm_, XP xp_, XR xr_, YM ym_, YP yp
 // all pa + pb (IEEE addition commutes, so the build direction does not matter) and the six
 // dots are two distinct values, (M⁻¹pa)·ρ and (M⁻¹pb)·ρ, each appearing three times: the
 // result is bit-identical to merge_core.  Half of all merges of a tree are of this kind.
-template <int NPL, class PA, class MK>
+template <int NPL, bool XL = false, class PA, class MK>
 __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
                                                 double (&cf)[NPL], double (&cr)[NPL], const double (&pb)[NPL], int nl = 64) {
     LaneAcc<2, NPL> A;
@@ -288,8 +303,14 @@ __device__ __forceinline__ bool merge_leaf_leaf(PA pa_, MK mk_,
     }
     double acc[2];
     A.fold_all(acc);
-    wave_allreduce<2>(acc, nl);
-    return acc[0] < 0 || acc[1] < 0;
+    if constexpr (XL) {
+        double u[1];
+        xl_reduce<2>(acc, u);
+        return xl_any_negative<2>(u);
+    } else {
+        wave_allreduce<2>(acc, nl);
+        return acc[0] < 0 || acc[1] < 0;
+    }
 }
 
 // The two logaddexp's of a merge (visited statistic and ω).  Wave-uniform arguments: each is ≈ 20 vector instructions with its
@@ -302,6 +323,22 @@ __device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, 
     r1 = uni_f64(v1);
     r2 = uni_f64(v2);
 }
+
+// The softplus rows of a merge's logaddexp pair, requested BEFORE the merge's vector part: the arguments (the suspended level's
+// and the running subtree's ω and visited statistic) are known then, the rows are not needed for another ≈ 1 500 clocks, and the
+// scalar cache misses often enough (four chains per CU walk a 16 KB table among other tables) that the pair's two dependent
+// scalar loads were exposed L2 round trips.  One dword of each row is loaded into a scalar register that is kept until the
+// retiring s_waitcnt; the pair's own loads of the rows then hit the scalar cache.  Changes no value.
+struct LaePrefetch { uint32_t t1, t2; };
+__device__ __forceinline__ LaePrefetch lae_prefetch(double a1, double b1, double a2, double b2) {
+    const double d1 = __builtin_fabs(a1 - b1), d2 = __builtin_fabs(a2 - b2);
+    const int i1 = dm_u::idx((d1 < 16.0) ? (int)(d1 * 16.0) : 0), i2 = dm_u::idx((d2 < 16.0) ? (int)(d2 * 16.0) : 0);
+    LaePrefetch f;
+    asm volatile("s_load_dword %0, %1, 0x0 ; dhmc_pf_s" : "=s"(f.t1) : "s"(&DM_SOFTPLUS_TBL[i1][0]));
+    asm volatile("s_load_dword %0, %1, 0x0 ; dhmc_pf_s" : "=s"(f.t2) : "s"(&DM_SOFTPLUS_TBL[i2][0]));
+    return f;
+}
+__device__ __forceinline__ void lae_prefetch_retire(const LaePrefetch& f) { asm volatile("s_waitcnt lgkmcnt(0) ; dhmc_pf_s_retire %0 %1" :: "s"(f.t1), "s"(f.t2)); }
 
 // p = W .* randn (hamiltonian.jl:124) from the chain's stream.  The Box–Muller pairs are taken in batches of four: Philox and the
 // argument reductions of the whole batch first, then ALL its table rows (log cell, sin/cos cell: per-lane gathers) and W
@@ -372,7 +409,13 @@ __device__ unsigned long long g_phase[16];
 template <class T, int NPL, bool L1LDS>
 __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kernel(RunParams P) {
     const int chain = P.launch_order ? P.launch_order[blockIdx.x] : (int)blockIdx.x;
-    const int lane = threadIdx.x;
+    // XL (wave.hpp, "the same tree on a permuted wave"): hardware lane `plane` holds the coordinates of LOGICAL lane `lane`.
+    // Rule: whatever the ABI lays out — the chain's state, outputs, window moments, the random stream's coordinate counters, the
+    // target's parameters — is indexed by `lane`; the kernel's own rows (LDS, workspace), its lane arrays and its Exp(1) buffer
+    // by `plane`.
+    constexpr bool XL = kXlLanes && T::kElementwise && NPL >= 2;
+    const int plane = threadIdx.x;
+    const int lane = XL ? xl_logical_lane(plane) : plane;
     const int D = P.D, Dpad = P.Dpad;
 
     extern __shared__ double lds[];
@@ -401,16 +444,29 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     } else {
         const double* mrow = P.st.minv + row;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) m_lds[lane + WAVE * k] = mrow[lane + WAVE * k];
+        for (int k = 0; k < NPL; ++k) m_lds[plane + WAVE * k] = mrow[lane + WAVE * k];
     }
     auto mk = [&](int k) -> double {                       // slot k of M⁻¹
         if constexpr (TPL) return mreg[k];
-        else return m_lds[lane + WAVE * k];
+        else return m_lds[plane + WAVE * k];
     };
     const double* Wrow = P.st.W + row;
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     const int max_depth = P.max_depth;
     const int nslots = ws_nslots(max_depth);
+#ifdef DHMC_PF_ROWS
+    constexpr bool PFR = NPL >= 4;                         // workspace rows pulled back into L2 ahead of their use (wave.hpp prefetch_row)
+#else
+    constexpr bool PFR = false;
+#endif
+#ifdef DHMC_PF_LAE
+    constexpr bool PFL = true;
+#else
+    constexpr bool PFL = false;
+#endif
+    PrefetchToken pft;
+    if constexpr (PFR) prefetch_token_init(pft);
+    const int pf_lines = Dpad / 16;                        // 128-byte lines of a row
     const int nl = uni_i32(reduce_lanes(NPL, D));          // lanes that can hold nonzero partial sums (wave.hpp wave_allreduce)
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
@@ -423,15 +479,21 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     double* const tpm_ws = ws + (size_t)ws_edge(0, 1) * Dpad;
     double* const tpp_ws = ws + (size_t)ws_edge(1, 1) * Dpad;
     double* const trho_ws = ws + (size_t)ws_rho_top() * Dpad;
-    double tpm[(TPL || TWS) ? 1 : NPL], tpp[(TPL || TWS) ? 1 : NPL], trho[TWS ? 1 : NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+#ifdef DHMC_TRHO_AGPR
+    constexpr bool TRA = TPL;                               // the trajectory's ρ parked in accumulation registers (wave.hpp AccRow)
+#else
+    constexpr bool TRA = false;
+#endif
+    double tpm[(TPL || TWS) ? 1 : NPL], tpp[(TPL || TWS) ? 1 : NPL], trho[(TWS || TRA) ? 1 : NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
+    AccRow<TRA ? NPL : 1> trho_a;
     auto a_tm = [&](int k) -> double {
-        if constexpr (TPL) return tpm_lds[lane + WAVE * k];
-        else if constexpr (TWS) return tpm_ws[lane + WAVE * k];
+        if constexpr (TPL) return tpm_lds[plane + WAVE * k];
+        else if constexpr (TWS) return tpm_ws[plane + WAVE * k];
         else return tpm[k];
     };
     auto a_tp = [&](int k) -> double {
-        if constexpr (TPL) return tpp_lds[lane + WAVE * k];
-        else if constexpr (TWS) return tpp_ws[lane + WAVE * k];
+        if constexpr (TPL) return tpp_lds[plane + WAVE * k];
+        else if constexpr (TWS) return tpp_ws[plane + WAVE * k];
         else return tpp[k];
     };
     ldv<NPL>(P.st.q + row, lane, q);
@@ -459,18 +521,18 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 
     // the chain's current position occupies proposal slot `init_slot` of the workspace
     int init_slot = 0;
-    stv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
-    if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+    stv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), plane, q);
+    if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), plane, g);
 
     // write a leaf held in registers into a fresh proposal slot
     uint64_t free_mask = 0;
     auto save_leaf = [&](double lq_leaf, double pi_leaf) -> int {
         int s = __builtin_ctzll(free_mask);
         free_mask &= ~(1ull << s);
-        stv<NPL>(wsv(ws_slot(max_depth, s, 0)), lane, q);
-        if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, s, 1)), lane, g);
-        sl_lq.set(s, lq_leaf, lane);
-        sl_pi.set(s, pi_leaf, lane);
+        stv<NPL>(wsv(ws_slot(max_depth, s, 0)), plane, q);
+        if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_slot(max_depth, s, 1)), plane, g);
+        sl_lq.set(s, lq_leaf, plane);
+        sl_pi.set(s, pi_leaf, plane);
         return s;
     };
 
@@ -505,33 +567,36 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             LaneAcc<1, NPL> kacc;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) kacc.add(0, k, p[k], mk(k) * p[k]);
-            pi0 = uni_f64(joint_logdensity(lq_cur, wave_allreduce1(kacc.fold(0), nl) / 2.0));
+            pi0 = uni_f64(joint_logdensity(lq_cur, wave_total1<XL>(kacc.fold(0), nl) / 2.0));
         }
         // leaf τ of z₀ (NUTS.jl:120-123)
         if constexpr (TPL) {
-            stv<NPL>(tpm_lds, lane, p);
-            stv<NPL>(tpp_lds, lane, p);
+            stv<NPL>(tpm_lds, plane, p);
+            stv<NPL>(tpp_lds, plane, p);
         } else if constexpr (TWS) {
-            stv<NPL>(tpm_ws, lane, p);
-            stv<NPL>(tpp_ws, lane, p);
-            stv<NPL>(trho_ws, lane, p);
+            stv<NPL>(tpm_ws, plane, p);
+            stv<NPL>(tpp_ws, plane, p);
+            stv<NPL>(trho_ws, plane, p);
         } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; }
         }
-        if constexpr (!TWS) {
+        if constexpr (TRA) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) trho_a.set(k, p[k]);
+        } else if constexpr (!TWS) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) trho[k] = p[k];
         }
-        sl_lq.set(init_slot, lq_cur, lane);
-        sl_pi.set(init_slot, pi0, lane);
+        sl_lq.set(init_slot, lq_cur, plane);
+        sl_pi.set(init_slot, pi0, plane);
 
         // Exp(1) draws of this transition, 64 at a time: lane l holds draw (rexp_base + l)
         uint32_t nrand = 0, rexp_base = 0;
         double rexp_vals;
         auto rexp_fill = [&](uint32_t base) {
             uint64_t r1, r2;
-            stream_raw64(key, base + (uint32_t)lane, PURPOSE_TREE, tr, r1, r2);
+            stream_raw64(key, base + (uint32_t)plane, PURPOSE_TREE, tr, r1, r2);
             rexp_vals = det_randexp_v(r1);
             rexp_base = base;
         };
@@ -566,17 +631,17 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             PH(2)   // edge switch
             if (reg_edge != 2 && reg_edge != dir) {
                 // park the edge we leave ...
-                stv<NPL>(wsv(ws_edge(reg_edge, 0)), lane, q);
-                if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_edge(reg_edge, 2)), lane, g);
+                stv<NPL>(wsv(ws_edge(reg_edge, 0)), plane, q);
+                if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_edge(reg_edge, 2)), plane, g);
                 if (reg_edge == 1) stored1 = true; else stored0 = true;
                 // ... and fetch the one we extend now
                 const bool have = fwd ? stored1 : stored0;
                 const int qsrc = have ? ws_edge(dir, 0) : ws_slot(max_depth, init_slot, 0);
                 const int gsrc = have ? ws_edge(dir, 2) : ws_slot(max_depth, init_slot, 1);
-                ldv<NPL>(wsv(qsrc), lane, q);
+                ldv<NPL>(wsv(qsrc), plane, q);
                 if constexpr (T::kPointwiseGrad) {}
                 else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-                else ldv<NPL>(wsv(gsrc), lane, g);
+                else ldv<NPL>(wsv(gsrc), plane, g);
                 if (fwd) {
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) p[k] = a_tp(k);
@@ -586,6 +651,15 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 }
             }
             reg_edge = dir;
+            if constexpr (PFR) {
+                // the next doubling's direction is known (the word of directions): if it extends the other edge, its parked
+                // position comes back from the workspace then — ask for it now
+                const int ndir = (int)(dirs & 1u);
+                if (depth + 1 < max_depth && ndir != dir) {
+                    const bool have = ndir ? stored1 : stored0;
+                    prefetch_row(pft, wsv(have ? ws_edge(ndir, 0) : ws_slot(max_depth, init_slot, 0)), plane, pf_lines);
+                }
+            }
             int64_t i = fwd ? i_plus : i_minus;
             const int64_t di = fwd ? 1 : -1;
             const double eps_s = fwd ? eps : -eps;
@@ -598,10 +672,27 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
+                if constexpr (PFR) {
+                    // the cascade of leaf j merges the suspended levels 0 .. (trailing ones of j) - 1: those kept in the workspace
+                    // are asked for before the leapfrog
+                    constexpr int FIRST_WS = L1LDS ? 2 + NXL : 1;
+                    const int t1 = __builtin_ctz(~j);
+                    for (int l2 = FIRST_WS; l2 < t1; ++l2) {
+                        prefetch_row(pft, wsv(ws_stack(l2, 0)), plane, pf_lines);
+                        prefetch_row(pft, wsv(ws_stack(l2, 1)), plane, pf_lines);
+                        prefetch_row(pft, wsv(ws_stack(l2, 2)), plane, pf_lines);
+                    }
+                }
                 PH(3)   // leaf
                 bool turning0;
-                leapfrog_leaf_m<T, NPL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl, kFuseLeafMerge0 && (j & 1u) != 0,
-                                        [&](int k) { return l0_lds[lane + WAVE * k]; }, cf, cr, turning0);
+#ifdef DHMC_KILL_SUMMARY
+                // the running summary of the previous leaf's cascade was suspended (or discarded) there: tell the register allocator
+                // that its rows do not live through the leapfrog (a definition without an instruction)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) { asm volatile("" : "=v"(cf[k])); asm volatile("" : "=v"(cr[k])); }
+#endif
+                leapfrog_leaf_m<T, NPL, XL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl, kFuseLeafMerge0 && (j & 1u) != 0,
+                                            [&](int k) { return l0_lds[plane + WAVE * k]; }, cf, cr, turning0);
                 PH(4)   // leaf scalars
                 if (!pos_finite) status |= DHMC_ST_NONFINITE_POSITION;
                 i += di;
@@ -624,38 +715,42 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         auto a_p = [&](int k) { return p[k]; };
                         auto a_cr = [&](int k) { return cr[k]; };
                         bool turning;
+                        LaePrefetch lpf;
+                        if constexpr (PFL) lpf = sub ? lae_prefetch(lv_vlsa.get(level), v_lsa, lv_omega.get(level), c_omega)
+                                                     : lae_prefetch(vtop_lsa, v_lsa, omega_top, c_omega);
                         PH(5)   // merge, vector part
                         if (sub) {
                             if (level == 0) {
                                 if constexpr (kFuseLeafMerge0) turning = turning0;      // taken with the leaf's own reduction (leapfrog_leaf_m)
-                                else turning = merge_leaf_leaf<NPL>([&](int k) { return l0_lds[lane + WAVE * k]; }, mk, cf, cr, p, nl);
+                                else turning = merge_leaf_leaf<NPL, XL>([&](int k) { return l0_lds[plane + WAVE * k]; }, mk, cf, cr, p, nl);
                             } else if (L1LDS && level == 1) {
-                                auto a_lf = [&](int k) { return l1f_lds[lane + WAVE * k]; };
-                                auto a_ll = [&](int k) { return l1l_lds[lane + WAVE * k]; };
-                                auto a_lr = [&](int k) { return l1f_lds[lane + WAVE * k] + l1l_lds[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
+                                auto a_lf = [&](int k) { return l1f_lds[plane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return l1l_lds[plane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return l1f_lds[plane + WAVE * k] + l1l_lds[plane + WAVE * k]; };
+                                turning = fwd ? merge_core<NPL, XL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL, XL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             } else if (NXL > 0 && level < 2 + NXL) {
                                 const double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
                                 const double* Ll = Lf + Dpad;
                                 const double* Lr = Ll + Dpad;
-                                auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
-                                auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
-                                auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
+                                auto a_lf = [&](int k) { return Lf[plane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return Ll[plane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return Lr[plane + WAVE * k]; };
+                                turning = fwd ? merge_core<NPL, XL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL, XL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             } else {
                                 const double* Lf = wsv(ws_stack(level, 0));
                                 const double* Ll = wsv(ws_stack(level, 1));
                                 const double* Lr = wsv(ws_stack(level, 2));
-                                auto a_lf = [&](int k) { return Lf[lane + WAVE * k]; };
-                                auto a_ll = [&](int k) { return Ll[lane + WAVE * k]; };
-                                auto a_lr = [&](int k) { return Lr[lane + WAVE * k]; };
-                                turning = fwd ? merge_core<NPL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
+                                auto a_lf = [&](int k) { return Lf[plane + WAVE * k]; };
+                                auto a_ll = [&](int k) { return Ll[plane + WAVE * k]; };
+                                auto a_lr = [&](int k) { return Lr[plane + WAVE * k]; };
+                                turning = fwd ? merge_core<NPL, XL>(a_lf, a_ll, a_lr, a_cf, a_p, a_cr, a_lf, mk, cf, cr, nl)
+                                              : merge_core<NPL, XL>(a_p, a_cf, a_cr, a_ll, a_lf, a_lr, a_lf, mk, cf, cr, nl);
                             }
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
                             PH(6)   // merge, scalar part
+                            if constexpr (PFL) lae_prefetch_retire(lpf);
                             const double wl = lv_omega.get(level);
                             double w;
                             logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
@@ -683,17 +778,19 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             // top level (trees.jl:294-316): merge with τ of the whole trajectory, which is
                             // time-ordered (tpm, tpp, trho) whatever the direction
                             auto a_tr = [&](int k) -> double {
-                                if constexpr (TWS) return trho_ws[lane + WAVE * k];
+                                if constexpr (TWS) return trho_ws[plane + WAVE * k];
+                                else if constexpr (TRA) return trho_a.get(k);
                                 else return trho[k];
                             };
                             if (depth == 0) {
-                                turning = merge_leaf_leaf<NPL>(a_tr, mk, cf, cr, p, nl);
+                                turning = merge_leaf_leaf<NPL, XL>(a_tr, mk, cf, cr, p, nl);
                             } else {
-                                turning = fwd ? merge_core<NPL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr, nl)
-                                              : merge_core<NPL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr, nl);
+                                turning = fwd ? merge_core<NPL, XL>(a_tm, a_tp, a_tr, a_cf, a_p, a_cr, a_cf, mk, cf, cr, nl)
+                                              : merge_core<NPL, XL>(a_p, a_cf, a_cr, a_tm, a_tp, a_tr, a_cf, mk, cf, cr, nl);
                             }
                             double w;
                             PH(6)
+                            if constexpr (PFL) lae_prefetch_retire(lpf);
                             logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
                             vtop_steps += v_steps;
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
@@ -715,10 +812,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             } else if (depth < max_depth) {
                                 // τ of the doubled trajectory: the new edge momentum and Σp
                                 if constexpr (TPL) {
-                                    stv<NPL>(fwd ? tpp_lds : tpm_lds, lane, p);
+                                    stv<NPL>(fwd ? tpp_lds : tpm_lds, plane, p);
                                 } else if constexpr (TWS) {
-                                    stv<NPL>(fwd ? tpp_ws : tpm_ws, lane, p);
-                                    stv<NPL>(trho_ws, lane, cr);
+                                    stv<NPL>(fwd ? tpp_ws : tpm_ws, plane, p);
+                                    stv<NPL>(trho_ws, plane, cr);
                                 } else if (fwd) {
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) tpp[k] = p[k];
@@ -726,7 +823,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) tpm[k] = p[k];
                                 }
-                                if constexpr (!TWS) {
+                                if constexpr (TRA) {
+#pragma unroll
+                                    for (int k = 0; k < NPL; ++k) trho_a.set(k, cr[k]);
+                                } else if constexpr (!TWS) {
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) trho[k] = cr[k];
                                 }
@@ -740,24 +840,24 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         // suspend the running subtree at `level` until its right sibling is built
                         if (c_zeta < 0) c_zeta = save_leaf(lq_leaf, pi_leaf);
                         if (level == 0) {
-                            stv<NPL>(l0_lds, lane, p);
+                            stv<NPL>(l0_lds, plane, p);
                         } else if (L1LDS && level == 1) {
-                            stv<NPL>(l1f_lds, lane, cf);
-                            stv<NPL>(l1l_lds, lane, p);
+                            stv<NPL>(l1f_lds, plane, cf);
+                            stv<NPL>(l1l_lds, plane, p);
                         } else if (NXL > 0 && level < 2 + NXL) {
                             double* Lf = xl_lds + (size_t)(3 * (level - 2)) * Dpad;
-                            stv<NPL>(Lf, lane, cf);
-                            stv<NPL>(Lf + Dpad, lane, p);
-                            stv<NPL>(Lf + 2 * Dpad, lane, cr);
+                            stv<NPL>(Lf, plane, cf);
+                            stv<NPL>(Lf + Dpad, plane, p);
+                            stv<NPL>(Lf + 2 * Dpad, plane, cr);
                         } else {
-                            stv<NPL>(wsv(ws_stack(level, 0)), lane, cf);
-                            stv<NPL>(wsv(ws_stack(level, 1)), lane, p);
-                            stv<NPL>(wsv(ws_stack(level, 2)), lane, cr);
+                            stv<NPL>(wsv(ws_stack(level, 0)), plane, cf);
+                            stv<NPL>(wsv(ws_stack(level, 1)), plane, p);
+                            stv<NPL>(wsv(ws_stack(level, 2)), plane, cr);
                         }
-                        lv_omega.set(level, c_omega, lane);
-                        lv_vlsa.set(level, v_lsa, lane);
-                        lv_vsteps.set(level, v_steps, lane);
-                        lv_zeta.set(level, c_zeta, lane);
+                        lv_omega.set(level, c_omega, plane);
+                        lv_vlsa.set(level, v_lsa, plane);
+                        lv_vsteps.set(level, v_steps, plane);
+                        lv_zeta.set(level, c_zeta, plane);
                     }
                 }
                 if (invalid) {
@@ -784,10 +884,11 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         }();
         total_steps += (unsigned long long)vtop_steps;
         init_slot = zeta_top;
-        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), lane, q);
+        if constexpr (PFR) prefetch_row(pft, Wrow, plane, pf_lines);   // the next transition's momentum refresh reads W: one round trip with the proposal's
+        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), plane, q);
         if constexpr (T::kPointwiseGrad) {}
         else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-        else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), lane, g);
+        else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), plane, g);
         lq_cur = sl_lq.get(init_slot);
         const double pi_stat = sl_pi.get(init_slot);
 
@@ -796,6 +897,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         // runs under it — 3.10e8 against 3.16e8 leapfrog-steps/s on one box, the loads kept in flight across the loop's back edge
         // cost more in waits at the loop head than the round trip they hide)
         store_draw(n_done + n);
+        if constexpr (PFR) prefetch_token_keep(pft);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
             if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273

@@ -88,6 +88,111 @@ __device__ __forceinline__ double wave_allreduce1(double x, int nl = 64) {
     return v[0];
 }
 
+// ---- The same tree on a PERMUTED wave (round 6; the wide per-draw kernel of coordinate-wise targets) ------------------------
+// The ABI pins the pairing over COORDINATES (partial sum l of a row pairs with l^1, then l^2, … l^32), not over hardware lanes.
+// If hardware lane p holds partial sum  l(p) = p[5] | p[4] << 1 | p[3:0] << 2  (a row of 512 bytes is still one coalesced
+// segment, read in another lane order), the tree's first two levels pair p with p^32 and p^16 — exactly what gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange between TWO registers.  So two values are reduced for the price of one at
+// those levels (swap the halves / rows of x and y, add: the low half now holds x's pair sums, the high half y's), six values
+// arrive at level 3 in two registers instead of six, and levels 3–6 stay inside a row of 16 lanes (quad_perm, quad_perm,
+// row_half_mirror, row_mirror; no row_bcast).  Same pairs, same operands per addition (IEEE addition commutes): same bits as
+// wave_allreduce on the unpermuted wave.  6 values: 39 vector instructions instead of 108; 2 values: 18 instead of 36.
+__device__ __forceinline__ int xl_logical_lane(int p) { return ((p >> 5) & 1) | (((p >> 4) & 1) << 1) | ((p & 15) << 2); }
+
+__device__ __forceinline__ void xl_words(double x, uint32_t& lo, uint32_t& hi) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    lo = (uint32_t)b; hi = (uint32_t)(b >> 32);
+}
+__device__ __forceinline__ double xl_f64(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); }
+// x := [x lanes 0-31 | y lanes 0-31],  y := [x lanes 32-63 | y lanes 32-63]
+__device__ __forceinline__ void xl_swap32(double& x, double& y) {
+    uint32_t xl, xh, yl, yh;
+    xl_words(x, xl, xh); xl_words(y, yl, yh);
+    auto a = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+    x = xl_f64(a[0], b[0]); y = xl_f64(a[1], b[1]);
+}
+// rows of 16 lanes: x := [x0, y0, x2, y2],  y := [x1, y1, x3, y3]
+__device__ __forceinline__ void xl_swap16(double& x, double& y) {
+    uint32_t xl, xh, yl, yh;
+    xl_words(x, xl, xh); xl_words(y, yl, yh);
+    auto a = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+    x = xl_f64(a[0], b[0]); y = xl_f64(a[1], b[1]);
+}
+__device__ __forceinline__ double xl_any() {      // a register whose contents do not matter (the partner of an odd value out)
+    uint32_t lo, hi;
+    asm volatile("" : "=v"(lo));
+    asm volatile("" : "=v"(hi));
+    return xl_f64(lo, hi);
+}
+// N partial sums per lane -> (N + 3) / 4 registers; the total of value i = 4 j + t stands in EVERY lane of row XL_ROW[t] of
+// register j (rows that belong to no value hold garbage)
+__device__ constexpr int xl_row(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : 3; }
+template <int N>
+__device__ __forceinline__ void xl_reduce(const double (&v)[N], double (&u)[(N + 3) / 4]) {
+    constexpr int NW = (N + 1) / 2, NU = (N + 3) / 4;
+    double w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {                 // level 1: p ^ 32
+        double x = v[2 * i], y = (2 * i + 1 < N) ? v[2 * i + 1] : xl_any();
+        xl_swap32(x, y);
+        w[i] = x + y;                              // [v_2i | v_2i+1]
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {                 // level 2: p ^ 16
+        double x = w[2 * j], y = (2 * j + 1 < NW) ? w[2 * j + 1] : xl_any();
+        xl_swap16(x, y);
+        u[j] = x + y;                              // rows [v_4j, v_4j+2, v_4j+1, v_4j+3]
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = u[j] + dpp_f64<0xB1>(u[j]);    // levels 3-6 inside the rows
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = u[j] + dpp_f64<0x4E>(u[j]);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = u[j] + dpp_f64<0x141>(u[j]);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = u[j] + dpp_f64<0x140>(u[j]);
+}
+template <int N>
+__device__ __forceinline__ double xl_value(const double (&u)[(N + 3) / 4], int i) { return readlane_f64(u[i / 4], 16 * xl_row(i % 4)); }
+// any of the N totals < 0 (strict; false for NaN and -0, like the scalar comparison): two compares and a mask instead of 2 N
+// v_readlane and N compares
+template <int N>
+__device__ __forceinline__ bool xl_any_negative(const double (&u)[(N + 3) / 4]) {
+    constexpr int NU = (N + 3) / 4;
+    uint64_t any = 0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        uint64_t valid = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * j + t < N) valid |= 0xffffull << (16 * xl_row(t));
+        any |= __ballot(u[j] < 0.0) & valid;
+    }
+    return any != 0;
+}
+template <int N>
+__device__ __forceinline__ void wave_allreduce_xl(double (&v)[N]) {
+    double u[(N + 3) / 4];
+    xl_reduce<N>(v, u);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = xl_value<N>(u, i);
+}
+
+// the totals as scalars, by either reduction
+template <int N, bool XL>
+__device__ __forceinline__ void wave_totals(double (&v)[N], int nl) {
+    if constexpr (XL) wave_allreduce_xl<N>(v);
+    else wave_allreduce<N>(v, nl);
+}
+template <bool XL>
+__device__ __forceinline__ double wave_total1(double x, int nl) {
+    double v[1] = {x};
+    wave_totals<1, XL>(v, nl);
+    return v[0];
+}
+
 __device__ __forceinline__ bool wave_all(bool pred) { return __ballot(pred) == ~0ull; }
 
 // The ABI's per-lane part of a dot product (include/dhmc.h "Summation order"): a padded row is cut into BLOCKS of
@@ -155,6 +260,45 @@ template <int NPL>
 struct RegRow {
     const double (&v)[NPL];
     __device__ __forceinline__ double operator()(int k) const { return v[k]; }
+};
+
+// Software prefetch for a lone wave (round 6).  A chain's workspace rows are written 10–40 µs before they are read again, and in
+// that time its XCD's L2 (4 MB) has been written over by the other 127 chains of the XCD: the re-read comes from the Infinity
+// Cache or HBM, and a wave that owns its SIMD waits the whole round trip out.  One dword load per 128-byte line — lane l touches
+// line l of the row, so ONE instruction covers a row of 1024 doubles — issued a few thousand clocks ahead pulls the row back
+// into L2.  The loaded dwords are never looked at; they land in the ACCUMULATION register of `tok` (vector memory instructions
+// address that file directly; the allocator parks an architectural register's value elsewhere under pressure and reuses it), which the caller keeps alive (and otherwise
+// untouched) for the whole kernel: loads return in issue order, so by the time the real loads of the row have been waited for,
+// the prefetch has landed, and nothing else ever lives in that register (tools/isa_prefetch_verify.py checks the compiled
+// kernel for exactly that: every "dhmc_pf" load writes ONE register and no other instruction writes it).
+struct PrefetchToken { uint32_t v; };
+__device__ __forceinline__ void prefetch_token_init(PrefetchToken& tok) { asm volatile("; dhmc_pf_init %0" : "=a"(tok.v)); }
+__device__ __forceinline__ void prefetch_row(PrefetchToken& tok, const double* row, int plane, int lines) {
+    if (plane < lines) {
+        const char* a = reinterpret_cast<const char*>(row) + 128 * plane;
+        asm volatile("global_load_dword %0, %1, off ; dhmc_pf" : "+a"(tok.v) : "v"(a));
+    }
+}
+__device__ __forceinline__ void prefetch_token_keep(PrefetchToken& tok) { asm volatile("; dhmc_pf_keep %0" : "+a"(tok.v)); }
+
+// A D-vector parked in ACCUMULATION registers: rows the tree touches once per doubling (the trajectory's ρ) held where they cost no
+// architectural VGPR.  The register allocator of gfx950 uses the accumulation file as spill space by itself, but it chooses WHAT
+// to park by use density over the whole loop nest; naming the cold row here keeps the leapfrog's own rows architectural.
+// One v_accvgpr_write / v_accvgpr_read per 32-bit half and access (no hazards between VALU and these on gfx950).
+template <int NPL>
+struct AccRow {
+    uint32_t lo[NPL], hi[NPL];
+    __device__ __forceinline__ void set(int k, double x) {
+        const uint64_t b = (uint64_t)__double_as_longlong(x);
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo[k]) : "v"((uint32_t)b));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi[k]) : "v"((uint32_t)(b >> 32)));
+    }
+    __device__ __forceinline__ double get(int k) const {
+        uint32_t l, h;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo[k]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi[k]));
+        return __longlong_as_double((long long)(((uint64_t)h << 32) | l));
+    }
 };
 
 // A small array of wave-uniform scalars held in the LANES of one register: element i lives in lane i (i < 64).
