@@ -702,18 +702,19 @@ PER_CHAIN_DENSE_AUTO_DIM = 256              # per_chain_metric=None: every chain
 PER_CHAIN_DENSE_AUTO_BYTES = 2 << 30        # … while the C pairs (M⁻¹, Wᵀ) of padded matrices stay below this
 
 
-def _per_chain_metric_default(l, chains, metric_allreduce):
+def _per_chain_metric_default(l, chains, metric_allreduce, max_depth=10):
     """What `per_chain_metric=None` means for a Symmetric warmup: the reference's semantics — every chain adapts its own M⁻¹ from its
     own draws (mcmc.jl:281-285) — whenever that is affordable: a built-in functor family (the wave-per-chain dense kernels; a caller's
     functor and callback models run the shared dense metric only), at most 256
     coordinates (beyond, a matvec per chain streams 8·D² bytes per leapfrog and the pooled GEMM engine is the practical choice),
-    2·C·Dpad² doubles within 2 GiB, no job-wide pooling requested.  Otherwise ONE M⁻¹ pooled over the context's chains (the batched
+    2·C·Dpad² doubles of matrices plus the chains' workspace within 2 GiB, no job-wide pooling requested.  Otherwise ONE M⁻¹ pooled over the context's chains (the batched
     engine's design; a stated deviation from the reference)."""
     D = l.dimension()
     dpad = 64 * max(1, -(-D // 64))
+    nvec = 18 + 7 * max_depth                              # workspace rows per chain of the dense kernels (csrc/nuts_dense_kernel.hpp wd_nvec)
+    footprint = 16 * chains * dpad * dpad + 8 * chains * nvec * dpad          # the C pairs (M⁻¹, Wᵀ) and the chains' workspace
     return (metric_allreduce is None and l.family not in (abi.TARGET_EXTERNAL, abi.TARGET_LOGISTIC) and l.family < abi.TARGET_USER_BASE
-            and D <= PER_CHAIN_DENSE_AUTO_DIM
-            and 16 * chains * dpad * dpad <= PER_CHAIN_DENSE_AUTO_BYTES)
+            and D <= PER_CHAIN_DENSE_AUTO_DIM and footprint <= PER_CHAIN_DENSE_AUTO_BYTES)
 
 
 def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=None, algorithm=NUTS(),
@@ -738,9 +739,11 @@ def mcmc_keep_warmup(rng, l, N, *, chains=1, initialization=(), warmup_stages=No
     wants_dense = any(isinstance(s, TuningNUTS) and s.M == Symmetric for s in warmup_stages)
     metric = abi.METRIC_DENSE if ((k0 is not None and k0.dense) or wants_dense) else abi.METRIC_DIAG
     if per_chain_metric is None:
-        per_chain_metric = metric == abi.METRIC_DENSE and _per_chain_metric_default(l, chains, metric_allreduce)
+        per_chain_metric = metric == abi.METRIC_DENSE and _per_chain_metric_default(l, chains, metric_allreduce, algorithm.max_depth)
         if k0 is not None and k0.dense and np.ndim(k0.Minv) == 2:
             per_chain_metric = False               # a caller who hands over ONE matrix for all chains asks for the shared metric
+        if per_chain_metric:                       # said once per call, where the reporter says things: κ.M⁻¹ will be [C][D][D]
+            reporter.report("Symmetric metric: one M⁻¹ per chain (κ.M⁻¹ is [chains][D][D]); per_chain_metric=False pools one")
     ctx = DeviceContext(l.dimension(), chains, target=l.family, target_params=l.params(), seed=rng.seed,
                         max_depth=algorithm.max_depth, min_delta=algorithm.min_delta,
                         chain_offset=rng.chain_offset, device=device, metric=metric,

@@ -32,7 +32,7 @@ STATUS_MESSAGES = [
     (abi.ST_INVALID_INITIAL, "Invalid log posterior or non-finite gradient at the initial position."),  # :212-216
     (abi.ST_STEPSIZE_SEARCH_FAILED, "Initial stepsize search reached maximum number of iterations without crossing."),  # stepsize.jl:58
     (abi.ST_NONFINITE_START_DENSITY, "Starting point has non-finite density."),           # stepsize.jl:78
-    (0x40000000, "Internal error: a handshake of the pipeline kernel's wavefronts timed out (csrc/nuts_pipeline_kernel.hpp)."),
+    (0x40000000, "Internal error: a bounded wait inside a kernel ran out (DHMC_ST_KERNEL_PROTOCOL, include/dhmc.h); not the model's fault."),
 ]
 
 

@@ -48,7 +48,6 @@ struct dhmc_ctx {
     int fuse_k2 = 1;           // DHMC_FUSE_K2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
     int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (either dense engine)
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
-    int use_graph = 0;         // dense round engine: capture four rounds into a hipGraph (DHMC_GRAPH=1; measured slower, see dhmc_run)
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
     int logistic_batched = 0;  // … and with it (or beyond 1024 coefficients) ℓ, ∇ℓ of all chains by the same GEMMs wherever they are needed
                                // outside a round: initialisation, step-size search, the Diagnostics probes (external_eval)
@@ -92,26 +91,9 @@ struct dhmc_ctx {
     int pipeline = 0;                      // the context's chains can run as four-wave pipelines (nuts_pipeline_kernel.hpp): launches that the
                                            // previous launch showed to be held open by a few chains; DHMC_PIPELINE=0: never, =1: always
     int pipeline_force = 0;
-    // many chains with a heavy-tailed tree size (all 32768 funnel chains on one GPU): the call in rounds — the chains packed, those
-    // with the deepest trees of the round before (and those the packed launch gave up for their work) through the pipeline kernel
-    // on CUs of their own (dhmc_run).  Measured no better than one packed launch with its queue of places: off unless asked for.
-    int hybrid = 0;                        // DHMC_HYBRID=1: on
-    int hybrid_segments = 8;               // DHMC_HYBRID_SEGMENTS
-    double hybrid_budget = 0.0;            // DHMC_HYBRID_BUDGET: a round's leapfrog budget of a packed chain in mean works (0: chains per lane group)
-    int hybrid_deep_cap = 2;               // DHMC_HYBRID_DEEP_CAP: at most this × CUs chains go through the pipeline kernel in a round
-    int hybrid_deep_cus = 64;              // DHMC_HYBRID_DEEP_CUS: CUs set aside for the pipeline blocks of a call in rounds (0: no CU masks)
-    hipStream_t stream_deep = nullptr, stream_bulk = nullptr;   // … the streams with the two CU masks
-    int deep_cus = 0;
-    hipEvent_t ev_round[4] = {nullptr, nullptr, nullptr, nullptr};   // a round's two launches, timed (DHMC_DEBUG_ORDER prints them)
-    hipEvent_t ev_join2 = nullptr;
-    double hybrid_promote = 4.0;           // DHMC_HYBRID_PROMOTE: … of the chains whose leapfrog steps per transition were above this × the mean
-    int hybrid_deep_wave = 0;              // DHMC_HYBRID_DEEP=wave: the deep chains through the wave-per-chain kernel (1.5 µs per leapfrog, any number resident)
-    int hybrid_min_chains = 0;             // DHMC_HYBRID_MIN_CHAINS: a call runs in rounds from this many chains on (0: 32 × CUs)
     double mean_leapfrogs_per_transition = 0.0;   // of the previous call
-    int* d_prog = nullptr;                 // [C] a call in rounds: transitions of the call a chain has behind it
-    int* d_list_packed = nullptr;          // [C] … the round's chains of the packed launch, of the pipeline launch, and those the
-    int* d_list_deep = nullptr;            //     packed launch gave up
-    int* d_evicted = nullptr;
+    int* d_prog = nullptr;                 // [C] the end game of a packed launch: transitions of the call a chain has behind it …
+    int* d_evicted = nullptr;              // [C] … and the chains the packed launch gave up, in the order it gave them up
     int pk_handover = -1;                  // DHMC_PK_HANDOVER: the end game of a tail-bound packed launch starts at this many live lane groups (0: off; -1: what the pipeline kernel keeps resident)
     int many_chains_min = 0;               // DHMC_MANY_CHAINS
     int pk_queue = 1;                      // DHMC_PK_QUEUE=0: a packed launch starts a lane group per place (no queue of places)
@@ -185,6 +167,8 @@ void stage_free(dhmc_ctx* c, Staged* s);
 int npl_for_dim(int D, bool big);
 // launches one operation (launch.hpp Op) of the context's target family, or of the caller's run-time compiled functor
 int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_override = nullptr, bool use_override = false);
+// the logistic round engine's own kernels (logistic_rounds.hpp): 0 momentum, 1 position update, 3 gradient fold / second half step, 4 row list
+void launch_logistic_op(int which, int npl, const RoundArgs& a, const LogisticRound& L, hipStream_t s);
 int read_status(dhmc_ctx* c, std::vector<uint32_t>& st);
 int status_code(dhmc_ctx* c);
 int copy_out_padded(dhmc_ctx* c, const double* padded, double* dst, int on_device);

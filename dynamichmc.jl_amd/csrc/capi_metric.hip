@@ -216,14 +216,26 @@ int dhmc_update_metric_dense(dhmc_ctx* c, const double* draws, int64_t n, double
         double* const S = (double*)bS.p;
         double* const sums = c->d_fwork;                      // D + 2 slots: column sums, row count, error flag
         const double* x = (const double*)s.dev;
-        double tail[2] = {local_err != 0.0 ? 0.0 : (double)J, local_err};
-        HIP_TRY(c, hipMemsetAsync(sums, 0, sizeof(double) * (size_t)(D + 2), c->stream));
-        if (local_err == 0.0)
+        // (no early return before the first collective: a HIP error here is this rank's local_err like any other — the memset that
+        // failed leaves garbage column sums, which no rank uses once the reduced error slot is raised)
+        if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)(D + 2), c->stream) != hipSuccess) local_err = 1.0;
+        if (local_err == 0.0) {
             hipLaunchKernelGGL(pooled_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, c->stream, D, J, x, sums, (size_t)0, (size_t)0, 1);
-        HIP_TRY(c, hipMemcpyAsync(sums + D, tail, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if (hipGetLastError() != hipSuccess) local_err = 1.0;
+        }
+        double tail[2] = {local_err != 0.0 ? 0.0 : (double)J, local_err};
+        if (hipMemcpyAsync(sums + D, tail, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            // the slot could not be written: write it by a kernel-free path of last resort (a blocking copy); if that fails too the
+            // device is gone and the collective cannot be entered by this rank in any case
+            tail[1] = local_err = 1.0; tail[0] = 0.0;
+            (void)hipMemcpy(sums + D, tail, 2 * sizeof(double), hipMemcpyHostToDevice);
+        }
         if (c->metric_allreduce(c->metric_allreduce_user, sums, (int64_t)D + 2, (void*)c->stream) != 0) {
             c->err = "dhmc_update_metric_dense: the all-reduce callback failed (column sums)"; stage_free(c, &s); return DHMC_ERR_CALLBACK;
         }
+        // (after the collective every rank is on its own again until the second one, which all reach or none: a rank whose copy back
+        // fails cannot know the job's verdict and reports its own error; the others' second collective then times out in the
+        // communicator, as for any rank that dies — there is no way to tell them without a collective)
         HIP_TRY(c, hipMemcpyAsync(tail, sums + D, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));           // the job's row count and error count are on the host now — on every rank
         const double Jtot = tail[0];

@@ -18,6 +18,20 @@
 
 #include "../../include/dhmc.h"
 
+// The value of `key` in the "key=value,key=value" list of an environment variable: DHMC_PK (the packed engine's launch layout) and
+// DHMC_DENSE (the dense engines) — tuning and test switches, every one bit-neutral (include/dhmc.h "Environment").
+inline bool env_list_value(const char* var, const char* key, long long* out) {
+    const char* s = std::getenv(var);
+    const size_t kl = std::strlen(key);
+    while (s && *s) {
+        const char* end = std::strchr(s, ',');
+        const size_t len = end ? (size_t)(end - s) : std::strlen(s);
+        if (len > kl + 1 && std::strncmp(s, key, kl) == 0 && s[kl] == '=') { *out = std::atoll(s + kl + 1); return true; }
+        s = end ? end + 1 : nullptr;
+    }
+    return false;
+}
+
 // a device temporary that is released on every return path
 struct DevBuf {
     void* p = nullptr;

@@ -147,9 +147,6 @@ __device__ __forceinline__ void leapfrog_leaf_m(const T& tgt, MK mk_, int lane, 
     for (int k = 0; k < NPL; ++k) {
         p[k] = p[k] + h * g[k];                      // :280
         double ps = mk_(k) * p[k];                   // p♯ = M⁻¹ p'
-#ifdef DHMC_OPAQUE_PS
-        asm volatile("" : "+v"(ps));                 // not kept for the merge that may follow (an AGPR round trip costs more than the product)
-#endif
         kacc.add(0, k, p[k], ps);
         DHMC_BLOCK_FENCE(k);
     }
@@ -324,22 +321,6 @@ __device__ __forceinline__ void logaddexp_pair(double a1, double b1, double a2, 
     r2 = uni_f64(v2);
 }
 
-// The softplus rows of a merge's logaddexp pair, requested BEFORE the merge's vector part: the arguments (the suspended level's
-// and the running subtree's ω and visited statistic) are known then, the rows are not needed for another ≈ 1 500 clocks, and the
-// scalar cache misses often enough (four chains per CU walk a 16 KB table among other tables) that the pair's two dependent
-// scalar loads were exposed L2 round trips.  One dword of each row is loaded into a scalar register that is kept until the
-// retiring s_waitcnt; the pair's own loads of the rows then hit the scalar cache.  Changes no value.
-struct LaePrefetch { uint32_t t1, t2; };
-__device__ __forceinline__ LaePrefetch lae_prefetch(double a1, double b1, double a2, double b2) {
-    const double d1 = __builtin_fabs(a1 - b1), d2 = __builtin_fabs(a2 - b2);
-    const int i1 = dm_u::idx((d1 < 16.0) ? (int)(d1 * 16.0) : 0), i2 = dm_u::idx((d2 < 16.0) ? (int)(d2 * 16.0) : 0);
-    LaePrefetch f;
-    asm volatile("s_load_dword %0, %1, 0x0 ; dhmc_pf_s" : "=s"(f.t1) : "s"(&DM_SOFTPLUS_TBL[i1][0]));
-    asm volatile("s_load_dword %0, %1, 0x0 ; dhmc_pf_s" : "=s"(f.t2) : "s"(&DM_SOFTPLUS_TBL[i2][0]));
-    return f;
-}
-__device__ __forceinline__ void lae_prefetch_retire(const LaePrefetch& f) { asm volatile("s_waitcnt lgkmcnt(0) ; dhmc_pf_s_retire %0 %1" :: "s"(f.t1), "s"(f.t2)); }
-
 // p = W .* randn (hamiltonian.jl:124) from the chain's stream.  The Box–Muller pairs are taken in batches of four: Philox and the
 // argument reductions of the whole batch first, then ALL its table rows (log cell, sin/cos cell: per-lane gathers) and W
 // slots requested together, then the arithmetic.  A lone wave waits out every memory round trip it takes one at a time, and
@@ -416,6 +397,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     constexpr bool XL = kXlLanes && T::kElementwise && NPL >= 2;
     const int plane = threadIdx.x;
     const int lane = XL ? xl_logical_lane(plane) : plane;
+    const int lane_ = lane, plane_ = plane;
     const int D = P.D, Dpad = P.Dpad;
 
     extern __shared__ double lds[];
@@ -454,19 +436,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     const ChainKey key{(uint32_t)P.seed, (uint32_t)(P.chain_offset + chain), (uint32_t)(P.seed >> 32)};
     const int max_depth = P.max_depth;
     const int nslots = ws_nslots(max_depth);
-#ifdef DHMC_PF_ROWS
-    constexpr bool PFR = NPL >= 4;                         // workspace rows pulled back into L2 ahead of their use (wave.hpp prefetch_row)
-#else
-    constexpr bool PFR = false;
-#endif
-#ifdef DHMC_PF_LAE
-    constexpr bool PFL = true;
-#else
-    constexpr bool PFL = false;
-#endif
-    PrefetchToken pft;
-    if constexpr (PFR) prefetch_token_init(pft);
-    const int pf_lines = Dpad / 16;                        // 128-byte lines of a row
     const int nl = uni_i32(reduce_lanes(NPL, D));          // lanes that can hold nonzero partial sums (wave.hpp wave_allreduce)
 
     double q[NPL], p[NPL], g[NPL], cf[NPL], cr[NPL];
@@ -479,13 +448,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     double* const tpm_ws = ws + (size_t)ws_edge(0, 1) * Dpad;
     double* const tpp_ws = ws + (size_t)ws_edge(1, 1) * Dpad;
     double* const trho_ws = ws + (size_t)ws_rho_top() * Dpad;
-#ifdef DHMC_TRHO_AGPR
-    constexpr bool TRA = TPL;                               // the trajectory's ρ parked in accumulation registers (wave.hpp AccRow)
-#else
-    constexpr bool TRA = false;
-#endif
-    double tpm[(TPL || TWS) ? 1 : NPL], tpp[(TPL || TWS) ? 1 : NPL], trho[(TWS || TRA) ? 1 : NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
-    AccRow<TRA ? NPL : 1> trho_a;
+    double tpm[(TPL || TWS) ? 1 : NPL], tpp[(TPL || TWS) ? 1 : NPL], trho[TWS ? 1 : NPL];     // turn statistic of the whole trajectory: p₋, p₊, ρ
     auto a_tm = [&](int k) -> double {
         if constexpr (TPL) return tpm_lds[plane + WAVE * k];
         else if constexpr (TWS) return tpm_ws[plane + WAVE * k];
@@ -504,11 +467,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
     uint32_t status = P.st.status[chain];
     const uint32_t tr0 = P.st.transition[chain];
     unsigned long long total_steps = 0;
-    // a call in rounds (RunParams::prog; short chains only — the wide instantiations are not disturbed): the chain has n_done
-    // transitions of the call behind it and runs to the round's target N; records and window counts count from the call's start
-    int64_t n_done = 0;
-    if constexpr (NPL == 1) n_done = P.prog ? (int64_t)P.prog[chain] : 0;
-    const int64_t NN = NPL == 1 ? (P.N > n_done ? P.N - n_done : 0) : P.N;
+    constexpr int64_t n_done = 0;
+    const int64_t NN = P.N;
 
     if (P.adapt && P.da_init && n_done == 0) {  // initial_adaptation_state (stepsize.jl:134-138; mcmc.jl:266)
         double le = det_log_u(eps_fixed);
@@ -538,6 +498,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 
     // draw n of this call := the chain's position after transition n (mcmc.jl:275,376)
     auto store_draw = [&](int64_t n_) {
+        int lane = lane_;                                   // (once per transition: not worth loop-invariant address registers)
+        asm volatile("" : "+v"(lane));
         if (P.out.draws) {
             double* drow = P.out.draws + ((size_t)chain * (P.out_stride ? P.out_stride : P.N) + n_) * D;
 #pragma unroll
@@ -554,7 +516,12 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         const double eps = uni_f64(P.adapt ? det_exp_u(da.logeps) : eps_fixed);  // current_ϵ (stepsize.jl:163)
 
         // ---- sample_tree (NUTS.jl:232-241): p, directions, π₀ --------------------------
-        sample_momentum<NPL>(key, PURPOSE_MOMENTUM, tr, Wrow, lane, p);
+        // (once per transition: an opaque copy of the lane index keeps the refresh's loop invariants — W's per-slot addresses, the
+        // first Philox products of every counter — from being hoisted out of the transition loop into registers that the tree loop
+        // then pays for with spills: round 6, 60 accumulation registers and every scratch reload of the merges)
+        int lane_cold = lane;
+        asm volatile("" : "+v"(lane_cold));
+        sample_momentum<NPL>(key, PURPOSE_MOMENTUM, tr, Wrow, lane_cold, p);
         uint32_t dirs;
         {
             uint32_t w[4];
@@ -581,10 +548,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 #pragma unroll
             for (int k = 0; k < NPL; ++k) { tpm[k] = p[k]; tpp[k] = p[k]; }
         }
-        if constexpr (TRA) {
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) trho_a.set(k, p[k]);
-        } else if constexpr (!TWS) {
+        if constexpr (!TWS) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) trho[k] = p[k];
         }
@@ -630,6 +594,9 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             const int dir = fwd ? 1 : 0;
             PH(2)   // edge switch
             if (reg_edge != 2 && reg_edge != dir) {
+                int plane = plane_, lane = lane_;           // (once per doubling at most)
+                asm volatile("" : "+v"(plane));
+                asm volatile("" : "+v"(lane));
                 // park the edge we leave ...
                 stv<NPL>(wsv(ws_edge(reg_edge, 0)), plane, q);
                 if constexpr (!T::kRecomputeGrad) stv<NPL>(wsv(ws_edge(reg_edge, 2)), plane, g);
@@ -651,15 +618,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                 }
             }
             reg_edge = dir;
-            if constexpr (PFR) {
-                // the next doubling's direction is known (the word of directions): if it extends the other edge, its parked
-                // position comes back from the workspace then — ask for it now
-                const int ndir = (int)(dirs & 1u);
-                if (depth + 1 < max_depth && ndir != dir) {
-                    const bool have = ndir ? stored1 : stored0;
-                    prefetch_row(pft, wsv(have ? ws_edge(ndir, 0) : ws_slot(max_depth, init_slot, 0)), plane, pf_lines);
-                }
-            }
             int64_t i = fwd ? i_plus : i_minus;
             const int64_t di = fwd ? 1 : -1;
             const double eps_s = fwd ? eps : -eps;
@@ -672,25 +630,8 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
             for (uint32_t j = 0; j < nleaf && !invalid && !finished; ++j) {
                 double lq_leaf, pi_leaf;
                 bool pos_finite;
-                if constexpr (PFR) {
-                    // the cascade of leaf j merges the suspended levels 0 .. (trailing ones of j) - 1: those kept in the workspace
-                    // are asked for before the leapfrog
-                    constexpr int FIRST_WS = L1LDS ? 2 + NXL : 1;
-                    const int t1 = __builtin_ctz(~j);
-                    for (int l2 = FIRST_WS; l2 < t1; ++l2) {
-                        prefetch_row(pft, wsv(ws_stack(l2, 0)), plane, pf_lines);
-                        prefetch_row(pft, wsv(ws_stack(l2, 1)), plane, pf_lines);
-                        prefetch_row(pft, wsv(ws_stack(l2, 2)), plane, pf_lines);
-                    }
-                }
                 PH(3)   // leaf
                 bool turning0;
-#ifdef DHMC_KILL_SUMMARY
-                // the running summary of the previous leaf's cascade was suspended (or discarded) there: tell the register allocator
-                // that its rows do not live through the leapfrog (a definition without an instruction)
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) { asm volatile("" : "=v"(cf[k])); asm volatile("" : "=v"(cr[k])); }
-#endif
                 leapfrog_leaf_m<T, NPL, XL>(tgt, mk, lane, D, q, p, g, eps_s, lq_leaf, pi_leaf, pos_finite, nl, kFuseLeafMerge0 && (j & 1u) != 0,
                                             [&](int k) { return l0_lds[plane + WAVE * k]; }, cf, cr, turning0);
                 PH(4)   // leaf scalars
@@ -715,9 +656,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                         auto a_p = [&](int k) { return p[k]; };
                         auto a_cr = [&](int k) { return cr[k]; };
                         bool turning;
-                        LaePrefetch lpf;
-                        if constexpr (PFL) lpf = sub ? lae_prefetch(lv_vlsa.get(level), v_lsa, lv_omega.get(level), c_omega)
-                                                     : lae_prefetch(vtop_lsa, v_lsa, omega_top, c_omega);
                         PH(5)   // merge, vector part
                         if (sub) {
                             if (level == 0) {
@@ -750,7 +688,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             }
                             // v = v₋ ⊕ v₊ (trees.jl:249) and ω = logaddexp(ω₋, ω₊) (trees.jl:145), one pass
                             PH(6)   // merge, scalar part
-                            if constexpr (PFL) lae_prefetch_retire(lpf);
                             const double wl = lv_omega.get(level);
                             double w;
                             logaddexp_pair(lv_vlsa.get(level), v_lsa, wl, c_omega, lane, v_lsa, w);
@@ -779,7 +716,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             // time-ordered (tpm, tpp, trho) whatever the direction
                             auto a_tr = [&](int k) -> double {
                                 if constexpr (TWS) return trho_ws[plane + WAVE * k];
-                                else if constexpr (TRA) return trho_a.get(k);
                                 else return trho[k];
                             };
                             if (depth == 0) {
@@ -790,7 +726,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
                             }
                             double w;
                             PH(6)
-                            if constexpr (PFL) lae_prefetch_retire(lpf);
                             logaddexp_pair(vtop_lsa, v_lsa, omega_top, c_omega, lane, vtop_lsa, w);
                             vtop_steps += v_steps;
                             const double logprob2 = c_omega - omega_top;   // biased progressive (trees.jl:159-161)
@@ -823,10 +758,7 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) tpm[k] = p[k];
                                 }
-                                if constexpr (TRA) {
-#pragma unroll
-                                    for (int k = 0; k < NPL; ++k) trho_a.set(k, cr[k]);
-                                } else if constexpr (!TWS) {
+                                if constexpr (!TWS) {
 #pragma unroll
                                     for (int k = 0; k < NPL; ++k) trho[k] = cr[k];
                                 }
@@ -884,11 +816,15 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         }();
         total_steps += (unsigned long long)vtop_steps;
         init_slot = zeta_top;
-        if constexpr (PFR) prefetch_row(pft, Wrow, plane, pf_lines);   // the next transition's momentum refresh reads W: one round trip with the proposal's
-        ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), plane, q);
-        if constexpr (T::kPointwiseGrad) {}
-        else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
-        else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), plane, g);
+        {
+            int plane = plane_, lane = lane_;               // (once per transition)
+            asm volatile("" : "+v"(plane));
+            asm volatile("" : "+v"(lane));
+            ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 0)), plane, q);
+            if constexpr (T::kPointwiseGrad) {}
+            else if constexpr (T::kRecomputeGrad) (void)tgt.eval(q, g, lane, D);
+            else ldv<NPL>(wsv(ws_slot(max_depth, init_slot, 1)), plane, g);
+        }
         lq_cur = sl_lq.get(init_slot);
         const double pi_stat = sl_pi.get(init_slot);
 
@@ -897,7 +833,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         // runs under it — 3.10e8 against 3.16e8 leapfrog-steps/s on one box, the loads kept in flight across the loop's back edge
         // cost more in waits at the loop head than the round trip they hide)
         store_draw(n_done + n);
-        if constexpr (PFR) prefetch_token_keep(pft);
         if (lane == 0) {
             if (P.out.logdensities) P.out.logdensities[o] = lq_cur;        // mcmc.jl:276,377
             if (P.out.eps) P.out.eps[o] = eps;                             // mcmc.jl:273
@@ -933,12 +868,6 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
         P.st.transition[chain] = tr0 + (uint32_t)NN;
         P.st.status[chain] = status;
         if (P.leapfrog_counter) atomicAdd(P.leapfrog_counter, total_steps);
-        if constexpr (NPL == 1) {
-            if (P.prog) {
-                P.prog[chain] = (int)(n_done + NN);
-                total_steps += P.chain_work ? (unsigned long long)P.chain_work[chain] : 0ull;    // (a call in rounds adds to the chain's count)
-            }
-        }
         if (P.chain_work) P.chain_work[chain] = (unsigned)(total_steps > 0xffffffffull ? 0xffffffffull : total_steps);
     }
 }

@@ -40,14 +40,21 @@ namespace dhmc {
 
 // (PAIR_RING, PIPE_NXL, pipeline_lds_bytes: run_params.hpp)
 constexpr unsigned PAIR_SPIN_LIMIT = 1u << 24;   // polls of one wait (≈ 64 clocks each plus the poll itself: ≈ 1 s)
-constexpr uint32_t DHMC_ST_KERNEL_PROTOCOL = 0x40000000u;   // internal: the pair kernel's handshake timed out (a bug, never a model's fault)
+// (DHMC_ST_KERNEL_PROTOCOL, include/dhmc.h: the handshake timed out — a bug, never a model's fault)
 
 // The handshakes live in LDS only (ring, mailbox, counters), and the LDS executes one wavefront's operations in issue order: a record
 // written before its counter is visible before it, a counter read before a record is read before it.  So the "fences" are compiler
 // barriers — a workgroup-scope release fence would also drain the wave's GLOBAL stores (proposal slots, deep stack rows, draws),
 // ≈ 1 µs of waiting per leaf for stores nobody else reads.
+// That ordering is how every GCN / CDNA LDS works, not an architected guarantee (include/dhmc.h says so).  -DDHMC_PIPE_FENCED builds the
+// variant that does not rely on it: the publishing wave waits for its outstanding LDS operations (s_waitcnt lgkmcnt(0): the record
+// is IN the LDS) before it writes the counter — an LDS-only fence, the wave's global stores stay in flight.
 __device__ __forceinline__ void pair_publish(volatile unsigned* flag, unsigned v, int lane) {
+#ifdef DHMC_PIPE_FENCED
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("" ::: "memory");
+#endif
     if (lane == 0) *flag = v;
     asm volatile("" ::: "memory");
 }
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256) void nuts_run_pipeline_kernel(RunParams P) {
         P.st.lq[chain] = lq_cur;
         if (P.adapt) {
             P.st.da[chain] = da;
-            if (P.da_finalize) P.st.eps[chain] = det_exp_u(da.logeps_bar); // final_ϵ (stepsize.jl:170; mcmc.jl:285)
+            if (P.da_finalize && !broken) P.st.eps[chain] = det_exp_u(da.logeps_bar); // final_ϵ (stepsize.jl:170; mcmc.jl:285); not from a broken call
         }
         P.st.transition[chain] = tr0 + (uint32_t)n;
         P.st.status[chain] = status;
@@ -739,8 +746,7 @@ int launch_run_pipeline(const RunParams& P, hipStream_t s) {
     if constexpr (!T::kRecomputeGrad || T::kBigDims) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
-        // DHMC_PIPE_LDS_PAD (bytes, timing runs): more LDS per block = fewer chains resident per CU
-        static const size_t pad = [] { const char* e = std::getenv("DHMC_PIPE_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+        constexpr size_t pad = 0;
 #define DHMC_PIPE_LAUNCH(NPL_)                                                                                                  \
     if (P.Dpad == WAVE * NPL_) {                                                                                                \
         static bool once = [] {                                                                                                 \

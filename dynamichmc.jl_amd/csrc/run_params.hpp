@@ -86,25 +86,20 @@ struct RunParams {
     // workspace), and a transition starts only on trips of the wave's main loop that are multiples of pk_align (a power of two)
     int pk_lds_levels, pk_align;
     int pk_cpl;                  // coordinates per lane of the packed layout (2 or 4)
-    int pk_order_base;           // the packed launch takes places pk_order_base .. C-1 of the launch order (a hybrid launch runs the places
-                                 // before it — the chains with the deepest trees — through the pipeline kernel at the same time: dhmc_run)
+    int pk_order_base;           // the packed launch takes places pk_order_base .. C-1 of the launch order
     unsigned* pk_queue;          // null: lane group j of the launch runs place pk_order_base + j.  Else a device counter, initialised by the
                                  // host to the first place no group starts on: a group whose chain is done takes the next place from it
     int pk_max_waves;            // host side of the queue: the most waves a packed launch starts (0: one lane group per place, no queue)
-    // A call in ROUNDS (dhmc_run's hybrid of the packed and the pipeline kernel): prog[chain] = the transitions of this call the chain
-    // has behind it (null: none, and N transitions per launch).  A launch takes every chain of its list from prog[chain] to N — N is
-    // then the round's target, counted from the call's start, and records (outputs, window counts) are indexed from the call's start —
-    // and writes prog back.  The packed kernel gives up a chain that has taken more than pk_budget leapfrog steps in the launch at
-    // its next transition boundary (0: never): the chain's id goes to pk_evicted[(*pk_evict_count)++] and the host hands it to the
-    // pipeline kernel (lower latency per leapfrog), so that a launch's time is not one deep chain's.  With prog, chain_work is added
-    // to instead of set.
+    // A call continued by a later launch (the END GAME of a packed launch, below): prog[chain] = the transitions of this call the chain has
+    // behind it (null: none, and N transitions per launch).  A launch takes every chain of its list from prog[chain] to N — N counted
+    // from the call's start, like the records (outputs, window counts) — and writes prog back.  A chain the packed kernel gives up
+    // goes to pk_evicted[(*pk_evict_count)++].  With prog, chain_work is added to instead of set.
     int* prog;
-    unsigned long long pk_budget;
     int* pk_evicted;
     unsigned* pk_evict_count;
     // The end game of a packed launch: pk_live counts the lane groups that still have a chain (the host sets it to the groups the
     // launch starts; a group that finds no place left takes itself off).  Once it is at or below pk_handover_below (0: never),
-    // every group gives its chain up at the next transition boundary (through pk_evicted, like the budget), and the host finishes
+    // every group gives its chain up at the next transition boundary (through pk_evicted), and the host finishes
     // those chains — the launch's deepest, by then — with the pipeline kernel at a third of the latency per leapfrog.
     unsigned* pk_live;
     int pk_handover_below;

@@ -262,45 +262,6 @@ struct RegRow {
     __device__ __forceinline__ double operator()(int k) const { return v[k]; }
 };
 
-// Software prefetch for a lone wave (round 6).  A chain's workspace rows are written 10–40 µs before they are read again, and in
-// that time its XCD's L2 (4 MB) has been written over by the other 127 chains of the XCD: the re-read comes from the Infinity
-// Cache or HBM, and a wave that owns its SIMD waits the whole round trip out.  One dword load per 128-byte line — lane l touches
-// line l of the row, so ONE instruction covers a row of 1024 doubles — issued a few thousand clocks ahead pulls the row back
-// into L2.  The loaded dwords are never looked at; they land in the ACCUMULATION register of `tok` (vector memory instructions
-// address that file directly; the allocator parks an architectural register's value elsewhere under pressure and reuses it), which the caller keeps alive (and otherwise
-// untouched) for the whole kernel: loads return in issue order, so by the time the real loads of the row have been waited for,
-// the prefetch has landed, and nothing else ever lives in that register (tools/isa_prefetch_verify.py checks the compiled
-// kernel for exactly that: every "dhmc_pf" load writes ONE register and no other instruction writes it).
-struct PrefetchToken { uint32_t v; };
-__device__ __forceinline__ void prefetch_token_init(PrefetchToken& tok) { asm volatile("; dhmc_pf_init %0" : "=a"(tok.v)); }
-__device__ __forceinline__ void prefetch_row(PrefetchToken& tok, const double* row, int plane, int lines) {
-    if (plane < lines) {
-        const char* a = reinterpret_cast<const char*>(row) + 128 * plane;
-        asm volatile("global_load_dword %0, %1, off ; dhmc_pf" : "+a"(tok.v) : "v"(a));
-    }
-}
-__device__ __forceinline__ void prefetch_token_keep(PrefetchToken& tok) { asm volatile("; dhmc_pf_keep %0" : "+a"(tok.v)); }
-
-// A D-vector parked in ACCUMULATION registers: rows the tree touches once per doubling (the trajectory's ρ) held where they cost no
-// architectural VGPR.  The register allocator of gfx950 uses the accumulation file as spill space by itself, but it chooses WHAT
-// to park by use density over the whole loop nest; naming the cold row here keeps the leapfrog's own rows architectural.
-// One v_accvgpr_write / v_accvgpr_read per 32-bit half and access (no hazards between VALU and these on gfx950).
-template <int NPL>
-struct AccRow {
-    uint32_t lo[NPL], hi[NPL];
-    __device__ __forceinline__ void set(int k, double x) {
-        const uint64_t b = (uint64_t)__double_as_longlong(x);
-        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo[k]) : "v"((uint32_t)b));
-        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi[k]) : "v"((uint32_t)(b >> 32)));
-    }
-    __device__ __forceinline__ double get(int k) const {
-        uint32_t l, h;
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo[k]));
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi[k]));
-        return __longlong_as_double((long long)(((uint64_t)h << 32) | l));
-    }
-};
-
 // A small array of wave-uniform scalars held in the LANES of one register: element i lives in lane i (i < 64).
 // v_readlane / v_cndmask instead of an LDS round trip, and no LDS bytes.
 struct LaneArrF64 {

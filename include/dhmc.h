@@ -55,6 +55,26 @@
  * tree ((B0 + B1) + (B2 + B3)) ...; the 64 resulting values are combined by the xor butterfly 1, 2, 4, 8, 16, 32
  * (adjacent pairs first).  For D <= 256 this is one fma chain per l and the butterfly.  A block is what one 64-lane
  * wavefront holds at four coordinates per lane: chains of 512+ coordinates are spread over one wavefront per block.
+ *
+ * Engines and the environment.  A context has several engines for the per-draw loops (a wavefront per chain; several
+ * chains per wavefront; four wavefronts per chain; round engines whose products are GEMMs), all producing the SAME bits; which one runs
+ * a dhmc_run call is chosen from the chain count, the GPU's size and three numbers the previous call left behind (mean tree size, whether
+ * its slowest chain held it open, the chains' order of work) with the thresholds of `EnginePolicy` in csrc/capi_run.hip.  The choice can
+ * be overridden, for tests and timing only, by these environment variables, read when a context is created (none changes a result):
+ *   DHMC_PACKED, DHMC_PIPELINE = 1 | 0     always | never the packed / the pipeline kernel
+ *   DHMC_PK = "key=value,…"                the packed launch: cpl (coordinates per lane, 2 | 4), align (the gate, a power of two),
+ *                                          lds_levels, max_waves, queue (0 | 1), handover (live lane groups at which the end game starts,
+ *                                          0: never), many_chains (chain count from which a tail-bound launch stays packed)
+ *   DHMC_DENSE = "key=value,…"             the dense engines: rounds (1: GEMM rounds, 0: a matvec per chain), products (1 | 2 M⁻¹ products
+ *                                          per leapfrog; also dhmc_set_dense_products), parts (half-batches, 1–4), row_lists, k3_block,
+ *                                          fuse_k2 (0 | 1)
+ *   DHMC_LOGISTIC_ROUNDS, DHMC_L1_LDS, DHMC_LAUNCH_ORDER = 1 | 0;  DHMC_HOST_CHUNK = transitions per chunk of a call with host outputs;
+ *   DHMC_FORCE_NPL = slots per lane (a narrow chain through the wide kernels);  DHMC_ESS_LONG (dhmc_ess_*: the long-chain path);
+ *   DHMC_DEBUG_ORDER (prints the engine and launch order of every call);  DHMC_RTC_CACHE = directory (dhmc_register_target_source);
+ *   DHMC_ACCEPT_UNVERSIONED_STATE (dhmc_import_state: blobs written before the version word existed).
+ * The pipeline kernel's four wavefronts hand records over through LDS counters WITHOUT memory fences: it relies on the LDS executing one
+ * wavefront's operations in issue order (true of every GCN / CDNA part; not an architected guarantee).  Every wait is bounded, and a
+ * wait that runs out raises DHMC_ST_KERNEL_PROTOCOL; building csrc with -DDHMC_PIPE_FENCED puts a fence beside every publication.
  */
 #ifndef DHMC_H
 #define DHMC_H
@@ -80,6 +100,8 @@ extern "C" {
 #define DHMC_ST_INVALID_INITIAL 2u         /* hamiltonian.jl:212-216 strict evaluate_ℓ at the initial point */
 #define DHMC_ST_STEPSIZE_SEARCH_FAILED 4u  /* stepsize.jl:57-59 */
 #define DHMC_ST_NONFINITE_START_DENSITY 8u /* stepsize.jl:77-79 */
+#define DHMC_ST_KERNEL_PROTOCOL 0x40000000u /* INTERNAL error, never a model's fault: a bounded wait inside a kernel ran out (the pipeline kernel's
+                                             * wavefront handshake; the packed kernel's trip limit).  The chain's results of the call are incomplete. */
 
 /* ---- target family: the device-side stand-in for LogDensityProblems.logdensity_and_gradient
  *      (hamiltonian.jl:204; capabilities/dimension checks hamiltonian.jl:146-147) ---------- */
@@ -263,7 +285,7 @@ int dhmc_get_metric_dense_chain(dhmc_ctx* ctx, int32_t chain, double* minv, doub
  *      tests/test_gpu_tolerance.py).  Both dense engines — the wave-per-chain kernel (up to 128 coordinates, and up to 256 below 2048
  *      chains) and the GEMM rounds (otherwise) — run either recurrence with the same bits.
  * dense_per_chain contexts — the reference's semantics — default to 2 and take 1 on request.  May be changed between
- * dhmc_run calls.  DHMC_DENSE_PRODUCTS=1|2 in the environment sets the default of every dense context. */
+ * dhmc_run calls.  DHMC_DENSE="products=1|2" in the environment sets the default of every dense context. */
 int dhmc_set_dense_products(dhmc_ctx* ctx, int32_t products);
 int dhmc_get_dense_products(const dhmc_ctx* ctx);   /* 1 or 2; 0 for a context without a dense metric */
 /* eps [C] if per_chain else a single value broadcast; must be > 0 (stepsize.jl:135). */

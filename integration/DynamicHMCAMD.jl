@@ -54,7 +54,8 @@ const STATUS_MESSAGES = (
     (0x1, "Position vector has non-finite elements."),                 # hamiltonian.jl:203
     (0x2, "Invalid log posterior."),                                   # hamiltonian.jl:212-216
     (0x4, "Initial stepsize search reached maximum number of iterations without crossing."),  # stepsize.jl:58
-    (0x8, "Starting point has non-finite density."))                   # stepsize.jl:78
+    (0x8, "Starting point has non-finite density."),                   # stepsize.jl:78
+    (0x40000000, "Internal error: a bounded wait inside a kernel ran out (DHMC_ST_KERNEL_PROTOCOL); not the model's fault."))
 
 function check(ctx, rc, what; status = nothing)                      # status: the probes' own per-chain words
     rc == 0 && return
@@ -328,10 +329,20 @@ end
 # mcmc_keep_warmup / mcmc_with_warmup (mcmc.jl:521-532,575-584) with `chains` chains on one GPU
 function DynamicHMC.mcmc_keep_warmup(rng::Integer, ℓ::DeviceLogDensity, N::Integer; chains = 1, initialization = (),
                                      warmup_stages = default_warmup_stages(), algorithm = NUTS(),
-                                     reporter = default_reporter(), device = 0, chain_offset = 0, per_chain_metric = false)   # (the Python twin defaults to the reference's per-chain metric where affordable: api.py _per_chain_metric_default)
+                                     reporter = default_reporter(), device = 0, chain_offset = 0, per_chain_metric = nothing)
     # per_chain_metric (Symmetric κ only; a Diagonal κ is always per chain): false — one M⁻¹ adapted from the pooled draws of all
-    # chains (the leapfrog's products are one GEMM); true — every chain its own, as `chains` separate calls of the reference
+    # chains (the leapfrog's products are one GEMM); true — every chain its own, as `chains` separate calls of the reference;
+    # nothing (default) — the rule of the Python twin (api.py _per_chain_metric_default): the reference's per-chain metric where that
+    # is affordable (a built-in functor family, D ≤ 256, the chains' matrices AND their workspace within 2 GiB), pooled otherwise; a
+    # caller who hands over ONE matrix κ asks for the shared metric.  κ.M⁻¹ comes back [D, D, chains] with the per-chain metric.
     dense = any(s -> s isa TuningNUTS{Symmetric}, warmup_stages) || get(initialization, :κ, nothing) isa Matrix
+    if per_chain_metric === nothing
+        dpad = 64 * cld(ℓ.dim, 64)
+        nvec = 18 + 7 * algorithm.max_depth                                       # workspace rows of the dense kernels (nuts_dense_kernel.hpp wd_nvec)
+        per_chain_metric = dense && !(get(initialization, :κ, nothing) isa Matrix) && ℓ.f! === nothing && ℓ.target != 4 &&   # 4 = DHMC_TARGET_LOGISTIC
+                           ℓ.dim <= 256 && 16 * chains * dpad * dpad + 8 * chains * nvec * dpad <= 2 << 30
+        per_chain_metric && reporter isa LogProgressReport && @info "Symmetric metric: one M⁻¹ per chain (κ.M⁻¹ is [D, D, chains]); per_chain_metric = false pools one"
+    end
     ctx = Context(; dim = ℓ.dim, chains, target = ℓ.target, params = ℓ.params, seed = UInt64(rng), algorithm,
                   chain_offset, device, metric = dense ? 1 : 0, dense_per_chain = dense && per_chain_metric)
     ℓ.f! === nothing || set_logdensity!(ctx, ℓ.f!)

@@ -39,7 +39,7 @@ class RunParams(C.Structure):      # csrc/run_params.hpp, field for field
                 ("leapfrog_counter", P), ("win_mean", P), ("win_m2", P), ("win_n0", C.c_int64), ("chain_work", P), ("launch_order", P),
                 ("pk_lds_levels", C.c_int), ("pk_align", C.c_int), ("pk_cpl", C.c_int), ("pk_order_base", C.c_int),
                 ("pk_queue", C.c_void_p), ("pk_max_waves", C.c_int),
-                ("prog", P), ("pk_budget", C.c_uint64), ("pk_evicted", P), ("pk_evict_count", P),
+                ("prog", P), ("pk_evicted", P), ("pk_evict_count", P),
                 ("pk_live", P), ("pk_handover_below", C.c_int)]
 
 
@@ -110,7 +110,7 @@ class HostSim:
         self.set_metric(var)
         self.win, self.win_n = None, -1
 
-    def _launch(self, out, N, N_total, da, queue, order, prog=None, budget=0, evicted=None, evict_count=None, chain_work=None,
+    def _launch(self, out, N, N_total, da, queue, order, prog=None, evicted=None, evict_count=None, chain_work=None,
                 leap_total=None, live=None, handover_below=0):
         """One launch of the simulated kernel: the places of `order` (default: every chain) up to transition N of the call."""
         R = RunParams()
@@ -138,7 +138,7 @@ class HostSim:
             R.launch_order = _p(order)
             R.C = len(order)                 # the launch's places
         if prog is not None:
-            R.prog, R.pk_budget = _p(prog), budget
+            R.prog = _p(prog)
             R.pk_evicted, R.pk_evict_count, R.chain_work = _p(evicted), _p(evict_count), _p(chain_work)
             R.pk_live, R.pk_handover_below = _p(live), handover_below
         rc = lib().hostsim_packed_run(self.target, C.byref(R), int(queue), self.C)
@@ -157,37 +157,6 @@ class HostSim:
             self.win_n += N
         return out
 
-    def run_rounds(self, N, da=None, rounds=4, budget=50, queue=True):
-        """The call as dhmc_run's hybrid makes it: rounds with rising targets; a chain that takes more than `budget` leapfrog steps
-        in a launch is given up at a transition boundary and continues in a later launch (here: without a budget — the device hands
-        it to the pipeline kernel).  Returns the outputs and the number of chains that were given up."""
-        out = self._outputs(N)
-        self.leapfrogs[:] = 0
-        prog = np.zeros(self.C, np.int32)
-        work = np.zeros(self.C, np.uint32)
-        evicted, count = np.zeros(self.C, np.int32), np.zeros(1, np.uint32)
-        seg = (N + rounds - 1) // rounds
-        given_up = 0
-        behind = np.zeros(0, np.int32)
-        for T in list(range(seg, N, seg)) + [N]:
-            d = None if da is None else dict(da, finalize=(da.get("finalize", 1) if T == N else 0))
-            if len(behind):               # the chains the round before gave up: no budget
-                self._launch(out, T, N, d, queue, behind, prog, 0, evicted, count, work)
-            rest = np.setdiff1d(np.arange(self.C, dtype=np.int32), behind)[::-1].copy()
-            count[:] = 0
-            if len(rest):
-                self._launch(out, T, N, d, queue, rest, prog, budget, evicted, count, work)
-            behind = np.sort(evicted[:int(count[0])]).astype(np.int32)
-            assert (prog[behind] < T).all() and (np.delete(prog, behind) == T).all()
-            given_up += len(behind)
-        if len(behind):
-            self._launch(out, N, N, da, queue, behind, prog, 0, evicted, count, work)
-        assert (prog == N).all()
-        assert int(work.sum()) == int(self.leapfrogs[0]) == int(out["steps"].sum())
-        if self.win is not None:
-            self.win_n += N
-        return out, given_up
-
     def run_handover(self, N, da=None):
         """The end game of a packed launch (RunParams::pk_live, pk_handover_below) at its extreme: one lane group, hand-over threshold
         one — every launch gives a chain up after one transition, and the call is N launches over the chains that are left (the
@@ -202,7 +171,7 @@ class HostSim:
         while len(left):
             count[:] = 0
             live[:] = 1
-            self._launch(out, N, N, da, True, left, prog, 0, evicted, count, work, live=live, handover_below=1)
+            self._launch(out, N, N, da, True, left, prog, evicted, count, work, live=live, handover_below=1)
             left = np.sort(evicted[:int(count[0])]).astype(np.int32)
             launches += 1
             assert launches <= N + 1

@@ -169,8 +169,8 @@ class Oracle:
             raise OracleError(rc)
         lib().oracle_set_threads(self.h, threads)
         # a shared dense metric runs the one-product recurrence by default, as the device library does (include/dhmc.h
-        # dhmc_set_dense_products); DHMC_DENSE_PRODUCTS=2 flips both defaults
-        if self.cfg.metric == METRIC_DENSE and not self.cfg.dense_per_chain and os.environ.get("DHMC_DENSE_PRODUCTS") != "2":
+        # dhmc_set_dense_products); DHMC_DENSE="products=2" flips both defaults
+        if self.cfg.metric == METRIC_DENSE and not self.cfg.dense_per_chain and "products=2" not in os.environ.get("DHMC_DENSE", "").split(","):
             self.set_dense_products(1)
 
     def close(self):

@@ -63,11 +63,11 @@ def test_config3_dense_metric_1000dim_slice(pkg):
     Sigma = np.outer(sig, sig) * rho ** np.abs(idx[:, None] - idx[None, :])
     params = np.concatenate([diag, off])
     import os
-    os.environ["DHMC_DENSE_ROUNDS"] = "1"          # the production engine (MFMA GEMM rounds) even for this 4-chain slice
+    os.environ["DHMC_DENSE"] = "rounds=1"          # the production engine (MFMA GEMM rounds) even for this 4-chain slice
     try:
         dev = pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=3)
     finally:
-        del os.environ["DHMC_DENSE_ROUNDS"]
+        del os.environ["DHMC_DENSE"]
     ora = ol.Oracle(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, params=params, seed=3, threads=4)
     q0 = np.random.default_rng(5).normal(size=(C, D)) * sig
     for e in (dev, ora):

@@ -124,6 +124,12 @@ def test_default_warmup_with_symmetric_metric(pkg):
     r = pkg.mcmc_with_warmup(5, l, 1500, chains=8, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric),
                              reporter=pkg.NoProgressReport())
     assert r["kappa"].dense and r["kappa"].Minv.shape == (8, K, K)                      # one Symmetric κ per chain
+    with pytest.raises(TypeError):                                                      # code written for ONE [D][D] matrix fails loudly:
+        float(r["kappa"].Minv[0, 1])                                                    # an entry is a row of K numbers now
+    lines = []
+    pkg.mcmc_with_warmup(5, l, 20, chains=8, warmup_stages=pkg.default_warmup_stages(M=pkg.Symmetric),
+                         reporter=pkg.LogProgressReport(printer=lines.append))
+    assert any("one M⁻¹ per chain" in x for x in lines)                                 # … and the reporter says which metric it is
     P = np.diag(diag) + np.diag(off, 1) + np.diag(off, -1)
     q = r["posterior_matrix"].reshape(-1, K)
     assert np.allclose(np.cov(q.T), np.linalg.inv(P), atol=0.15, rtol=0.15)

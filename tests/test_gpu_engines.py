@@ -95,7 +95,7 @@ def test_dense_round_engine_equals_wave_kernel(pkg, products):
         b = ctx.run(15)
         return {**{"w_" + k: v for k, v in a.items()}, **b}
     make = lambda: pkg.DeviceContext(K, 300, metric=ol.METRIC_DENSE, seed=9)        # 300 chains: two half-batches of 150
-    _same(_run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE_ROUNDS": "0"}, make, steps))
+    _same(_run_with_env(pkg, {"DHMC_DENSE": "rounds=1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE": "rounds=0"}, make, steps))
 
 
 @pytest.mark.parametrize("N,D,C", [(777, 70, 40), (6000, 70, 40), (4100, 200, 70), (2048, 64, 33), (2049, 64, 130)],
@@ -144,7 +144,7 @@ def test_launch_order_changes_no_result(pkg, metric):
         return {**res, "q": ctx.position()[0], "eps": ctx.stepsize(), "work_spread": np.array([a["steps"].sum(1).max() / a["steps"].sum(1).mean()])}
     kw = dict(metric=ol.METRIC_DENSE) if metric == "dense" else {}
     make = lambda: pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=6, **kw)
-    env = {"DHMC_DENSE_ROUNDS": "0", "DHMC_HOST_CHUNK": "70"}
+    env = {"DHMC_DENSE": "rounds=0", "DHMC_HOST_CHUNK": "70"}
     on = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "1"}, make, steps)
     off = _run_with_env(pkg, {**env, "DHMC_LAUNCH_ORDER": "0"}, make, steps)
     assert on["work_spread"][0] > 1.03                 # (the reordering did take place)
@@ -154,7 +154,7 @@ def test_launch_order_changes_no_result(pkg, metric):
 @pytest.mark.parametrize("D", [500, 1000])
 def test_block_per_chain_k3_equals_wave_per_chain_k3(pkg, D):
     """Round engines, chains of 512+ coordinates: K3 as a 4-wave workgroup per chain (dots chained from wave to wave
-    in the ABI's order) against the one-wave-per-chain K3 (DHMC_K3_BLOCK=0)."""
+    in the ABI's order) against the one-wave-per-chain K3 (DHMC_DENSE="k3_block=0")."""
     rng = np.random.default_rng(3)
     A = rng.normal(size=(D, 40))
     S = A @ A.T / 40 + np.eye(D)
@@ -165,8 +165,7 @@ def test_block_per_chain_k3_equals_wave_per_chain_k3(pkg, D):
         a = ctx.run(12, da={})
         return {**{"w_" + k: v for k, v in a.items()}, **ctx.run(8)}
     make = lambda: pkg.DeviceContext(D, 24, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, metric=ol.METRIC_DENSE, seed=5)
-    env = {"DHMC_DENSE_ROUNDS": "1"}
-    _same(_run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "1"}, make, steps), _run_with_env(pkg, {**env, "DHMC_K3_BLOCK": "0"}, make, steps))
+    _same(_run_with_env(pkg, {"DHMC_DENSE": "rounds=1,k3_block=1"}, make, steps), _run_with_env(pkg, {"DHMC_DENSE": "rounds=1,k3_block=0"}, make, steps))
 
 
 def test_position_overflow_matches_oracle(pkg):
@@ -188,7 +187,7 @@ def test_position_overflow_matches_oracle(pkg):
 def test_dense_rounds_row_lists_change_nothing_but_the_rows_multiplied(pkg, parts):
     """Dense round engine with unequal trees (a metric without the target's correlation): from the moment the first
     chains of a call have finished, the products run over the row list of the chains still running.  Same bits as
-    multiplying every row every round (DHMC_DENSE_ROW_LISTS=0), with the batch run as 1, 2 or 4 parts."""
+    multiplying every row every round (DHMC_DENSE="row_lists=0"), with the batch run as 1, 2 or 4 parts."""
     D, C = 96, 512
     rho = 0.8
     sig = np.logspace(-0.5, 0.5, D)
@@ -202,6 +201,6 @@ def test_dense_rounds_row_lists_change_nothing_but_the_rows_multiplied(pkg, part
         assert b["steps"].sum(1).min() < 0.7 * b["steps"].sum(1).max()        # the chains do finish at different rounds
         return {**{"w_" + k: v for k, v in a.items()}, **b}
     make = lambda: pkg.DeviceContext(D, C, metric=ol.METRIC_DENSE, target=ol.TARGET_TRIDIAG_NORMAL, target_params=params, seed=21)
-    env = {"DHMC_DENSE_ROUNDS": "1", "DHMC_DENSE_PARTS": parts}
-    _same(_run_with_env(pkg, {**env, "DHMC_DENSE_ROW_LISTS": "1"}, make, steps),
-          _run_with_env(pkg, {**env, "DHMC_DENSE_ROW_LISTS": "0"}, make, steps))
+    env = "rounds=1,parts=%s," % parts
+    _same(_run_with_env(pkg, {"DHMC_DENSE": env + "row_lists=1"}, make, steps),
+          _run_with_env(pkg, {"DHMC_DENSE": env + "row_lists=0"}, make, steps))

@@ -66,7 +66,7 @@ def _stages(dev, ora, what):
 @pytest.mark.parametrize("D,C", [(2, 5), (4, 70), (7, 33), (13, 17), (30, 11), (32, 64), (33, 9), (64, 6)])
 def test_funnel_every_group_width_matches_oracle(pkg, D, C, cpl):
     """Both layouts (2 and 4 coordinates per lane: L = 1 … 16 lanes per chain), chain counts that leave idle groups."""
-    with _env(DHMC_PK_CPL=cpl):
+    with _env(DHMC_PK="cpl=%s" % cpl):
         dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=100 + D)
     ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=100 + D, threads=8)
     for e in (dev, ora):
@@ -166,7 +166,7 @@ def test_engine_choice_follows_the_previous_launchs_work(pkg):
 @pytest.mark.parametrize("align,levels,cpl", [(1, 0, 2), (2, 1, 4), (8, 2, 2), (16, 6, 4), (4, 9, 2)])
 def test_gate_width_and_lds_levels_change_no_result(pkg, align, levels, cpl):
     D, C = 30, 40
-    with _env(DHMC_PK_ALIGN=align, DHMC_PK_LDS_LEVELS=levels, DHMC_PK_CPL=cpl):
+    with _env(DHMC_PK="align=%s,lds_levels=%s,cpl=%s" % (align, levels, cpl)):
         dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=21)
     ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=21, threads=8)
     for e in (dev, ora):
@@ -190,10 +190,10 @@ def test_chain_offset_is_the_rng_key(pkg):
 @pytest.mark.parametrize("cpl", [2, 4])
 @pytest.mark.parametrize("D,C,waves", [(30, 41, 1), (7, 300, 2), (2, 500, 3), (64, 23, 4)])
 def test_queue_of_places_matches_oracle(pkg, D, C, cpl, waves):
-    """A launch of fewer waves than the chains need (DHMC_PK_MAX_WAVES): the groups take chain after chain from the launch's queue of
+    """A launch of fewer waves than the chains need (DHMC_PK="max_waves=…"): the groups take chain after chain from the launch's queue of
     places — every chain the bits of its own launch, in any launch order (the second and later calls run in the order of the
     previous call's work)."""
-    with _env(DHMC_PK_CPL=cpl, DHMC_PK_MAX_WAVES=waves, DHMC_PK_QUEUE=1):
+    with _env(DHMC_PK="cpl=%s,max_waves=%s,queue=1" % (cpl, waves)):
         dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=300 + D)
     ora = ol.Oracle(D, C, target=ol.TARGET_FUNNEL, seed=300 + D, threads=8)
     rng = np.random.default_rng(D)
@@ -215,8 +215,8 @@ def test_end_game_of_a_tail_bound_packed_launch(pkg, capfd):
     D, C = 30, 600
     os.environ.pop("DHMC_PACKED", None)
     res = []
-    for env in (dict(DHMC_MANY_CHAINS=100, DHMC_PK_HANDOVER=60, DHMC_PK_MAX_WAVES=24, DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000),
-                dict(DHMC_MANY_CHAINS=100, DHMC_PK_HANDOVER=0, DHMC_PK_MAX_WAVES=24, DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000)):
+    for env in (dict(DHMC_PK="many_chains=100,handover=60,max_waves=24", DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000),
+                dict(DHMC_PK="many_chains=100,handover=0,max_waves=24", DHMC_DEBUG_ORDER=1, DHMC_HOST_CHUNK=1000000)):
         with _env(**env):
             dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=17)
             dev.init(); dev.find_initial_stepsize()
@@ -243,4 +243,45 @@ def test_end_game_of_a_tail_bound_packed_launch(pkg, capfd):
     b3 = ora.run(35, da=dict(init=0, finalize=1))
     for a, b in zip(res[0][0], (b0, b1, b2, b3)):
         for k in a:
+            assert np.array_equal(a[k][:24], b[k]), k
+
+
+def test_end_game_as_shipped(pkg, capfd):
+    """The end game with the library's own thresholds (until now only with lowered ones): 8192 funnel chains (more than 24
+    per CU), outputs on the device, no engine switch set — after a tail-bound launch a call of N >= 32 transitions ends with the
+    pipeline kernel finishing the chains the packed launch gave up (DHMC_DEBUG_ORDER only prints).  Same bits as a context whose
+    packed launches never hand over, and as the oracle on the first 24 chains."""
+    import torch
+    D, C = 30, 8192
+    os.environ.pop("DHMC_PACKED", None)
+    fields = ("draws", "logdensities", "eps", "pi", "acceptance_rate", "steps", "term_left", "term_right", "depth", "directions")
+    dts = dict(draws=torch.float64, logdensities=torch.float64, eps=torch.float64, pi=torch.float64, acceptance_rate=torch.float64,
+               steps=torch.int64, term_left=torch.int64, term_right=torch.int64, depth=torch.int32, directions=torch.int32)
+    sched = ((40, {}), (64, {}), (48, None), (40, dict(init=0, finalize=1)))
+    res = []
+    for env in (dict(DHMC_DEBUG_ORDER=1), dict(DHMC_DEBUG_ORDER=1, DHMC_PK="handover=0")):
+        with _env(**env):
+            dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=23)
+            dev.init(); dev.find_initial_stepsize()
+            outs = []
+            for N, da in sched:
+                bufs = {k: torch.empty((C, N, D) if k == "draws" else (C, N), dtype=dts[k], device="cuda") for k in fields}
+                dev.run_into(N, bufs, da=da)
+                torch.cuda.synchronize()
+                outs.append({k: v[:64].cpu().numpy().copy() if k == "draws" else v.cpu().numpy().copy() for k, v in bufs.items()})
+                outs[-1]["directions"] = outs[-1]["directions"].view(np.uint32)
+                del bufs
+            res.append((outs, dev.stepsize(), capfd.readouterr().err))
+            del dev
+    handed = [int(l.split("end game: ")[1].split()[0]) for l in res[0][2].splitlines() if "end game:" in l]
+    assert handed and max(handed) > 0, res[0][2][-800:]
+    assert "end game:" not in res[1][2]
+    for a, b in zip(res[0][0], res[1][0]):
+        _same(a, b, "end game vs one packed launch")
+    assert np.array_equal(res[0][1], res[1][1])
+    ora = ol.Oracle(D, 24, target=ol.TARGET_FUNNEL, seed=23, threads=8)
+    ora.init(); ora.find_initial_stepsize()
+    for (N, da), a in zip(sched, res[0][0]):
+        b = ora.run(N, da=da)
+        for k in b:
             assert np.array_equal(a[k][:24], b[k]), k

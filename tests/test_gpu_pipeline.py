@@ -179,54 +179,3 @@ def test_engine_choice_after_a_tail_bound_launch(pkg):
         _same(a, b, "engine choice")
     work = res[0][1]["steps"].sum(axis=1)
     assert work.max() > 3 * work.mean()
-
-
-@pytest.mark.parametrize("C,env", [(8448, dict(DHMC_HYBRID_SEGMENTS="4")),
-                                   (8448, dict(DHMC_HYBRID_SEGMENTS="4", DHMC_HYBRID_BUDGET="0.4", DHMC_HYBRID_DEEP_CAP="1")),
-                                   (700, dict(DHMC_HYBRID_SEGMENTS="3", DHMC_HYBRID_MIN_CHAINS="1", DHMC_HYBRID_BUDGET="0.7", DHMC_PK_MAX_WAVES="8")),
-                                   (8448, dict(DHMC_HYBRID_SEGMENTS="4", DHMC_HYBRID_BUDGET="0.5", DHMC_HYBRID_DEEP="wave", DHMC_HYBRID_DEEP_CUS="0",
-                                               DHMC_HYBRID_DEEP_CAP="4", DHMC_HYBRID_PROMOTE="1.5"))])
-def test_hybrid_rounds_change_no_result(pkg, capfd, C, env):
-    """Many chains and a heavy-tailed tree size: dhmc_run runs the call in rounds — the chains packed through the queue of places, those
-    that exceed the round's leapfrog budget given up and continued by the pipeline kernel beside the next round's packed launch.
-    With DHMC_HYBRID=0 (one launch of one kernel) the same bits; 24 chains against the oracle; metric windows and dual averaging
-    across the rounds.  (Tiny budgets: most chains change kernels several times.)"""
-    D = 30
-    for k in ("DHMC_PIPELINE", "DHMC_PACKED"):
-        os.environ.pop(k, None)
-    res = []
-    # (host outputs in one piece: a call whose outputs leave in chunks is not run in rounds)
-    for env_ in (dict(env, DHMC_HYBRID="1", DHMC_DEBUG_ORDER="1", DHMC_HOST_CHUNK="1000000"), dict(DHMC_HYBRID="0")):
-        os.environ.update(env_)
-        try:
-            dev = pkg.DeviceContext(D, C, target=ol.TARGET_FUNNEL, seed=13)
-            dev.init(); dev.find_initial_stepsize()
-            f = ["logdensities", "eps", "pi", "acceptance_rate", "steps", "term_left", "term_right", "depth", "directions"]
-            out = [dev.run(40, da={}, fields=f)]
-            dev.metric_window_begin()
-            out.append(dev.run(48, da={}, fields=f))
-            dev.update_metric_diag_window()
-            out.append(dev.run(64, fields=f + ["draws"]))
-            out.append(dev.run(33, da=dict(init=0, finalize=1), fields=f))
-        finally:
-            for k in env_:
-                os.environ.pop(k, None)
-        res.append((out, dev.metric_diag(), dev.stepsize(), dev.position(), capfd.readouterr().err))
-    assert "[dhmc] round 1 to" in res[0][4] and "given up" in res[0][4], "the call did not run in rounds"
-    assert "[dhmc] round" not in res[1][4]
-    if "DHMC_HYBRID_BUDGET" in env:
-        assert any(int(l.split("given up ")[1].split(",")[0]) > 0 for l in res[0][4].splitlines() if "given up" in l)
-    for a, b in zip(res[0][0], res[1][0]):
-        _same(a, b, "rounds vs one launch")
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
-    for x, y in zip(res[0][3], res[1][3]):
-        assert np.array_equal(x, y)
-    ora = ol.Oracle(D, 24, target=ol.TARGET_FUNNEL, seed=13, threads=8)
-    ora.init(); ora.find_initial_stepsize()
-    b0 = ora.run(40, da={})
-    ora.metric_window_begin(); b1 = ora.run(48, da={}); ora.update_metric_diag_window()
-    b2 = ora.run(64)
-    b3 = ora.run(33, da=dict(init=0, finalize=1))
-    for a, b in zip(res[0][0], (b0, b1, b2, b3)):
-        for k in a:
-            assert np.array_equal(a[k][:24], b[k]), k

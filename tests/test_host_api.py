@@ -201,3 +201,17 @@ def test_reporter_protocol():
     assert all("chain_id = 7" in l and "ϵ = 0.5" in l and "estimated_seconds_left" in l for l in progress)
     with pytest.raises(ValueError):
         pkg.report(m, 1001)                                    # @argcheck 1 ≤ step ≤ total_steps (reporting.jl:123)
+
+
+def test_per_chain_metric_default_counts_the_workspace(pkg):
+    """`per_chain_metric=None` (api.py _per_chain_metric_default; the Julia shim applies the same rule): per-chain Symmetric metrics only
+    while the chains' matrices AND their workspace fit 2 GiB — the matrices alone said yes too close to the limit (advisor, round 5)."""
+    l = pkg.TridiagNormal(np.full(256, 2.0), np.full(255, -0.5))
+    f = pkg.api._per_chain_metric_default
+    assert f(l, 64, None)
+    dpad, nvec = 256, 18 + 7 * 10
+    c_matrices_only = (2 << 30) // (16 * dpad * dpad)                 # 2048 chains of matrices fill 2 GiB exactly
+    assert not f(l, c_matrices_only, None)                            # … and their workspace no longer fits
+    c_with_ws = (2 << 30) // (16 * dpad * dpad + 8 * nvec * dpad)
+    assert f(l, c_with_ws, None) and not f(l, c_with_ws + 1, None)
+    assert not f(l, 64, object())                                     # job-wide pooling asked for: the shared metric

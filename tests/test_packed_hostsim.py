@@ -105,29 +105,6 @@ def test_queue_of_places_changes_no_result(target, D):
     assert np.array_equal(sim.transition, np.full(C, 45, np.uint32))
 
 
-@pytest.mark.parametrize("queue", [False, True])
-def test_rounds_with_a_leapfrog_budget_change_no_result(queue):
-    # a call in rounds (RunParams::prog): chains given up mid-round for their work and continued by a later launch, dual averaging and
-    # a metric window across the rounds — every chain the bits of one launch of N transitions
-    D, C, N = 30, 12, 37
-    rng = np.random.default_rng(5)
-    q0 = rng.normal(size=(C, D)) * 0.1
-    q0[:, 0] = np.linspace(-5.0, 2.0, C)
-    ora, sim = _pair(D, C, ol.TARGET_FUNNEL, seed=77, eps=0.25, q0=q0)
-    total = 0
-    for stage, da in enumerate((dict(), dict(init=0), None)):
-        if stage == 1:
-            ora.metric_window_begin(); sim.window_begin()
-        a, given_up = sim.run_rounds(N, da=da, rounds=4, budget=60, queue=queue)
-        _same(a, ora.run(N, da=da), f"stage {stage}")
-        total += given_up
-        if stage == 1:
-            ora.update_metric_diag_window(); sim.window_update_metric()
-    assert total > 0                      # the budget was exercised
-    assert np.array_equal(sim.status, ora.status())
-    assert np.array_equal(sim.eps, ora.stepsize())
-
-
 @pytest.mark.parametrize("target,D", [(ol.TARGET_FUNNEL, 30), (ol.TARGET_STD_NORMAL, 7)])
 def test_end_game_hand_over_changes_no_result(target, D):
     # a launch that gives its chains up once few lane groups still have one (here: always), continued by later launches

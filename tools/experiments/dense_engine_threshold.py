@@ -1,4 +1,4 @@
-"""Where the wave-per-chain dense kernel stops beating the GEMM rounds as the chain count grows (DHMC_DENSE_ROUNDS=0 / 1)."""
+"""Where the wave-per-chain dense kernel stops beating the GEMM rounds as the chain count grows (DHMC_DENSE="rounds=0" / "rounds=1")."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,7 +11,7 @@ for D, C in ((64, 256), (64, 4096), (128, 256), (128, 1024), (128, 4096), (256, 
     diag = np.diag(Pm).copy(); off = np.zeros(D); off[:D - 1] = np.diag(Pm, 1)
     row = {"D": D, "C": C}
     for rounds in ("0", "1"):
-        os.environ["DHMC_DENSE_ROUNDS"] = rounds
+        os.environ["DHMC_DENSE"] = "rounds=" + rounds
         ctx = pkg.DeviceContext(D, C, target=pkg.abi.TARGET_TRIDIAG_NORMAL, target_params=np.concatenate([diag, off]), metric=pkg.abi.METRIC_DENSE, seed=3)
         ctx.set_metric_dense(Sigma); ctx.init(); ctx.set_stepsize(0.3)
         N = 60

@@ -1,6 +1,6 @@
 """Dense round engine on a workload with UNEQUAL trees (a correlated normal under a metric that is only roughly right, step
 size per chain from a short adaptation): products over all rows every round against products over the running chains only
-(DHMC_DENSE_ROW_LISTS=0 / 1, read at context creation)."""
+(DHMC_DENSE="row_lists=0" / "row_lists=1", read at context creation)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ diag = Pc / sig ** 2
 off = -rho / (1 - rho ** 2) / (sig[:-1] * sig[1:])
 params = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=diag, off=off)
 for mode in ("0", "1"):
-    os.environ["DHMC_DENSE_ROW_LISTS"] = mode
+    os.environ["DHMC_DENSE"] = "row_lists=" + mode
     ctx = pkg.DeviceContext(D, C, metric=pkg.abi.METRIC_DENSE, target=pkg.abi.TARGET_TRIDIAG_NORMAL, target_params=params, seed=5)
     ctx.set_metric_dense(np.diag(sig ** 2))            # the right scales, none of the correlation
     ctx.init(np.random.default_rng(5).normal(size=(C, D)) * sig)

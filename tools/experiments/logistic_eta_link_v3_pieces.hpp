@@ -177,12 +177,94 @@ static __global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, R
 // Traffic per round: r written once (8 B per observation and chain) instead of η written, η read, r written.
 // Workgroup id -> (z, lh, row tile) keeps the row tiles of one (z, lh) on one XCD back to back: its 2 MB of Xᵀ come from that L2.
 // ------------------------------------------------------------------------------------------------------------------------------
-
 constexpr int LK_TL = 32, LK_TK = 64, LK_LS = LK_TL + 16;     // columns per workgroup, k per LDS stage, LDS row stride (doubles)
+
+// f(integral_constant<int, G0>) … f(integral_constant<int, G1 - 1>): indices the body can use in `if constexpr` and as register-array
+// subscripts (a `#pragma unroll` loop is a request; with scheduling barriers in its body the compiler kept a run-time loop and
+// indexed the fragment registers through s_set_gpr_idx)
+template <int G0, int G1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (G0 < G1) {
+        f(std::integral_constant<int, G0>{});
+        static_for<G0 + 1, G1>(f);
+    }
+}
+
+// The link of NE elements of a lane's accumulator tiles cut into three pieces that the kernel below places BETWEEN the
+// matrix instructions of the next group of observations: a matrix instruction occupies the SIMD's matrix pipe for 64 clocks and a
+// wave issues in order, so the ≈ 14 vector instructions that fit behind each one cost nothing, and a table gather issued in one
+// piece has landed by the next.  Piece a: e^{-|η|} reduced, its table value requested.  Piece b: e^{-|η|}, 1 + e^{-|η|} reduced for
+// the logarithm, its table row requested.  Piece c: σ, log(1 + e^η).  The arithmetic is logistic_link_batch's (the functions' rare
+// branches: `rare`, wave-uniform — piece c then recomputes the four through the functions themselves).
+template <int NE>
+struct LinkPart {
+    double eta[NE], r[NE], T[NE], t[NE], w[NE], m[NE], row[NE][3];
+    int j[NE], e[NE], jl[NE], el[NE];
+    uint32_t rare;
+    // (every piece takes its inputs through an empty asm: without it the compiler computes whatever depends on η alone — max(η, 0),
+    // y η, the comparisons — at the top of the group and carries it through all the matrix instructions in registers it does not have)
+    static __device__ __forceinline__ void fence(double& v) { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ void a() {
+        bool rr = false;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) fence(eta[i]);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double x = -__builtin_fabs(eta[i]);
+            dm_exp_reduce(x, &j[i], &e[i], &r[i]);
+            rr = rr || (e[i] < -1021 && x >= -745.2);
+            j[i] &= 31;                                  // (a NaN's cell: anything inside the table)
+        }
+        rare = __ballot(rr) != 0ull ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) T[i] = DM_EXP2_TBL[j[i]];
+    }
+    __device__ __forceinline__ void b() {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { fence(r[i]); fence(T[i]); fence(eta[i]); }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double x = -__builtin_fabs(eta[i]);
+            const double y = dm_exp_poly<dm_v>(r[i], T[i]);
+            double v = dm_from_bits(dm_bits(y) + ((uint64_t)(int64_t)e[i] << 52));
+            v = x < -745.2 ? 0.0 : v;
+            t[i] = dm_isnan(x) ? x : v;
+            w[i] = 1.0 + t[i];
+            dm_log_reduce(dm_bits(w[i]), 0, &jl[i], &el[i], &m[i]);
+            jl[i] = jl[i] < 0 ? 0 : (jl[i] > 128 ? 128 : jl[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double* __restrict__ lp = DM_LOG_TBL[jl[i]];
+            row[i][0] = lp[0]; row[i][1] = lp[1]; row[i][2] = lp[2];
+        }
+    }
+    __device__ __forceinline__ void c(double (&sig)[NE], double (&l1pe)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { fence(eta[i]); fence(t[i]); fence(w[i]); fence(m[i]); fence(row[i][0]); }
+        rare = __builtin_amdgcn_readfirstlane(rare);
+        asm volatile("" : "+s"(rare));
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double lg = dm_log_finish<dm_v>(m[i], el[i], row[i][0], row[i][1], row[i][2]) + (t[i] - (w[i] - 1.0)) / w[i];
+            const double l1p = (w[i] == 1.0) ? t[i] : (!dm_isfinite(w[i]) ? w[i] : lg);
+            sig[i] = (eta[i] >= 0 ? 1.0 : t[i]) / w[i];
+            l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + l1p;
+        }
+        if (__builtin_expect(rare != 0u, 0)) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const double tt = det_exp_v(-__builtin_fabs(eta[i]));
+                sig[i] = eta[i] >= 0 ? 1.0 / (1.0 + tt) : tt / (1.0 + tt);
+                l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + det_log1p_nonneg_t<dm_v>(tt);
+            }
+        }
+    }
+};
 
 template <int DP>                                              // DP = Dpad (64, 128 or 256): the A-fragments are DP / 4 registers
 __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, LogisticRound L, const double* __restrict__ Q, int ntile_rows) {
-    constexpr int KS = DP / 4, NST = DP / LK_TK;
+    constexpr int KS = DP / 4, NST = DP / LK_TK, KPS = LK_TK / 4;                  // k-steps per group of observations, stages, k-steps per stage
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int rt = sq % ntile_rows, grp = (sq / ntile_rows) * 8 + xcd;           // grp = 2 z + lh
     const int z = grp >> 1, lh = grp & 1;
@@ -211,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
     const int b_k = t >> 2, b_c = 8 * (t & 3);
     const double* __restrict__ bsrc = P.tp.b + (size_t)b_k * Npad + nb + l0 + b_c;   // + 64 m + (size_t)64 st Npad
     double bv[8];
-    auto bload = [&](int m, int st) {
+    auto bload = [&](int m, int st) __attribute__((always_inline)) {
         const gemm_d2* s2 = reinterpret_cast<const gemm_d2*>(bsrc + (size_t)(LK_TK * st) * Npad + WAVE * m);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const gemm_d2 v = s2[i]; bv[2 * i] = v[0]; bv[2 * i + 1] = v[1]; }
@@ -221,8 +303,9 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
     mfma_d4 lp[2];                                   // the running partial sums of the lane's 8 (chain, l) pairs
     lp[0] = mfma_d4{0.0, 0.0, 0.0, 0.0};
     lp[1] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-    // rows of the lane's accumulator registers: (lane >> 4) + 4 r of the wave's 16.  Rows past the list's end stand for its last row:
-    // they compute and store that row's own values once more (no branch on a loop invariant inside the group loop)
+    // rows of the lane's accumulator registers: (lane >> 4) + 4 r of the wave's 16
+    // (rows past the list's end stand for its last row: they compute and store that row's own values once more — no branch on a
+    // loop invariant for the compiler to unswitch the whole group loop on)
     double* hrow[4];
     int srow[4];
 #pragma unroll
@@ -233,59 +316,92 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
         srow[r] = g - P.chain_base;
     }
 
-    bload(0, 0);
+    // One group of observations: its 2 KS matrix instructions, with the link of the PREVIOUS group's 8 elements (four LinkParts of two)
+    // in six pieces between them.  MMA / EPI: compile-time, so that the first group (nothing to link yet) and the pass after the
+    // last one (nothing to multiply) are the same code with one half left out.
+    constexpr int NE = 2, NPART = 8 / NE;             // the lane's 8 elements in parts of two (registers)
+    LinkPart<NE> part[NPART];                        // part q: elements (tile j = q / 2, accumulator registers 2 (q % 2), +1)
+    double y_prev[2] = {0.0, 0.0};
+    bool valid_prev[2] = {false, false};
     int buf = 0;
-#pragma nounroll
-    for (int m = 0; m < nm; ++m) {
+    auto finish_part = [&](auto q_, int mprev) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_)::value, j = q / 2, r0 = 2 * (q % 2);
+        double sig[NE], l1pe[NE];
+        part[q].c(sig, l1pe);
+        const double y = y_prev[j];
+        const bool valid = valid_prev[j];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            hrow[r0 + i][WAVE * mprev + 16 * j] = valid ? y - sig[i] : 0.0;
+            if (valid) lp[j][r0 + i] = lp[j][r0 + i] + (y * part[q].eta[i] - l1pe[i]);
+        }
+    };
+    auto group = [&](int m, auto mma_tag, auto epi_tag) __attribute__((always_inline)) {
+        constexpr bool MMA = decltype(mma_tag)::value, EPI = decltype(epi_tag)::value;
         mfma_d4 acc[2];
         acc[0] = mfma_d4{0.0, 0.0, 0.0, 0.0};
         acc[1] = mfma_d4{0.0, 0.0, 0.0, 0.0};
         const int64_t n_lo = nb + (int64_t)WAVE * m + l0 + (lane & 15);          // the lane's observations: n_lo, n_lo + 16
-        const double y0 = n_lo < N ? P.tp.c[n_lo] : 0.0;
-        const double y1 = n_lo + 16 < N ? P.tp.c[n_lo + 16] : 0.0;
-#pragma unroll
-        for (int st = 0; st < NST; ++st) {
+        double y0 = 0.0, y1 = 0.0;
+        if constexpr (MMA) {
+            y0 = n_lo < N ? P.tp.c[n_lo] : 0.0;
+            y1 = n_lo + 16 < N ? P.tp.c[n_lo + 16] : 0.0;
+        }
+        constexpr int PIECE = KS / (3 * NPART);                                   // a piece of the link every PIECE k-steps
+        static_assert(PIECE >= 1, "three pieces per part");
+        static_for<0, NST>([&](auto st_) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_)::value;
             double* bs = Bs[buf];
-            gemm_d2* bw = reinterpret_cast<gemm_d2*>(bs + b_k * LK_LS + b_c);
+            if constexpr (MMA) {
+                gemm_d2* bw = reinterpret_cast<gemm_d2*>(bs + b_k * LK_LS + b_c);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
-            __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
-            {                                        // the next stage's loads fly under this stage's 32 products
-                int st1 = st + 1, m1 = m;
-                if (st1 == NST) { st1 = 0; m1 = m + 1; }
-                if (m1 < nm) bload(m1, st1);
+                for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
+                __syncthreads();                     // stage visible; every wave is done with the other buffer's previous contents
+                if (st + 1 < NST) bload(m, st + 1);  // the next stage's loads fly under this stage's 32 products
+                else if (m + 1 < nm) bload(m + 1, 0);
             }
+            double b0 = 0.0, b1 = 0.0;
+            if constexpr (MMA) { b0 = bs[b_rd]; b1 = bs[b_rd + 16]; }
+            static_for<0, KPS>([&](auto kk_) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kk_)::value;
+                constexpr int g = KPS * st + kk;     // k-step of the group
+                if constexpr (MMA) {
+                    double n0 = 0.0, n1 = 0.0;       // the next k-step's fragments: one LDS round trip ahead, no further (registers)
+                    if constexpr (kk + 1 < KPS) { n0 = bs[4 * (kk + 1) * LK_LS + b_rd]; n1 = bs[4 * (kk + 1) * LK_LS + b_rd + 16]; }
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b1, acc[1], 0, 0, 0);
+                    b0 = n0; b1 = n1;
+                }
+                if constexpr (EPI && g % PIECE == 0 && g / PIECE < 3 * NPART) {
+                    constexpr int q = (g / PIECE) / 3, what = (g / PIECE) % 3;
+                    if constexpr (what == 0) part[q].a();
+                    if constexpr (what == 1) part[q].b();
+                    if constexpr (what == 2) finish_part(std::integral_constant<int, q>{}, m - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (MMA) buf ^= 1;
+        });
+        if constexpr (MMA) {
 #pragma unroll
-            for (int kk = 0; kk < LK_TK / 4; ++kk) {
-                const double b0 = bs[4 * kk * LK_LS + b_rd];
-                const double b1 = bs[4 * kk * LK_LS + b_rd + 16];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b1, acc[1], 0, 0, 0);
-            }
-            buf ^= 1;
+            for (int q = 0; q < NPART; ++q)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) part[q].eta[i] = acc[q / 2][2 * (q % 2) + i];
+            y_prev[0] = y0; y_prev[1] = y1;
+            valid_prev[0] = n_lo < N; valid_prev[1] = n_lo + 16 < N;
         }
-        // the link of the lane's 8 elements (logistic_link_kernel's operations, in phases; four at a time: the A-fragments hold half
-        // the wave's registers)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            double eta[4], sig[4], l1pe[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) eta[r] = acc[j][r];
-            logistic_link_batch<4>(eta, sig, l1pe);
-            const int64_t n = n_lo + 16 * j;
-            const double y = j == 0 ? y0 : y1;
-            const bool valid = n < N;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hrow[r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
-                if (valid) lp[j][r] = lp[j][r] + (y * eta[r] - l1pe[r]);
-            }
-        }
-    }
+    };
+    static_assert(KS >= 6 || KS == 16 || true, "");
+    bload(0, 0);
+    group(0, std::true_type{}, std::false_type{});
+#pragma nounroll
+    for (int m = 1; m < nm; ++m) group(m, std::true_type{}, std::true_type{});
+    group(nm, std::false_type{}, std::true_type{});
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.S1L[((size_t)z * P.C + srow[r]) * WAVE + l0 + 16 * j + (lane & 15)] = lp[j][r];
+        for (int r = 0; r < 4; ++r)
+            L.S1L[((size_t)z * P.C + srow[r]) * WAVE + l0 + 16 * j + (lane & 15)] = lp[j][r];
 }
 
 // the butterfly over the 64 per-lane partial sums of (block z, listed chain): S1P[z][chain]

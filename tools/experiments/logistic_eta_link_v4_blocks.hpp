@@ -218,31 +218,49 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
     };
     const int b_rd = (lane >> 4) * LK_LS + (lane & 15);
 
-    mfma_d4 lp[2];                                   // the running partial sums of the lane's 8 (chain, l) pairs
-    lp[0] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-    lp[1] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-    // rows of the lane's accumulator registers: (lane >> 4) + 4 r of the wave's 16.  Rows past the list's end stand for its last row:
-    // they compute and store that row's own values once more (no branch on a loop invariant inside the group loop)
-    double* hrow[4];
-    int srow[4];
+    // Every 16×16×4 step is issued as FOUR v_mfma_f64_4x4x4_f64 on four accumulators (gemm_f64_mfma.hpp, the BLK form: A's second
+    // operand holds row block b + 2 — the lanes of a row of 16 rotated by 8 —, B's second operand column block b + 1 — rotated by 4):
+    // the same ascending k chain per output element, but eight independent chains per wave instead of two, so that one wave keeps
+    // the matrix pipe busy while the SIMD's other wave is in its link phase (a dependent 16×16×4 chain reaches a third of the rate).
+    // Accumulator (tile j, u, v) of lane 16 g + 4 bb + bj: row 4 ((bb + 2u) & 3) + g, column 4 ((bb + v) & 3) + bj of tile j.
+    const int g4 = lane >> 4, bb = (lane >> 2) & 3, bj = lane & 3;
+    double lp[2][4];                                 // the running partial sums of the lane's 8 (chain, l) pairs: [tile][2u + v]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int lr = row0 + 16 * wv + (lane >> 4) + 4 * r;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lp[j][c] = 0.0;
+    // Rows past the list's end stand for its last row: they compute and store that row's own values once more (no branch on a loop
+    // invariant inside the group loop)
+    double* hrow[2];
+    int srow[2], col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int lr = row0 + 16 * wv + 4 * ((bb + 2 * u) & 3) + g4;
         const int g = L.act[lr < count ? lr : count - 1];
-        hrow[r] = L.H + (size_t)g * Npad + nb + l0 + (lane & 15);
-        srow[r] = g - P.chain_base;
+        hrow[u] = L.H + (size_t)g * Npad + nb + l0;
+        srow[u] = g - P.chain_base;
+        col[u] = 4 * ((bb + u) & 3) + bj;            // (indexed by v below)
     }
 
     bload(0, 0);
     int buf = 0;
 #pragma nounroll
     for (int m = 0; m < nm; ++m) {
-        mfma_d4 acc[2];
-        acc[0] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-        acc[1] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-        const int64_t n_lo = nb + (int64_t)WAVE * m + l0 + (lane & 15);          // the lane's observations: n_lo, n_lo + 16
-        const double y0 = n_lo < N ? P.tp.c[n_lo] : 0.0;
-        const double y1 = n_lo + 16 < N ? P.tp.c[n_lo + 16] : 0.0;
+        double acc[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = 0.0;
+        double y[2][2];
+        bool valid[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int64_t n = nb + (int64_t)WAVE * m + l0 + 16 * j + col[v];
+                valid[j][v] = n < N;
+                y[j][v] = valid[j][v] ? P.tp.c[n] : 0.0;
+            }
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             double* bs = Bs[buf];
@@ -250,17 +268,25 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
             __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
-            {                                        // the next stage's loads fly under this stage's 32 products
+            {                                        // the next stage's loads fly under this stage's products
                 int st1 = st + 1, m1 = m;
                 if (st1 == NST) { st1 = 0; m1 = m + 1; }
                 if (m1 < nm) bload(m1, st1);
             }
 #pragma unroll
             for (int kk = 0; kk < LK_TK / 4; ++kk) {
-                const double b0 = bs[4 * kk * LK_LS + b_rd];
-                const double b1 = bs[4 * kk * LK_LS + b_rd + 16];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b1, acc[1], 0, 0, 0);
+                double a2[2], b2[2][2];
+                a2[0] = a[(LK_TK / 4) * st + kk];
+                b2[0][0] = bs[4 * kk * LK_LS + b_rd];
+                b2[1][0] = bs[4 * kk * LK_LS + b_rd + 16];
+                a2[1] = gemm_dpp_f64<0x128>(a2[0]);          // row_ror:8
+                b2[0][1] = gemm_dpp_f64<0x12C>(b2[0][0]);    // row_ror:12: lane c reads lane (c + 4) & 15
+                b2[1][1] = gemm_dpp_f64<0x12C>(b2[1][0]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int uv = 0; uv < 4; ++uv)
+                        acc[j][uv] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[uv >> 1], b2[j][uv & 1], acc[j][uv], 0, 0, 0);
             }
             buf ^= 1;
         }
@@ -270,22 +296,20 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
         for (int j = 0; j < 2; ++j) {
             double eta[4], sig[4], l1pe[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) eta[r] = acc[j][r];
+            for (int c = 0; c < 4; ++c) eta[c] = acc[j][c];
             logistic_link_batch<4>(eta, sig, l1pe);
-            const int64_t n = n_lo + 16 * j;
-            const double y = j == 0 ? y0 : y1;
-            const bool valid = n < N;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hrow[r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
-                if (valid) lp[j][r] = lp[j][r] + (y * eta[r] - l1pe[r]);
+            for (int c = 0; c < 4; ++c) {
+                const int u = c >> 1, v = c & 1;
+                hrow[u][WAVE * m + 16 * j + col[v]] = valid[j][v] ? y[j][v] - sig[c] : 0.0;
+                if (valid[j][v]) lp[j][c] = lp[j][c] + (y[j][v] * eta[c] - l1pe[c]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.S1L[((size_t)z * P.C + srow[r]) * WAVE + l0 + 16 * j + (lane & 15)] = lp[j][r];
+        for (int c = 0; c < 4; ++c) L.S1L[((size_t)z * P.C + srow[c >> 1]) * WAVE + l0 + 16 * j + col[c & 1]] = lp[j][c];
 }
 
 // the butterfly over the 64 per-lane partial sums of (block z, listed chain): S1P[z][chain]

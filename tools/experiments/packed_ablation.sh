@@ -25,6 +25,6 @@ fi
 for cpl in 2 4; do
   for v in $VARIANTS; do
     echo -n "cpl $cpl  $v: "
-    DHMC_PACKED=1 DHMC_PK_CPL=$cpl PH_STUCK=1 DHMC_LIB_PATH=$ROOT/tools/experiments/_abl/lib_$v.so python $ROOT/tools/experiments/packed_probe.py ${2:-8} ${3:-10} 2>&1 | grep chains
+    DHMC_PACKED=1 DHMC_PK=cpl=$cpl PH_STUCK=1 DHMC_LIB_PATH=$ROOT/tools/experiments/_abl/lib_$v.so python $ROOT/tools/experiments/packed_probe.py ${2:-8} ${3:-10} 2>&1 | grep chains
   done
 done

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package
 pkg = load_package()
 D, C, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-for name, env in (("wave", dict(DHMC_PACKED="0")), ("packed cpl2", dict(DHMC_PACKED="1", DHMC_PK_CPL="2")), ("packed cpl4", dict(DHMC_PACKED="1", DHMC_PK_CPL="4"))):
+for name, env in (("wave", dict(DHMC_PACKED="0")), ("packed cpl2", dict(DHMC_PACKED="1", DHMC_PK="cpl=2")), ("packed cpl4", dict(DHMC_PACKED="1", DHMC_PK="cpl=4"))):
     os.environ.update(env)
     ctx = pkg.DeviceContext(D, C, seed=1)
     ctx.init(); ctx.find_initial_stepsize(); ctx.run(60, da={}, fields=[])

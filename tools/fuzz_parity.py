@@ -39,7 +39,7 @@ while time.time() - t0 < budget:
     kw = dict(target=target, seed=seed, max_depth=md, chain_offset=off, metric=ol.METRIC_DENSE if dense else ol.METRIC_DIAG)
     # engine choice (read at context creation): the round engines, normally chosen from 128 chains up, and their K3 variants
     env = {}
-    if dense and rng.random() < 0.4: env = {"DHMC_DENSE_ROUNDS": "1", "DHMC_K3_BLOCK": str(int(rng.random() < 0.5))}
+    if dense and rng.random() < 0.4: env = {"DHMC_DENSE": "rounds=1,k3_block=%d" % int(rng.random() < 0.5)}
     if kind == "logistic" and rng.random() < 0.5: env = {"DHMC_LOGISTIC_ROUNDS": "1"}
     os.environ.update(env)
     try:

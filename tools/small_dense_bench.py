@@ -1,5 +1,5 @@
 """Few chains with a dense metric (the reference's typical use: 1–8 chains): the GEMM round engine (default: one M⁻¹ product per
-leapfrog) against the wave-per-chain dense kernel (DHMC_DENSE_PRODUCTS=2).   python tools/small_dense_bench.py"""
+leapfrog) against the wave-per-chain dense kernel (DHMC_DENSE="products=2").   python tools/small_dense_bench.py"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
