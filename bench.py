@@ -318,7 +318,7 @@ def bench_config45(args, pkg, torch):
         if flops_per_leapfrog:
             ach = lf * flops_per_leapfrog / (sum(kms) * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
-                    "kernel": "gemm_rows_f64_kernel (fp64 MFMA; Q'·Xᵀ over the active rows, R·X split over blocks of observations), share of whole round time",
+                    "kernel": "logistic_eta_link_kernel (fp64 MFMA: Q'·Xᵀ over the active rows with the link in its epilogue) + gemm_rows_f64_kernel (R·X split over blocks of observations), share of whole round time",
                     "note": "4·N·p flops per leapfrog of the chains that took it / total kernel time of the rounds"}
         else:
             ach = lf * 48.0 * D / (sum(kms) * 1e-3) / 1e9

@@ -75,6 +75,8 @@ struct dhmc_ctx {
     hipEvent_t ev_done[2] = {};
     int64_t host_chunk = 0;    // DHMC_HOST_CHUNK: transitions per chunk of a call with host outputs (0: ≈1 GiB of draws per chunk)
     const UserKernels* user = nullptr;   // target >= DHMC_TARGET_USER_BASE: the run-time compiled kernels of the caller's functor
+    hipFunction_t user_packed = nullptr; // … and its packed per-draw kernel (D <= 64, a functor whose ℓ is a sum of per-coordinate terms)
+    int user_packed_cpl = 0;             //     for this many coordinates per lane (the module holds one lane-group shape)
     hipFunction_t user_eval = nullptr;   // … beyond 1024 coordinates: its batched evaluation for the streaming round engine (user stays null)
     void* d_user_params = nullptr;
     // the per-draw kernels' launch order (nuts_kernels.hpp RunParams::launch_order): chains sorted by the leapfrog steps of the previous

@@ -22,8 +22,10 @@ uint64_t rtc_checksum(const char* p, uint64_t n) {      // FNV-1a over the code 
     for (uint64_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
     return h;
 }
+// npl < 0: the PACKED per-draw kernel alone (several chains per wavefront, packed_kernels.hpp PackedFunctor), -npl = 100 L + cpl
 std::vector<std::string> rtc_kernel_names(const std::string& name, int npl, bool dense) {
     const std::string T = "dhmc::" + name, N = std::to_string(npl);
+    if (npl < 0) return {"dhmc::nuts_run_packed_kernel<dhmc::PackedFunctor<" + T + ">, " + std::to_string((-npl) / 100) + ", " + std::to_string((-npl) % 100) + ">"};
     if (npl >= 32) return {"dhmc::functor_eval_kernel<" + T + ", " + N + ">"};      // beyond 1024 coordinates: the batched evaluation only
     if (!dense) {
         std::vector<std::string> names = {"dhmc::nuts_run_kernel<" + T + ", " + N + ", true>", "dhmc::nuts_run_kernel<" + T + ", " + N + ", false>",
@@ -45,7 +47,8 @@ int rtc_compile(const std::string& source, const std::string& name, int npl, boo
     src += "\n// ---- the caller's functor -------------------------------------------------------------\n";
     src += source;
     // the functor's traits for the host (dhmc_create reads the symbol: which kernels may run it)
-    src += "\nextern \"C\" __device__ __attribute__((used)) int dhmc_user_traits = (dhmc::" + name + "::kRecomputeGrad ? 1 : 0) | (dhmc::" + name + "::kBigDims ? 2 : 0);\n";
+    src += "\nextern \"C\" __device__ __attribute__((used)) int dhmc_user_traits = (dhmc::" + name + "::kRecomputeGrad ? 1 : 0) | (dhmc::" + name + "::kBigDims ? 2 : 0)"
+           " | (dhmc::PackedFunctor<dhmc::" + name + ">::kEligible ? 4 : 0);\n";       // 4: may run packed (a sum of per-coordinate terms)
     const std::vector<std::string> exprs = rtc_kernel_names(name, npl, dense);
     // the architecture of the device the context lives on (this library's own kernels are built for gfx950; a functor follows
     // whatever device it will run beside them on)

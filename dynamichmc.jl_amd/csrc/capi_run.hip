@@ -136,11 +136,13 @@ void plan_packed_launch(RunCall& r) {
     // against 1.44e9 with four per lane at one wave per SIMD, 6.8e8 against 6.0e8 in calls of 20; profiles/r06_packed_occupancy2.txt)
     int cpl = D > 32 ? 4 : 2;
     if (c->pk_cpl && D <= 32) cpl = c->pk_cpl;
+    if (c->user_packed) cpl = c->user_packed_cpl;                  // (a caller's functor: the one lane-group shape its module was compiled for)
     const int L = pk::lanes_per_chain(D, cpl), gpw = 64 / L;
     const long long waves = ((long long)C + gpw - 1) / gpw;
     const int simd_waves = cpl == 2 ? 2 : 1;                       // resident waves per SIMD
     const long long wpc = std::min<long long>(4 * simd_waves, std::max<long long>(1, (waves + c->num_cus - 1) / c->num_cus));
-    const size_t budget = std::min<size_t>(pk::kMaxLdsPerWave, (size_t)160 * 1024 / (size_t)wpc);
+    // (a run-time compiled kernel is launched through the module API, which has no opt-in beyond 64 KB of dynamic LDS: 48 KB there)
+    const size_t budget = std::min<size_t>(c->user_packed ? (size_t)48 * 1024 : pk::kMaxLdsPerWave, (size_t)160 * 1024 / (size_t)wpc);
     const size_t fixed = pk::lds_bytes_per_wave(L, cpl, P.max_depth, 0);
     int levels = budget > fixed ? (int)((budget - fixed) / pk::lds_bytes_per_level(cpl)) : 0;
     if (c->pk_lds_levels >= 0) levels = c->pk_lds_levels;

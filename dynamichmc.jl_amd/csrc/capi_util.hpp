@@ -46,7 +46,8 @@ struct UserKernels {
     hipModule_t mod = nullptr;
     hipFunction_t run_lds = nullptr, run = nullptr, init = nullptr, search = nullptr, probe_traj = nullptr, probe_ratio = nullptr;
     hipFunction_t pipeline = nullptr;      // nuts_run_pipeline_kernel (chain widths of one or two slots per lane)
-    int traits = 0;                        // dhmc_user_traits of the module: 1 kRecomputeGrad, 2 kBigDims
+    int traits = 0;                        // dhmc_user_traits of the module: 1 kRecomputeGrad, 2 kBigDims, 4 PackedFunctor::kEligible
+    hipFunction_t packed = nullptr;        // nuts_run_packed_kernel<PackedFunctor<T>, L, cpl>: a module of its own per (L, cpl), key (device, -(100 L + cpl))
     // DHMC_METRIC_DENSE: a second module, compiled when the first dense context of this functor is created
     hipModule_t dense_mod = nullptr;
     hipFunction_t k0 = nullptr, k2 = nullptr, k3 = nullptr, run_dense = nullptr, search_dense = nullptr, probe_traj_dense = nullptr,

@@ -67,6 +67,15 @@ int dispatch(const dhmc_ctx* c, Op op, const void* P, hipStream_t stream_overrid
             return launch(R.l1_in_lds ? U.run_lds : U.run, WAVE,
                           (unsigned)(R.l1_in_lds ? lds_bytes(R.Dpad, true, lds_extra_levels(c->NPL)) : lds_bytes(R.Dpad, false, 0)), args);
         }
+        case Op::RunPacked: {
+            if (M || !c->user_packed) return DHMC_ERR_UNSUPPORTED;
+            RunParams Q;
+            int Lp = 0;
+            size_t lds = 0;
+            if (int r = packed_launch_prepare(*(const RunParams*)P, cs, &Q, &Lp, &grid, &lds)) return r;
+            void* args[] = {&Q};
+            return launch(c->user_packed, WAVE, (unsigned)lds, args);
+        }
         case Op::RunPipeline: {
             const RunParams& R = *(const RunParams*)P;
             if (M || !U.pipeline || c->NPL > 2) return DHMC_ERR_UNSUPPORTED;
@@ -358,6 +367,29 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
         }
         if (user_big) c->user_eval = it->second.eval;       // the streaming engine's kernels are the library's own (ExternalT)
         else c->user = &it->second;
+        // … and packed (several chains per wavefront, packed_kernels.hpp PackedFunctor) where ℓ is a sum of per-coordinate terms: one
+        // more module per lane-group shape (its only kernel), compiled when the first such context of the functor is created
+        if (c->user && (c->user->traits & 4) && cfg->metric == DHMC_METRIC_DIAG && pk::dim_is_packed(D)) {
+            const int cpl = D > 32 ? 4 : 2, Lp = pk::lanes_per_chain(D, cpl);
+            const auto pkey = std::make_pair((int)cfg->device, -(100 * Lp + cpl));
+            auto pit = U.built.find(pkey);
+            if (pit == U.built.end()) {
+                std::vector<char> code;
+                std::vector<std::string> low;
+                UserKernels K;
+                auto load = [&]() { return rtc_load(code, low, &K.mod, {&K.packed}); };
+                if ((rc = rtc_compile(U.source, U.name, pkey.second, false, &code, &low))) return fail(rc);
+                if ((rc = load())) {
+                    code.clear(); low.clear();
+                    if ((rc = rtc_compile(U.source, U.name, pkey.second, false, &code, &low, true)) || (rc = load())) return fail(rc);
+                }
+                pit = U.built.emplace(pkey, K).first;
+            }
+            c->user_packed = pit->second.packed;
+            c->user_packed_cpl = cpl;
+            c->packed = 1;
+            if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = std::atoi(e) != 0; c->packed_force = c->packed; }
+        }
         // the pipeline kernel for a functor whose gradient is recomputed from a stored position, up to two slots per lane
         if (c->user && c->user->pipeline && (c->user->traits & 1) && cfg->metric == DHMC_METRIC_DIAG && c->NPL <= 2) {
             c->pipeline = true;

@@ -228,6 +228,34 @@ struct PackedTarget<DHMC_TARGET_FUNNEL> {
     }
 };
 
+// ℓ = -1/2 q'Pq, P symmetric tridiagonal (targets.hpp TridiagNormalT): (Pq)_e = diag_e q_e + off_{e-1} q_{e-1} + off_e q_{e+1}.  A lane holds
+// CPL CONSECUTIVE coordinates, so only its first and last one look at a neighbour lane of the group (Grp::prev / Grp::next; the
+// group's outermost lanes read a lane of another chain there, and the conditions on e discard it exactly where the functor's do).
+template <>
+struct PackedTarget<DHMC_TARGET_TRIDIAG_NORMAL> {
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    const double* diag;
+    const double* off;
+    PK_FN explicit PackedTarget(const TargetParams& p) : diag(p.a), off(p.b) {}
+    template <int CPL, class Grp, class Pol>
+    PK_FN double eval(const double (&q)[CPL], double (&g)[CPL], int e0, int D) const {
+        const double left = Grp::prev(q[CPL - 1]), right = Grp::next(q[0]);
+        double t[CPL];
+        PK_UNROLL
+        for (int k = 0; k < CPL; ++k) {
+            const int e = e0 + k;
+            const double qm = k > 0 ? q[k > 0 ? k - 1 : 0] : left;
+            const double qp = k + 1 < CPL ? q[k + 1 < CPL ? k + 1 : k] : right;
+            double w = diag[e] * q[k];
+            if (e > 0 && e < D) w = w + off[e - 1] * qm;
+            if (e < D - 1) w = w + off[e] * qp;
+            t[k] = __builtin_fma(q[k], w, 0.0);
+            g[k] = -w;
+        }
+        return -0.5 * Grp::sum(Tree<CPL>::sum(t));
+    }
+};
+
 // the reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73; targets.hpp AlwaysDivergentT)
 template <>
 struct PackedTarget<DHMC_TARGET_ALWAYS_DIVERGENT> {
@@ -255,8 +283,8 @@ inline int lanes_per_chain(int D, int cpl) {
 }
 inline bool dim_is_packed(int D) { return D >= 1 && D <= 64; }
 inline bool family_is_packed(int target) {
-    return target == DHMC_TARGET_STD_NORMAL || target == DHMC_TARGET_DIAG_NORMAL || target == DHMC_TARGET_FUNNEL ||
-           target == DHMC_TARGET_ALWAYS_DIVERGENT;
+    return target == DHMC_TARGET_STD_NORMAL || target == DHMC_TARGET_DIAG_NORMAL || target == DHMC_TARGET_TRIDIAG_NORMAL ||
+           target == DHMC_TARGET_FUNNEL || target == DHMC_TARGET_ALWAYS_DIVERGENT;
 }
 // LDS of one wave (bytes): six rows per chain that are touched once per doubling (64·CPL doubles per row set of the wave's 64 / L
 // chains), `levels` suspended levels (1 .. levels: first, last, ρ, proposal), and four scalars per level and chain

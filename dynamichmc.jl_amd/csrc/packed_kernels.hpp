@@ -13,6 +13,7 @@ namespace dhmc {
 template <class T> struct PackedId { static constexpr int value = -1; };
 template <> struct PackedId<StdNormalT> { static constexpr int value = DHMC_TARGET_STD_NORMAL; };
 template <> struct PackedId<DiagNormalT> { static constexpr int value = DHMC_TARGET_DIAG_NORMAL; };
+template <> struct PackedId<TridiagNormalT> { static constexpr int value = DHMC_TARGET_TRIDIAG_NORMAL; };
 template <> struct PackedId<FunnelT> { static constexpr int value = DHMC_TARGET_FUNNEL; };
 template <> struct PackedId<AlwaysDivergentT> { static constexpr int value = DHMC_TARGET_ALWAYS_DIVERGENT; };
 
@@ -68,6 +69,26 @@ struct PackedGroup {
             return b;
         }
     }
+    // the value of the group's lane before / after this one (row_shr:1 / row_shl:1: a group never crosses a row of 16 lanes); the
+    // group's first / last lane gets a lane of the neighbouring group, or 0 at the row's edge — its caller does not use it
+    static __device__ __forceinline__ double prev(double x) {
+        if constexpr (L == 1) return 0.0;
+        else {
+            const uint64_t b = (uint64_t)__double_as_longlong(x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x111, 0xF, 0xF, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x111, 0xF, 0xF, true);
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        }
+    }
+    static __device__ __forceinline__ double next(double x) {
+        if constexpr (L == 1) return 0.0;
+        else {
+            const uint64_t b = (uint64_t)__double_as_longlong(x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x101, 0xF, 0xF, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x101, 0xF, 0xF, true);
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        }
+    }
     static __device__ __forceinline__ double pick(double x, int src) {
         if constexpr (L == 1) return x;
         else return __shfl(x, (int)((threadIdx.x & ~(unsigned)(L - 1)) + (unsigned)src));
@@ -99,10 +120,35 @@ struct PackedGroup {
 #define PK_PH_FLUSH(trips)
 #endif
 
+// A caller's device functor (or any functor of targets.hpp) as a packed evaluator, for the functors whose ℓ is a sum of per-coordinate
+// terms (kElementwise && kDeferred: "eval takes any element base as its lane argument", targets.hpp): the functor is called once per
+// coordinate with ONE slot — its partial sum is then exactly the leaf of the ABI's summation tree that the packed engine adds up
+// (lane-local adjacent pairs, then the group's DPP butterfly), and `finish` makes ℓ of the total.  Same bits as the functor through
+// the wave-per-chain kernel at one slot per lane.
+template <class T>
+struct PackedFunctor {
+    static constexpr bool kFiniteLqImpliesFiniteQ = T::kFiniteLqImpliesFiniteQ;
+    static constexpr bool kEligible = T::kElementwise && T::kDeferred && T::kRecomputeGrad && T::kFiniteLqImpliesFiniteGrad && !T::kBigDims;
+    T f;
+    __device__ explicit PackedFunctor(const TargetParams& p) : f(p) {}
+    template <int CPL, class Grp, class Pol>
+    __device__ __forceinline__ double eval(const double (&q)[CPL], double (&g)[CPL], int e0, int D) const {
+        double t[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const double q1[1] = {q[k]};
+            double g1[1];
+            t[k] = f.template eval<1>(q1, g1, e0 + k, D);
+            g[k] = g1[0];
+        }
+        return f.finish(Grp::sum(pk::Tree<CPL>::sum(t)));
+    }
+};
+
 // One wavefront per workgroup, 64 / L chains in it: group `grp` of workgroup b runs the chain in place b·(64/L) + grp of the launch
 // order (RunParams::launch_order: the chains sorted by the previous launch's work, longest first — so that chains with
 // persistently deep trees share waves instead of each holding a wave of finished chains open).
-template <int TGT, int L, int CPL>
+template <class PT, int L, int CPL>
 __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
     constexpr int GPW = 64 / L;
     const int sub = (int)(threadIdx.x & (L - 1));
@@ -125,39 +171,29 @@ __global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
 #undef PK_ATOMIC_ADD_ULL
 }
 
+#ifndef __HIPCC_RTC__      // (the host side; a caller's functor is compiled with hiprtc: kernels only)
 template <class T>
 int launch_run_packed(const RunParams& P, hipStream_t s) {
     constexpr int TGT = PackedId<T>::value;
     if constexpr (TGT < 0) {
         return DHMC_ERR_UNSUPPORTED;
     } else {
+        typedef pk::PackedTarget<TGT> PT;
+        RunParams Q;
+        int L = 0;
+        unsigned waves = 0;
+        size_t lds = 0;
+        if (int rc = packed_launch_prepare(P, s, &Q, &L, &waves, &lds)) return rc;
         const int cpl = P.pk_cpl;
-        const int L = pk::lanes_per_chain(P.D, cpl);
-        if (L == 0 || (cpl != 2 && cpl != 4)) return DHMC_ERR_UNSUPPORTED;
-        const int gpw = 64 / L;
-        // More places than the lane groups of pk_max_waves waves: that many waves start (the GPU holds them all at once) and the
-        // rest of the launch order waits in the queue — a group takes the next place when its chain is done, so that the lanes of
-        // chains with little work do not idle behind the longest chain of their wave.
-        const int places = P.C - P.pk_order_base;
-        int waves = (places + gpw - 1) / gpw;
-        RunParams Q = P;
-        if (Q.pk_queue && Q.pk_max_waves > 0 && waves > Q.pk_max_waves) {
-            waves = Q.pk_max_waves;
-            if (hipMemsetD32Async((hipDeviceptr_t)Q.pk_queue, P.pk_order_base + waves * gpw, 1, s) != hipSuccess) return DHMC_ERR_HIP;
-        } else {
-            Q.pk_queue = nullptr;
-        }
-        if (Q.pk_live && hipMemsetD32Async((hipDeviceptr_t)Q.pk_live, waves * gpw, 1, s) != hipSuccess) return DHMC_ERR_HIP;   // every group of the launch
-        const dim3 grid((unsigned)waves), block(64);
-        const size_t lds = pk::lds_bytes_per_wave(L, cpl, P.max_depth, P.pk_lds_levels);
+        const dim3 grid(waves), block(64);
 #define DHMC_PK_LAUNCH(LL, CC)                                                                                                 \
     if (L == LL && cpl == CC) {                                                                                                \
         static bool once = [] {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<TGT, LL, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk::kMaxLdsPerWave); \
+            (void)hipFuncSetAttribute((const void*)nuts_run_packed_kernel<PT, LL, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk::kMaxLdsPerWave); \
             return true;                                                                                                       \
         }();                                                                                                                   \
         (void)once;                                                                                                            \
-        hipLaunchKernelGGL((nuts_run_packed_kernel<TGT, LL, CC>), grid, block, lds, s, Q);                                     \
+        hipLaunchKernelGGL((nuts_run_packed_kernel<PT, LL, CC>), grid, block, lds, s, Q);                                      \
         return DHMC_OK;                                                                                                        \
     }
         DHMC_PK_LAUNCH(1, 2) DHMC_PK_LAUNCH(2, 2) DHMC_PK_LAUNCH(4, 2) DHMC_PK_LAUNCH(8, 2) DHMC_PK_LAUNCH(16, 2)
@@ -166,5 +202,6 @@ int launch_run_packed(const RunParams& P, hipStream_t s) {
         return DHMC_ERR_UNSUPPORTED;
     }
 }
+#endif
 
 }  // namespace dhmc

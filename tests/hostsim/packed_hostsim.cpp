@@ -18,6 +18,8 @@ struct HostGroup {
     template <int N> static void sum_n(double (&)[N]) {}
     static double sum(double x) { return x; }
     static double first(double x) { return x; }
+    static double prev(double) { return 0.0; }
+    static double next(double) { return 0.0; }
     static int first_i(int x) { return x; }
     static double pick(double x, int) { return x; }
     static bool all(bool p) { return p; }
@@ -30,6 +32,7 @@ static void run_chain(const RunParams& P, int place, double* lds_cold, double* l
     const int sub = 0, grp = 0;
     typedef HostGroup Grp;
     typedef dm_generic Pol;
+    typedef pk::PackedTarget<TGT> PT;
 #define PK_ATOMIC_ADD_ULL(ptr, v) (*(ptr) += (v))
 #define PK_QUEUE_NEXT(ptr) ((*(ptr))++)
 #define PK_LOAD_UINT(ptr) (*(ptr))
@@ -61,6 +64,7 @@ extern "C" int hostsim_packed_run(int target, const dhmc::RunParams* Pin, int us
         switch (target) {
         case DHMC_TARGET_STD_NORMAL: run_chain<DHMC_TARGET_STD_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_DIAG_NORMAL: run_chain<DHMC_TARGET_DIAG_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
+        case DHMC_TARGET_TRIDIAG_NORMAL: run_chain<DHMC_TARGET_TRIDIAG_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_FUNNEL: run_chain<DHMC_TARGET_FUNNEL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_ALWAYS_DIVERGENT: run_chain<DHMC_TARGET_ALWAYS_DIVERGENT>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         default: return 2;

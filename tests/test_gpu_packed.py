@@ -92,6 +92,14 @@ def test_normal_families_match_oracle(pkg, D):
     for e in (dev, ora):
         e.init(); e.set_stepsize(0.3)
     _stages(dev, ora, f"diag normal D={D}")
+    # the tridiagonal-precision normal (round 6): neighbour coordinates across the lanes of a group (DPP row shifts)
+    diag, off = rng.uniform(1.5, 3.0, size=D), rng.uniform(-0.6, 0.6, size=max(D - 1, 0))
+    blob = ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=diag, off=off)
+    dev = pkg.DeviceContext(D, C, target=ol.TARGET_TRIDIAG_NORMAL, target_params=blob, seed=6)
+    ora = ol.Oracle(D, C, target=ol.TARGET_TRIDIAG_NORMAL, params=blob, seed=6, threads=8)
+    for e in (dev, ora):
+        e.init(); e.set_stepsize(0.3)
+    _stages(dev, ora, f"tridiagonal normal D={D}")
 
 
 def test_divergences_depth_limits_and_always_divergent(pkg):

@@ -208,6 +208,7 @@ def test_user_functor_through_the_pipeline_kernel(pkg, D, monkeypatch, capfd):
     a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
     assert "engine: pipeline" in capfd.readouterr().err
     monkeypatch.setenv("DHMC_PIPELINE", "0")
+    monkeypatch.setenv("DHMC_PACKED", "0")            # (since round 6 such a functor would otherwise run packed)
     b = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3))
     assert "engine: wave" in capfd.readouterr().err
     o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3, threads=5))
@@ -215,3 +216,47 @@ def test_user_functor_through_the_pipeline_kernel(pkg, D, monkeypatch, capfd):
     for k in a:
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], o[k]), k
+
+
+@pytest.mark.parametrize("D", [7, 30, 50])
+def test_user_functor_through_the_packed_kernel(pkg, D, monkeypatch, capfd):
+    """A caller's functor whose ℓ is a sum of per-coordinate terms (kElementwise, kDeferred) through the PACKED kernel (several chains per
+    wavefront; csrc/packed_kernels.hpp PackedFunctor, one more hiprtc module per lane-group shape): the bits of the wave-per-chain
+    kernel (DHMC_PACKED=0) and of the oracle, over adaptive and fixed stages with a metric window; a second functor (Student-t: no
+    built-in family, its own deterministic log) packed against the wave kernel."""
+    rng = np.random.default_rng(D)
+    mu = rng.normal(size=D); prec = np.exp(rng.normal(size=D))
+    user = pkg.DeviceFunctorLogDensity(D, uf.DIAG_NORMAL, "MyDiagNormal", params=np.concatenate([mu, prec]))
+    C = 37
+
+    def steps(ctx, eps):
+        out = {}
+        ctx.init(); ctx.set_stepsize(eps)
+        ctx.metric_window_begin()
+        a = ctx.run(30, da={})
+        ctx.update_metric_diag_window()
+        out.update({"w_" + k: v for k, v in a.items()})
+        out.update({"i_" + k: v for k, v in ctx.run(17).items()})
+        q, lq, g = ctx.position()
+        out.update(q=q, lq=lq, g=g, minv=ctx.metric_diag(), eps=ctx.stepsize())
+        return out
+    monkeypatch.setenv("DHMC_DEBUG_ORDER", "1")
+    monkeypatch.setenv("DHMC_PACKED", "1")
+    a = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3), 0.2)
+    assert "engine: packed" in capfd.readouterr().err
+    monkeypatch.setenv("DHMC_PACKED", "0")
+    b = steps(pkg.DeviceContext(D, C, target=user.family, target_params=user.params(), seed=3), 0.2)
+    assert "engine: packed" not in capfd.readouterr().err
+    o = steps(ol.Oracle(D, C, target=ol.TARGET_DIAG_NORMAL, params=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec), seed=3, threads=8), 0.2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], o[k]), k
+    scale = np.exp(rng.normal(size=D) * 0.3)
+    t = pkg.DeviceFunctorLogDensity(D, uf.STUDENT_T, "StudentT", params=np.concatenate([[5.0], scale]))
+    monkeypatch.setenv("DHMC_PACKED", "1")
+    a = steps(pkg.DeviceContext(D, C, target=t.family, target_params=t.params(), seed=4), 0.3)
+    assert "engine: packed" in capfd.readouterr().err
+    monkeypatch.setenv("DHMC_PACKED", "0")
+    b = steps(pkg.DeviceContext(D, C, target=t.family, target_params=t.params(), seed=4), 0.3)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k

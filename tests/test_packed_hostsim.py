@@ -80,6 +80,12 @@ def test_normal_families_match_oracle(D):
                      blob=ol.target_params_blob(ol.TARGET_DIAG_NORMAL, D, mu=mu, prec=prec))
     _same(sim.run(25, da=dict()), ora.run(25, da=dict()), "diag normal, adaptive")
     _same(sim.run(25), ora.run(25), "diag normal")
+    # tridiagonal-precision normal (round 6: the packed engine's fifth family): an AR(1)-like precision, diagonally dominant
+    diag, off = rng.uniform(1.5, 3.0, size=D), rng.uniform(-0.6, 0.6, size=max(D - 1, 0))
+    ora, sim = _pair(D, C, ol.TARGET_TRIDIAG_NORMAL, seed=6, eps=0.3, params=(diag, np.concatenate([off, [0.0]])),
+                     blob=ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=diag, off=off))
+    _same(sim.run(25, da=dict()), ora.run(25, da=dict()), "tridiagonal normal, adaptive")
+    _same(sim.run(25), ora.run(25), "tridiagonal normal")
 
 
 def test_always_divergent_matches_oracle():
