@@ -616,6 +616,10 @@ __global__ __launch_bounds__(64, (NPL >= 8 && L1LDS) ? 1 : 2) void nuts_run_kern
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) p[k] = a_tm(k);
                 }
+                // The edge's rows are waited for HERE, not at their first use: the first use is the top of the leaf loop, whose other
+                // predecessor (its own back edge) has nothing outstanding — the compiler's counted waits (one per slot: 24 s_waitcnt
+                // at 16 slots per lane) then sat in every leapfrog for the sake of one edge switch per doubling.
+                __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
             }
             reg_edge = dir;
             int64_t i = fwd ? i_plus : i_minus;
