@@ -148,8 +148,10 @@ struct PackedFunctor {
 // One wavefront per workgroup, 64 / L chains in it: group `grp` of workgroup b runs the chain in place b·(64/L) + grp of the launch
 // order (RunParams::launch_order: the chains sorted by the previous launch's work, longest first — so that chains with
 // persistently deep trees share waves instead of each holding a wave of finished chains open).
+// (two coordinates per lane: TWO waves per SIMD — 256 registers each; the launch plans its LDS and its queue for that, capi_run.hip
+// plan_packed_launch — four per lane: one)
 template <class PT, int L, int CPL>
-__global__ __launch_bounds__(64, 1) void nuts_run_packed_kernel(RunParams P) {
+__global__ __launch_bounds__(64, CPL == 2 ? 2 : 1) void nuts_run_packed_kernel(RunParams P) {
     constexpr int GPW = 64 / L;
     const int sub = (int)(threadIdx.x & (L - 1));
     const int grp = (int)(threadIdx.x / L);
