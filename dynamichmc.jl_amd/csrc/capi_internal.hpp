@@ -39,13 +39,13 @@ struct dhmc_ctx {
     RoundBuffers rbp[4]{};     // dense round engine: the batch is run as up to 4 parts on as many streams; every part has its own
                                // list and counters, the vectors are shared
     hipStream_t streams[4] = {};
-    int dense_parts = 2;       // DHMC_DENSE_PARTS
-    int dense_row_lists = 1;   // DHMC_DENSE_ROW_LISTS: products over the running chains only once some have finished
+    int dense_parts = 2;       // DHMC_DENSE=parts=
+    int dense_row_lists = 1;   // DHMC_DENSE=row_lists=: products over the running chains only once some have finished
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_joins[4] = {};
     int dense_rounds = 1;
-    int fuse_k2 = 1;           // DHMC_FUSE_K2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
+    int fuse_k2 = 1;           // DHMC_DENSE=fuse_k2=0: K3b leaves the next position update / density evaluation to K2 (dense_rounds_k3b.hpp)
     int dense_products = 2;    // dhmc_set_dense_products: 2 = the reference's recurrence; 1 = one M⁻¹ product per leapfrog (either dense engine)
     int per_chain_dense = 0;   // cfg.dense_per_chain: every chain has its own M⁻¹ / Wᵀ ([C][Dpad][Dpad]); wave-per-chain kernels only
     int logistic_rounds = 0;   // GEMM-gradient round engine for DHMC_TARGET_LOGISTIC with a diagonal metric
@@ -96,14 +96,14 @@ struct dhmc_ctx {
     double mean_leapfrogs_per_transition = 0.0;   // of the previous call
     int* d_prog = nullptr;                 // [C] the end game of a packed launch: transitions of the call a chain has behind it …
     int* d_evicted = nullptr;              // [C] … and the chains the packed launch gave up, in the order it gave them up
-    int pk_handover = -1;                  // DHMC_PK_HANDOVER: the end game of a tail-bound packed launch starts at this many live lane groups (0: off; -1: what the pipeline kernel keeps resident)
-    int many_chains_min = 0;               // DHMC_MANY_CHAINS
-    int pk_queue = 1;                      // DHMC_PK_QUEUE=0: a packed launch starts a lane group per place (no queue of places)
-    int pk_max_waves = 0;                  // DHMC_PK_MAX_WAVES: the waves a queued packed launch starts (0: one per SIMD)
+    int pk_handover = -1;                  // DHMC_PK=handover=: the end game of a tail-bound packed launch starts at this many live lane groups (0: off; -1: what the pipeline kernel keeps resident)
+    int many_chains_min = 0;               // DHMC_PK=many_chains=
+    int pk_queue = 1;                      // DHMC_PK=queue=0: a packed launch starts a lane group per place (no queue of places)
+    int pk_max_waves = 0;                  // DHMC_PK=max_waves=: the waves a queued packed launch starts (0: what the GPU holds at once)
     int tail_count = 0;                    // places at the head of the launch order whose work was far above the median's
-    int pk_align = 0;                      // DHMC_PK_ALIGN: transitions start on trips that are multiples of it (a power of two; 0: from the tree sizes)
-    int pk_cpl = 0;                        // DHMC_PK_CPL: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
-    int pk_lds_levels = -1;                // DHMC_PK_LDS_LEVELS: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)
+    int pk_align = 0;                      // DHMC_PK=align=: transitions start on trips that are multiples of it (a power of two; 0: from the tree sizes)
+    int pk_cpl = 0;                        // DHMC_PK=cpl=: coordinates per lane, 2 or 4 (0: by chain count, dhmc_run)
+    int pk_lds_levels = -1;                // DHMC_PK=lds_levels=: suspended levels kept in LDS (-1: what the launch's occupancy leaves room for)
     int num_cus = 256;
     bool tail_bound = false;               // the previous launch was held open by a few chains with many times the mean's leapfrog steps
                                            // (dhmc_run: such launches go to the wave-per-chain kernel, whose leapfrog latency is lower)

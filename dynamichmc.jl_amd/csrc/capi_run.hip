@@ -116,7 +116,7 @@ void choose_engine(RunCall& r) {
     // END GAME of a tail-bound packed launch (many chains: the rule above): once few lane groups still have a chain — no more than the
     // pipeline kernel keeps resident — the packed kernel gives those chains up at their next transition boundary and the pipeline
     // kernel finishes them at a third of the latency per leapfrog: the launch's deepest chains, which would otherwise run on alone
-    // at 2.5 µs per trip (RunParams::pk_live, pk_handover_below; DHMC_PK_HANDOVER = the threshold, 0: off).
+    // at 2.5 µs per trip (RunParams::pk_live, pk_handover_below; DHMC_PK=handover= the threshold, 0: off).
     const bool endgame = packed && !c->packed_force && c->pipeline && c->tail_bound && many_chains && c->pk_handover != 0 &&
                          c->d_chain_work && c->launch_order_on && N >= kPolicy.endgame_min_transitions;
     r.per_draw_kernel = per_draw_kernel; r.packed = packed; r.pipeline = pipeline; r.endgame = endgame; r.run_op = run_op;

@@ -47,7 +47,7 @@ void launch_round_op(int which, const RoundArgs& a, hipStream_t s) {
     case 1: hipLaunchKernelGGL((rounds_k0_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     case 2: hipLaunchKernelGGL((rounds_k2_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE), 0, s, a.P, a.R); break;
     default:
-        // chains of 512+ coordinates: a workgroup (4+ waves) per chain; DHMC_K3_BLOCK=0 (read at dhmc_create) keeps the one-wave kernel
+        // chains of 512+ coordinates: a workgroup (4+ waves) per chain; DHMC_DENSE=k3_block=0 (read at dhmc_create) keeps the one-wave kernel
         if constexpr (NPL >= 8) {
             if (a.P.k3_block || NPL > 16) {
                 hipLaunchKernelGGL((rounds_k3b_kernel<T, NPL>), dim3(a.P.C), dim3(WAVE * k3b_waves(NPL)), 0, s, a.P, a.R);
