@@ -41,6 +41,7 @@ struct EnginePolicy {
     double tail_ratio = 3.0;                 // a launch was "tail-bound": max chain work > tail_ratio × mean chain work
     double reorder_ratio = 1.03;             // the next launch starts its chains longest-first from max > reorder_ratio × mean
     double few_chains_min_tree = 24.0;       // C <= CUs and trees of at least this many leapfrogs: the pipeline kernel
+    int dense_normal_chains_per_cu = 16;     // the dense-precision normal runs packed from this many chains per CU on (below: the wave kernel)
     int many_chains_per_cu = 24;             // from this many chains per CU on a tail-bound launch stays packed and gets an end game
     int many_chains_per_pipeline_slot = 13;  // … a family without a packed evaluator: the wave kernel from this many chains per resident pipeline block
     int endgame_min_transitions = 32;        // a call shorter than this is one packed launch
@@ -109,7 +110,8 @@ void choose_engine(RunCall& r) {
                          : kPolicy.many_chains_per_pipeline_slot * (int)((size_t)160 * 1024 / pipeline_lds_bytes(c->NPL <= 4 ? c->NPL : 4)) * c->num_cus;   // (5, 2 or 1 blocks per CU)
     const bool many_chains = C > many_min;
     const bool pipeline = per_draw_kernel && c->pipeline && !c->packed_force && (c->pipeline_force || (c->tail_bound && !many_chains) || few_chains);
-    const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || !c->tail_bound || many_chains);
+    const bool enough_chains = c->cfg.target != DHMC_TARGET_DENSE_NORMAL || C >= kPolicy.dense_normal_chains_per_cu * c->num_cus;
+    const bool packed = !pipeline && per_draw_kernel && c->packed && (c->packed_force || ((!c->tail_bound || many_chains) && enough_chains));
     const Op run_op = pipeline ? Op::RunPipeline : packed ? Op::RunPacked : Op::Run;
     if (per_draw_kernel && std::getenv("DHMC_DEBUG_ORDER"))
         std::fprintf(stderr, "[dhmc] engine: %s (N=%lld, chains %d)\n", pipeline ? "pipeline" : packed ? "packed" : "wave", (long long)N, C);
@@ -624,8 +626,11 @@ int finish_call(RunCall& r) {
     if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
     if (e == hipSuccess && nbuf == 1 && !staged.empty()) e = copy_out_chunk(r, 0, 0, N, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->last_leapfrogs, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-    const bool reorder = P.chain_work && N >= kPolicy.endgame_min_transitions;                    // (a short call's counts say little about the chains, and sorting is not free)
-    if (e == hipSuccess && reorder) e = refresh_order(c, C, N);
+    // chain_work holds the counts of the call's LAST launch: the whole call, or a chunked call's last chunk (run_chunked) — that many
+    // transitions decide (a short launch's counts say little about the chains, and sorting is not free)
+    const int64_t counted = nbuf == 2 && r.L > 0 ? N - ((N + r.L - 1) / r.L - 1) * r.L : N;
+    const bool reorder = P.chain_work && counted >= kPolicy.endgame_min_transitions;
+    if (e == hipSuccess && reorder) e = refresh_order(c, C, counted);
     else if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && N > 0) c->mean_leapfrogs_per_transition = (double)c->last_leapfrogs / ((double)C * (double)N);
     if (e == hipSuccess) {

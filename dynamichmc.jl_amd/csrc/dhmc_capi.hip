@@ -265,6 +265,10 @@ int dhmc_create(const dhmc_config* cfg, dhmc_ctx** out) {
     // Chains of at most 64 coordinates with a diagonal metric: several chains per wavefront (packed_core.hpp) for the families that
     // have a packed evaluator; the same bits as the wave-per-chain kernel, which DHMC_PACKED=0 brings back.
     c->packed = cfg->metric == DHMC_METRIC_DIAG && pk::family_is_packed(cfg->target) && pk::dim_is_packed(D);
+    // the dense-precision normal's gradient is a D x D matvec walked through the lane group: ahead of the wave kernel to 32 coordinates
+    // when the chains fill the GPU's SIMDs several times over (D = 8 … 32, 16384 chains: 3.5 … 1.7 x; D = 64: 0.75 x; 1024 chains: 0.5 x —
+    // profiles/r06_packed_dense_normal.txt); the chain count is checked per call (choose_engine)
+    if (cfg->target == DHMC_TARGET_DENSE_NORMAL) c->packed = c->packed && D <= 32;
     if (const char* e = std::getenv("DHMC_PACKED")) { c->packed = c->packed && std::atoi(e) != 0; c->packed_force = c->packed; }
     // … and as a PIPELINE of four wavefronts per chain (integrator ‖ turn statistics ‖ visited statistic ‖ proposals, nuts_pipeline_kernel.hpp): the lowest
     // latency per leapfrog of a short chain, for launches that wait for a few deep chains

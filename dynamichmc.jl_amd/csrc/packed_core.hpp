@@ -256,6 +256,42 @@ struct PackedTarget<DHMC_TARGET_TRIDIAG_NORMAL> {
     }
 };
 
+// ℓ = -1/2 (q-μ)'P(q-μ), P symmetric and dense, [Dpad][Dpad] zero padded (targets.hpp DenseNormalT): (Pd)_i is ONE fma chain over
+// k = 0 … D-1 ascending of P[k][i]·d_k (oracle/targets.hpp DenseNormal).  A lane owns CPL consecutive coordinates i and walks k through
+// the group's lanes (d_k is register k mod CPL of lane k / CPL: Grp::pick), every chain of the wave reading the same row of P.
+template <>
+struct PackedTarget<DHMC_TARGET_DENSE_NORMAL> {
+    static constexpr bool kFiniteLqImpliesFiniteQ = true;
+    const double* mu;
+    const double* P;
+    int Dpad;
+    PK_FN explicit PackedTarget(const TargetParams& p) : mu(p.a), P(p.b), Dpad(p.Dpad) {}
+    template <int CPL, class Grp, class Pol>
+    PK_FN double eval(const double (&q)[CPL], double (&g)[CPL], int e0, int D) const {
+        double d[CPL], Pd[CPL], t[CPL];
+        PK_UNROLL
+        for (int k = 0; k < CPL; ++k) { d[k] = q[k] - mu[e0 + k]; Pd[k] = 0.0; }
+        for (int j = 0; j * CPL < D; ++j) {
+            PK_UNROLL
+            for (int c = 0; c < CPL; ++c) {
+                const int kk = j * CPL + c;
+                if (kk < D) {                                   // (the same for every chain: the chain of a padded k is never begun)
+                    const double dk = Grp::pick(d[c], j);
+                    const double* row = P + (size_t)kk * Dpad + e0;
+                    PK_UNROLL
+                    for (int i = 0; i < CPL; ++i) Pd[i] = __builtin_fma(row[i], dk, Pd[i]);
+                }
+            }
+        }
+        PK_UNROLL
+        for (int k = 0; k < CPL; ++k) {
+            t[k] = __builtin_fma(d[k], Pd[k], 0.0);
+            g[k] = -Pd[k];
+        }
+        return -0.5 * Grp::sum(Tree<CPL>::sum(t));
+    }
+};
+
 // the reference's AlwaysDivergentTest (test/test_NUTS.jl:58-73; targets.hpp AlwaysDivergentT)
 template <>
 struct PackedTarget<DHMC_TARGET_ALWAYS_DIVERGENT> {
@@ -284,7 +320,7 @@ inline int lanes_per_chain(int D, int cpl) {
 inline bool dim_is_packed(int D) { return D >= 1 && D <= 64; }
 inline bool family_is_packed(int target) {
     return target == DHMC_TARGET_STD_NORMAL || target == DHMC_TARGET_DIAG_NORMAL || target == DHMC_TARGET_TRIDIAG_NORMAL ||
-           target == DHMC_TARGET_FUNNEL || target == DHMC_TARGET_ALWAYS_DIVERGENT;
+           target == DHMC_TARGET_DENSE_NORMAL || target == DHMC_TARGET_FUNNEL || target == DHMC_TARGET_ALWAYS_DIVERGENT;
 }
 // LDS of one wave (bytes): six rows per chain that are touched once per doubling (64·CPL doubles per row set of the wave's 64 / L
 // chains), `levels` suspended levels (1 .. levels: first, last, ρ, proposal), and four scalars per level and chain

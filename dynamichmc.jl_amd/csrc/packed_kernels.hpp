@@ -14,6 +14,7 @@ template <class T> struct PackedId { static constexpr int value = -1; };
 template <> struct PackedId<StdNormalT> { static constexpr int value = DHMC_TARGET_STD_NORMAL; };
 template <> struct PackedId<DiagNormalT> { static constexpr int value = DHMC_TARGET_DIAG_NORMAL; };
 template <> struct PackedId<TridiagNormalT> { static constexpr int value = DHMC_TARGET_TRIDIAG_NORMAL; };
+template <> struct PackedId<DenseNormalT> { static constexpr int value = DHMC_TARGET_DENSE_NORMAL; };
 template <> struct PackedId<FunnelT> { static constexpr int value = DHMC_TARGET_FUNNEL; };
 template <> struct PackedId<AlwaysDivergentT> { static constexpr int value = DHMC_TARGET_ALWAYS_DIVERGENT; };
 

@@ -65,6 +65,7 @@ extern "C" int hostsim_packed_run(int target, const dhmc::RunParams* Pin, int us
         case DHMC_TARGET_STD_NORMAL: run_chain<DHMC_TARGET_STD_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_DIAG_NORMAL: run_chain<DHMC_TARGET_DIAG_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_TRIDIAG_NORMAL: run_chain<DHMC_TARGET_TRIDIAG_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
+        case DHMC_TARGET_DENSE_NORMAL: run_chain<DHMC_TARGET_DENSE_NORMAL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_FUNNEL: run_chain<DHMC_TARGET_FUNNEL>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         case DHMC_TARGET_ALWAYS_DIVERGENT: run_chain<DHMC_TARGET_ALWAYS_DIVERGENT>(P, chain, coldv.data(), rows.data(), sc.data()); break;
         default: return 2;

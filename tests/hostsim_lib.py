@@ -88,7 +88,12 @@ class HostSim:
         self.transition = np.zeros(chains, np.uint32)
         self.status = np.zeros(chains, np.uint32)
         self.params = [None, None]
-        if params is not None:              # diagonal normal: mu, prec (padded rows of 64)
+        if params is not None and np.ndim(params[1]) == 2:      # dense-precision normal: mu, the symmetric P as [64][64], zero padded
+            mu = np.zeros(64); Pm = np.zeros((64, 64))
+            mu[:D] = params[0]
+            Pm[:D, :D] = np.triu(params[1]) + np.triu(params[1], 1).T
+            self.params = [mu, Pm]
+        elif params is not None:            # diagonal normal: mu, prec (padded rows of 64)
             mu = np.zeros(64); prec = np.zeros(64)
             mu[:D], prec[:D] = params[0], params[1]
             self.params = [mu, prec]

@@ -100,6 +100,20 @@ def test_normal_families_match_oracle(pkg, D):
     for e in (dev, ora):
         e.init(); e.set_stepsize(0.3)
     _stages(dev, ora, f"tridiagonal normal D={D}")
+    # the dense-precision normal (round 6): a D x D matvec inside the lane group (the group's lanes pass d_k around: Grp::pick)
+    A = rng.normal(size=(D, D)) * 0.3
+    Pm = A @ A.T + np.diag(rng.uniform(1.0, 2.0, size=D))
+    mu = rng.normal(size=D)
+    blob = ol.target_params_blob(ol.TARGET_DENSE_NORMAL, D, mu=mu, P=Pm)
+    for cpl in (2, 4):
+        if D > 32 and cpl == 2:
+            continue
+        with _env(DHMC_PK="cpl=%d" % cpl, DHMC_PACKED="1"):     # (the library takes the packed kernel for this family from 16 chains per CU on, D <= 32)
+            dev = pkg.DeviceContext(D, C, target=ol.TARGET_DENSE_NORMAL, target_params=blob, seed=8)
+        ora = ol.Oracle(D, C, target=ol.TARGET_DENSE_NORMAL, params=blob, seed=8, threads=8)
+        for e in (dev, ora):
+            e.init(); e.set_stepsize(0.25)
+        _stages(dev, ora, f"dense-precision normal D={D} cpl={cpl}")
 
 
 def test_divergences_depth_limits_and_always_divergent(pkg):

@@ -86,6 +86,14 @@ def test_normal_families_match_oracle(D):
                      blob=ol.target_params_blob(ol.TARGET_TRIDIAG_NORMAL, D, diag=diag, off=off))
     _same(sim.run(25, da=dict()), ora.run(25, da=dict()), "tridiagonal normal, adaptive")
     _same(sim.run(25), ora.run(25), "tridiagonal normal")
+    # dense-precision normal (round 6: the sixth family): a well-conditioned SPD matrix, every (Pd)_i one k-ascending fma chain
+    A = rng.normal(size=(D, D)) * 0.3
+    Pm = A @ A.T + np.diag(rng.uniform(1.0, 2.0, size=D))
+    mu = rng.normal(size=D)
+    ora, sim = _pair(D, C, ol.TARGET_DENSE_NORMAL, seed=8, eps=0.25, params=(mu, Pm),
+                     blob=ol.target_params_blob(ol.TARGET_DENSE_NORMAL, D, mu=mu, P=Pm))
+    _same(sim.run(25, da=dict()), ora.run(25, da=dict()), "dense-precision normal, adaptive")
+    _same(sim.run(25), ora.run(25), "dense-precision normal")
 
 
 def test_always_divergent_matches_oracle():
