@@ -32,7 +32,7 @@ void run(double* out, int n, int wps) {
 }
 int main() {
     double* out; (void)hipMalloc(&out, (size_t)256 * 8 * 256 * 8);
-    for (int wps : {1, 2, 4}) { run<1, 16>(out, 40000, wps); run<4, 16>(out, 10000, wps); }
+    for (int wps : {1, 2, 4}) { run<1, 16>(out, 40000, wps); run<2, 16>(out, 20000, wps); run<4, 16>(out, 10000, wps); run<8, 16>(out, 5000, wps); run<16, 16>(out, 2500, wps); }
     for (int wps : {1, 2, 4, 8}) { run<1, 4>(out, 100000, wps); run<4, 4>(out, 25000, wps); }
     return 0;
 }
