@@ -1,8 +1,10 @@
 // Round 6 experiment, NOT part of the library: config 5's fused eta + link kernel with the ROLES split over the workgroup's waves
-// (profiles/r06_config5_fused_link.txt, "roles").  Bit-equal to the shipped kernel (tests/test_gpu_configs.py / test_gpu_engines.py logistic
-// cases with the kernel wired in: 9 passed) and slower: 1.56-1.63 ms against 1.30 ms — a lone wave per SIMD issues v_mfma_f64_16x16x4_f64
-// at 36 TFLOP/s at most whatever the number of accumulators (tools/experiments/mfma_f64_chain.hip), so the product waves' SIMDs are
-// 47 % busy although nothing but LDS reads and matrix instructions stands in their loop.
+// (profiles/r06_config5_fused_link.txt, "roles"), here with the clock counters that showed where it waits.  Bit-equal to the shipped kernel
+// (tests/test_gpu_configs.py / test_gpu_engines.py logistic cases with the kernel wired in: 9 passed) and slower: 1.56-1.63 ms against
+// 1.30 ms.  Per workgroup of 620 000 clocks (32 groups x 4 stages): the product waves stand at barriers for 45 % of them, the
+// staging + link waves for 6 %: the link of a group's 512 elements per wave costs ~11 000 clocks on ONE wave per SIMD (phase 3 alone 6 400:
+// two divisions per element) plus 3 500 waiting for X^T, against 8 200 for the group's 128 matrix instructions — one link wave per SIMD
+// cannot keep up with one product wave, and the product waves' 235 registers leave no room for a second one.
 // To try it: paste both pieces into csrc/logistic_rounds.hpp (the phases after logistic_link_batch, the kernel after
 // logistic_eta_link_kernel) and launch logistic_eta_link_roles_kernel<Dpad> with 512 threads on the same grid.
 #pragma once
@@ -74,12 +76,14 @@ struct LogisticLinkPhases {
 };
 
 
+
 // The same work with the ROLES split over the workgroup's waves (round 6, second form): waves 0-3 only multiply — a wave per SIMD, the
 // chain rows of Q′ in its registers, nothing but LDS reads and matrix instructions in its loop; waves 4-7 — the other wave of each
 // SIMD — bring Xᵀ's columns into the double-buffered LDS tile and run the link of the PREVIOUS group's 64 × 32 elements, which the product
 // waves leave in LDS (Es, double-buffered): the link's vector instructions issue under the other wave's matrix instructions instead of
 // between a wave's own.  One barrier per LDS stage for all eight waves; the elements, their order and every operation are the one-role
 // kernel's.  One workgroup per CU (the product waves' 128 fragment registers leave room for two waves per SIMD).
+static __device__ int lk_dbg_count = 0;
 template <int I, int N, class F>
 __device__ __forceinline__ void lk_static_for(F&& f) {
     if constexpr (I < N) {
@@ -108,6 +112,8 @@ __global__ __launch_bounds__(512, 1) void logistic_eta_link_roles_kernel(RunPara
     __shared__ double Bs[2][LK_TK * LK_LS];
     __shared__ double Es[2][4 * 8 * WAVE];                                         // [group parity][wave][j][r][lane]: the accumulators as they are
 
+    unsigned long long t_wait = 0, t_all = __builtin_readcyclecounter();
+#define LK_BARRIER() do { const unsigned long long tb_ = __builtin_readcyclecounter(); __syncthreads(); t_wait += __builtin_readcyclecounter() - tb_; } while (0)
     if (wv < 4) {
         // ---- product waves -------------------------------------------------------------------------------------------------------
         int arow = row0 + 16 * w4 + (lane & 15);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(512, 1) void logistic_eta_link_roles_kernel(RunPara
             acc[1] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                __syncthreads();                                                   // stage (m, st) is in Bs[buf]
+                LK_BARRIER();                                                   // stage (m, st) is in Bs[buf]
                 const double* bs = Bs[buf];
                 // the stage's B-fragments in batches of 8 k-steps, the next batch's LDS reads in flight under this one's products (a lone
                 // wave per SIMD: nothing else covers the read latency)
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(512, 1) void logistic_eta_link_roles_kernel(RunPara
 #pragma unroll
                 for (int r = 0; r < 4; ++r) es[(4 * j + r) * WAVE] = acc[j][r];
         }
-        __syncthreads();                                                           // the last group's η is in Es
+        LK_BARRIER();                                                           // the last group's η is in Es
+        if (blockIdx.x == 1000 && t == 0 && atomicAdd(&lk_dbg_count, 1) < 4) printf("[roles] product wave: %llu clocks, %llu at barriers, %d groups x %d stages\n", __builtin_readcyclecounter() - t_all, t_wait, nm, NST);
         return;
     }
     // ---- staging + link waves ------------------------------------------------------------------------------------------------------
@@ -187,13 +194,13 @@ __global__ __launch_bounds__(512, 1) void logistic_eta_link_roles_kernel(RunPara
         srow[r] = g - P.chain_base;
     }
     // the link of a group's 8 elements per lane runs one group behind the products, a phase per LDS stage (LogisticLinkPhases)
-    LogisticLinkPhases<4> K0, K1;                                                  // Kj: the lane's elements (j, r = 0 .. 3)
+    LogisticLinkPhases<8> K8;                                                      // the lane's elements 4 j + r
     double yv[2];
     int mt = 0;                                                                    // the group the held η belong to
     auto take = [&](int m1) __attribute__((always_inline)) {                       // group m1's η (and y) into registers
         const double* es = Es[m1 & 1] + (size_t)w4 * 8 * WAVE + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { K0.eta[r] = es[r * WAVE]; K1.eta[r] = es[(4 + r) * WAVE]; }
+        for (int e = 0; e < 8; ++e) K8.eta[e] = es[e * WAVE];
         const int64_t n_lo = nb + (int64_t)WAVE * m1 + l0 + (lane & 15);
         yv[0] = n_lo < N ? P.tp.c[n_lo] : 0.0;
         yv[1] = n_lo + 16 < N ? P.tp.c[n_lo + 16] : 0.0;
@@ -201,50 +208,49 @@ __global__ __launch_bounds__(512, 1) void logistic_eta_link_roles_kernel(RunPara
     };
     auto finish = [&](auto jc) __attribute__((always_inline)) {                    // r stored, the terms added (elements (j, r) of group mt)
         constexpr int j = decltype(jc)::value;
-        LogisticLinkPhases<4>& Kj = j == 0 ? K0 : K1;
         const int64_t n_lo = nb + (int64_t)WAVE * mt + l0 + (lane & 15);
         const double y = yv[j];
         const bool valid = n_lo + 16 * j < N;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            hrow[r][WAVE * mt + 16 * j] = valid ? y - Kj.sig[r] : 0.0;
-            if (valid) lp[j][r] = lp[j][r] + (y * Kj.eta[r] - Kj.l1pe[r]);
+            hrow[r][WAVE * mt + 16 * j] = valid ? y - K8.sig[4 * j + r] : 0.0;
+            if (valid) lp[j][r] = lp[j][r] + (y * K8.eta[4 * j + r] - K8.l1pe[4 * j + r]);
         }
     };
     auto phase = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        lk_static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            LogisticLinkPhases<4>& Kj = j == 0 ? K0 : K1;
-            if constexpr (k == 0) { Kj.phase1(); }
-            else if constexpr (k == 1) { Kj.phase2(); }
-            else { Kj.phase3(); finish(jc); }
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        if constexpr (k == 0) { K8.phase1(); }
+        else if constexpr (k == 1) { K8.phase2(); }
+        else { K8.phase3(); finish(std::integral_constant<int, 0>{}); finish(std::integral_constant<int, 1>{}); }
     };
+    unsigned long long t_ph[3] = {0, 0, 0}, t_stw = 0;
     lk_static_for<0, PF>([&](auto stc) __attribute__((always_inline)) { bload(0, stc); });
     int buf = 0;
 #pragma nounroll
     for (int m = 0; m < nm; ++m) {
         lk_static_for<0, NST>([&](auto stc) __attribute__((always_inline)) {
             constexpr int st = decltype(stc)::value;
+            const unsigned long long tw_ = __builtin_readcyclecounter();
             gemm_d2* bw = reinterpret_cast<gemm_d2*>(Bs[buf] + b_k * LK_LS + b_c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[st % PF][2 * i], bv[st % PF][2 * i + 1]};
-            __syncthreads();                                                       // stage (m, st) handed over; group m-1's η is in Es
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t_stw += __builtin_readcyclecounter() - tw_;
+            LK_BARRIER();                                                       // stage (m, st) handed over; group m-1's η is in Es
             if constexpr (st + PF < NST) bload(m, std::integral_constant<int, (st + PF) % NST>{});          // PF stages on, same ring slot
             else if (m + 1 < nm) bload(m + 1, std::integral_constant<int, (st + PF) % NST>{});
             if (m > 0) {                                                           // phase k of group m-1 in stage min(k, NST-1)
                 if (st == 0) take(m - 1);
                 lk_static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = decltype(kc)::value;
-                    if constexpr ((k < NST - 1 ? k : NST - 1) == st) phase(kc);
+                    if constexpr ((k < NST - 1 ? k : NST - 1) == st) { const unsigned long long tp_ = __builtin_readcyclecounter(); phase(kc); t_ph[k] += __builtin_readcyclecounter() - tp_; }
                 });
             }
             buf ^= 1;
         });
     }
-    __syncthreads();
+    LK_BARRIER();
+    if (blockIdx.x == 1000 && t == 256 && lk_dbg_count < 8) printf("[roles] staging+link wave: %llu clocks, %llu at barriers, phases %llu %llu %llu, waiting for X^T + LDS write %llu\n", __builtin_readcyclecounter() - t_all, t_wait, t_ph[0], t_ph[1], t_ph[2], t_stw);
     take(nm - 1);
     lk_static_for<0, 3>([&](auto kc) __attribute__((always_inline)) { phase(kc); });
 #pragma unroll
