@@ -467,10 +467,15 @@ __global__ __launch_bounds__(512, 1) void gemm_skinny_pc_f64_kernel(const double
 }
 
 // host launchers.  Square metric products: OUT rows <- A rows · B with K = N = ld = Dpad.
+// k per LDS stage of the 64×64-tile kernel (K must be a multiple; Dpad is one of 64): DHMC_GEMM_TK at build time for experiments
+#ifndef DHMC_GEMM_TK
+#define DHMC_GEMM_TK 16
+#endif
+constexpr int GEMM_ROWS_TK = DHMC_GEMM_TK;
 inline void launch_gemm_rows(const double* A, const double* B, double* OUT, int ld, int nrows, const int* row_list,
                              const int* row_count, hipStream_t s) {
     dim3 grid(ld / 64, (nrows + 63) / 64);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, GEMM_ROWS_TK, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, ld, B, ld, OUT, ld, ld, nrows, row_list, row_count);
 }
 // Split-K product over gathered rows: P[z][r][0..N) = Σ_{k in block z} A[r][k] · B[k][0..N) for the rows r of row_list
 // (all rows 0..M-1 when row_list is null), z = 0 .. ceil(K / kblk) - 1; P is [nz][zstride] with rows of ldo doubles.
@@ -478,14 +483,14 @@ inline void launch_gemm_splitk(const double* A, int lda, const double* B, int ld
                                int K, int N, int kblk, const int* row_list, const int* row_count, hipStream_t s) {
     const int nz = (K + kblk - 1) / kblk;
     dim3 grid(N / 64, (M + 63) / 64, nz);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, P, ldo, K, M, row_list,
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, GEMM_ROWS_TK, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, P, ldo, K, M, row_list,
                        row_count, kblk, zstride);
 }
 // OUT[r][0..N) = A[r][0..K) · B for the rows r of row_list (64×64 tiles)
 inline void launch_gemm_list(const double* A, int lda, const double* B, int ldb, double* OUT, int ldo, int M, int K, int N,
                              const int* row_list, const int* row_count, hipStream_t s) {
     dim3 grid(N / 64, (M + 63) / 64);
-    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, row_list,
+    hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, GEMM_ROWS_TK, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, row_list,
                        row_count, 0, (size_t)0);
 }
 // General product OUT[M][N] = A[M][K] · B[K][N] (N a multiple of 32, K of 16).  64×64 tiles (4 waves × 32×32)
@@ -496,7 +501,7 @@ inline void launch_gemm(const double* A, int lda, const double* B, int ldb, doub
     const long tiles64 = (long)((M + 63) / 64) * (N / 64);
     if (N % 64 == 0 && tiles64 >= 512) {
         dim3 grid(N / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, GEMM_ROWS_TK, DHMC_GEMM_BLK>), grid, dim3(256), 0, s, A, lda, B, ldb, OUT, ldo, K, M, nullptr, nullptr);
     } else if (K % SK_TK == 0 && K >= 64 * SK_TK) {   // (SK_TK is a multiple of PC_TK)
         const int ncol = N / 32, nrb = (M + 31) / 32;
 #ifdef DHMC_SK_SINGLE_ROLE

@@ -50,14 +50,25 @@ static void v2(const char* name, int M, int K, int N, int kblk, const double* A,
     printf("  %-22s grid %5d x %3d x %2d  lds %6zu: %7.3f ms  %5.1f TFLOP/s  mismatches %ld  (%s)\n", name, grid.x, grid.y, grid.z, lds, ms,
            2.0 * M * K * N / ms / 1e9, check(hA, hB, O, M, K, N, kblk), hipGetErrorString(e));
 }
-static void base(int M, int K, int N, int kblk, const double* A, const double* B, double* O, const std::vector<double>& hA, const std::vector<double>& hB) {
+template <int WT, int FR, int TK>
+static void base_t(const char* name, int M, int K, int N, int kblk, const double* A, const double* B, double* O, const std::vector<double>& hA, const std::vector<double>& hB) {
     const int nz = kblk ? (K + kblk - 1) / kblk : 1;
-    dim3 grid(N / 64, (M + 63) / 64, nz);
+    constexpr int T = 16 * FR * WT;
+    if (N % T) { printf("  %-22s n/a\n", name); return; }
+    dim3 grid(N / T, (M + T - 1) / T, nz);
     const float ms = time_it([&] {
-        hipLaunchKernelGGL((gemm_rows_f64_kernel<2, 2, 16, false>), grid, dim3(256), 0, 0, A, K, B, N, O, N, K, M, nullptr, nullptr, kblk, (size_t)M * N);
+        hipLaunchKernelGGL((gemm_rows_f64_kernel<WT, FR, TK, false>), grid, dim3(64 * WT * WT), 0, 0, A, K, B, N, O, N, K, M, nullptr, nullptr, kblk, (size_t)M * N);
     });
-    printf("  %-22s grid %5d x %3d x %2d            : %7.3f ms  %5.1f TFLOP/s  mismatches %ld\n", "library <2,2,16>", grid.x, grid.y, grid.z, ms,
+    printf("  %-22s grid %5d x %3d x %2d            : %7.3f ms  %5.1f TFLOP/s  mismatches %ld\n", name, grid.x, grid.y, grid.z, ms,
            2.0 * M * K * N / ms / 1e9, check(hA, hB, O, M, K, N, kblk));
+}
+static void base(int M, int K, int N, int kblk, const double* A, const double* B, double* O, const std::vector<double>& hA, const std::vector<double>& hB) {
+    base_t<2, 2, 16>("library <2,2,16>", M, K, N, kblk, A, B, O, hA, hB);
+    if (getenv("GEMM_BENCH_LIBRARY_TK")) {
+        base_t<2, 2, 32>("library <2,2,32>", M, K, N, kblk, A, B, O, hA, hB);
+        base_t<2, 2, 64>("library <2,2,64>", M, K, N, kblk, A, B, O, hA, hB);
+        base_t<2, 2, 8>("library <2,2,8>", M, K, N, kblk, A, B, O, hA, hB);
+    }
 }
 int main() {
     struct Shape { int M, K, N, kblk; } shapes[] = {{4096, 1024, 1024, 0}, {2048, 1024, 1024, 0}, {1024, 1024, 1024, 0}, {300, 1024, 1024, 0},
