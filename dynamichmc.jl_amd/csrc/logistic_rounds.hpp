@@ -121,10 +121,17 @@ __device__ __forceinline__ void logistic_link_batch(const double (&eta)[NE], dou
         const double* __restrict__ lp = DM_LOG_TBL[jl[i]];
         row[i][0] = lp[0]; row[i][1] = lp[1]; row[i][2] = lp[2];
     }
+    // the general value for EVERY argument, then det_log1p_nonneg_t's early returns as selects: written as branches (the compiler's choice when
+    // the value is only needed on one side) each argument's logarithm and division would be a chain of its own under its own exec mask,
+    // one after the other; this way the NE chains interleave
+    double lg[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) lg[i] = dm_log_finish<dm_v>(m[i], el[i], row[i][0], row[i][1], row[i][2]) + (t[i] - (w[i] - 1.0)) / w[i];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) asm volatile("" : "+v"(lg[i]));
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const double lg = dm_log_finish<dm_v>(m[i], el[i], row[i][0], row[i][1], row[i][2]) + (t[i] - (w[i] - 1.0)) / w[i];
-        const double l1p = (w[i] == 1.0) ? t[i] : (!dm_isfinite(w[i]) ? w[i] : lg);  // det_log1p_nonneg_t's early returns
+        const double l1p = (w[i] == 1.0) ? t[i] : (!dm_isfinite(w[i]) ? w[i] : lg[i]);
         sig[i] = (eta[i] >= 0 ? 1.0 : t[i]) / w[i];
         l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + l1p;
     }
@@ -178,6 +185,10 @@ static __global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, R
 // Workgroup id -> (z, lh, row tile) keeps the row tiles of one (z, lh) on one XCD back to back: its 2 MB of Xᵀ come from that L2.
 // ------------------------------------------------------------------------------------------------------------------------------
 
+#ifndef DHMC_LK_NE
+#define DHMC_LK_NE 2
+#endif
+constexpr int LK_NE = DHMC_LK_NE;                              // arguments of the link in flight together (of a lane's 4 per accumulator)
 constexpr int LK_TL = 32, LK_TK = 64, LK_LS = LK_TL + 16;     // columns per workgroup, k per LDS stage, LDS row stride (doubles)
 
 template <int DP>                                              // DP = Dpad (64, 128 or 256): the A-fragments are DP / 4 registers
@@ -268,17 +279,20 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
         // the wave's registers)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            double eta[4], sig[4], l1pe[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) eta[r] = acc[j][r];
-            logistic_link_batch<4>(eta, sig, l1pe);
             const int64_t n = n_lo + 16 * j;
             const double y = j == 0 ? y0 : y1;
             const bool valid = n < N;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hrow[r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
-                if (valid) lp[j][r] = lp[j][r] + (y * eta[r] - l1pe[r]);
+            for (int h = 0; h < 4 / LK_NE; ++h) {
+                double eta[LK_NE], sig[LK_NE], l1pe[LK_NE];
+#pragma unroll
+                for (int r = 0; r < LK_NE; ++r) eta[r] = acc[j][LK_NE * h + r];
+                logistic_link_batch<LK_NE>(eta, sig, l1pe);
+#pragma unroll
+                for (int r = 0; r < LK_NE; ++r) {
+                    hrow[LK_NE * h + r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
+                    if (valid) lp[j][LK_NE * h + r] = lp[j][LK_NE * h + r] + (y * eta[r] - l1pe[r]);
+                }
             }
         }
     }
