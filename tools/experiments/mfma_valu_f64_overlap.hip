@@ -4,10 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512) void mix(double* out, int n_mfma, int n_valu, int mode) {   // mode 1: matrix only, 2: vector only, 3: both
+__global__ __launch_bounds__(512) void mix(double* out, int n_mfma, int n_valu, int mode) {   // mode 1: matrix only, 2: vector only, 3: both, 4: all eight waves vector
     const int wv = threadIdx.x >> 6;
     double s = 0;
-    if (wv < 4) {
+    if (wv < 4 && mode != 4) {
         if (!(mode & 1)) return;
         d4 acc[4];
         for (int j = 0; j < 4; ++j) acc[j] = d4{0, 0, 0, 0};
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512) void mix(double* out, int n_mfma, int n_valu, 
             for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
         for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
     } else {
-        if (!(mode & 2)) return;
+        if (!(mode & 2) && mode != 4) return;
         double x[8];
         for (int j = 0; j < 8; ++j) x[j] = 1.0 + j + threadIdx.x * 1e-9;
         const double c = 0.999999, d = 1e-9;
@@ -44,5 +44,7 @@ int main() {
     printf("matrix waves alone  %.2f ms  (%.1f TFLOP/s)\n", m, 4.0 * nm * 2048 * 1024 / (m * 1e-3) / 1e12);
     printf("vector waves alone  %.2f ms  (%.1f TFLOP/s)\n", v, 8.0 * nv * 128 * 1024 / (v * 1e-3) / 1e12);
     printf("both together       %.2f ms  (sum of the two alone: %.2f ms, the longer one: %.2f ms)\n", b, m + v, m > v ? m : v);
+    const float v2 = run(out, nm, nv, 4);
+    printf("vector waves, two per SIMD  %.2f ms  (%.1f TFLOP/s; one per SIMD: %.1f)\n", v2, 2 * 8.0 * nv * 128 * 1024 / (v2 * 1e-3) / 1e12, 8.0 * nv * 128 * 1024 / (v * 1e-3) / 1e12);
     return 0;
 }
