@@ -583,6 +583,9 @@ def main():
                                  "turn checks; an unfused multiply or add counts 1, the peak counts an fma as 2) x leapfrogs per "
                                  "launch / kernel time (HIP events on the launch stream) against the fp64 vector peak; "
                                  "traffic = real HBM bytes per launch from the PMC passes",
+                         # measured on this part (profiles/r06_mfma_vgpr_form.txt §7): what ONE wave per SIMD — this kernel's layout — can issue
+                         "one_wave_per_simd_ceiling": {"value": 33.3, "unit": "TFLOP/s", "frac_of_it": valu_ach / 33.3,
+                                                       "note": "a lone wave with eight independent v_fma_f64 chains: one fma per ~9.4 clocks"},
                          # the streaming model SURVEY.md §8(d) starts from: the chain state never leaves the CU, so this exceeds 1
                          "hbm_model": {"algorithmic_bytes_per_leapfrog": ALGO_BYTES_PER_LEAPFROG, "achieved": achieved,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}},
