@@ -45,7 +45,7 @@ int main() {
     (void)hipMalloc(&g_clk, 16);
     for (int wps : {1, 2, 4}) { run<1, 16>(out, 40000, wps); run<2, 16>(out, 20000, wps); run<4, 16>(out, 10000, wps); run<8, 16>(out, 5000, wps); run<16, 16>(out, 2500, wps); }
     for (int wps : {1, 4}) run<4, 16>(out, 400000, wps);      // 40 x longer: the clock under a sustained load
-    for (int wps : {1, 2, 4}) { run<4, 20>(out, 10000, wps); run<8, 20>(out, 5000, wps); run<16, 20>(out, 2500, wps); }
+    for (int wps : {1, 2, 4}) { run<1, 20>(out, 40000, wps); run<2, 20>(out, 20000, wps); run<4, 20>(out, 10000, wps); run<8, 20>(out, 5000, wps); run<16, 20>(out, 2500, wps); }
     for (int wps : {1, 2, 4}) { run<4, 18>(out, 10000, wps); run<8, 18>(out, 5000, wps); run<16, 18>(out, 2500, wps); run<4, 19>(out, 10000, wps); run<8, 19>(out, 5000, wps); }
     for (int wps : {1, 2, 4, 8}) { run<1, 4>(out, 100000, wps); run<4, 4>(out, 25000, wps); }
     return 0;
