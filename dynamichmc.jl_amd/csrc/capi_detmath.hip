@@ -27,6 +27,8 @@ __device__ __forceinline__ double detmath_eval(int kind, double x, double y) {
     case 7: det_randn2_t<P>(r1, r2, &s, &c); return c;
     case 8: return det_logaddexp_t<P>(x, y);
     case 9: return det_pow_pos_t<P>(x, y);
+    case 10: return det_logistic_sigma_t<P>(x);
+    case 11: return det_log1pexp_t<P>(x);
     default: return dm_nan();
     }
 }
@@ -36,6 +38,19 @@ __global__ __launch_bounds__(64) void detmath_lane_kernel(int kind, int64_t n, c
                                                          const double* __restrict__ y, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i < n) out[i] = detmath_eval<P>(kind, x[i], y ? y[i] : 0.0);
+}
+
+// kinds 10 / 11 with policy 1: the logistic round engine's own evaluation — logistic_link_batch (detmath_dev.hpp), two arguments
+// of a lane at once (lane i: x[2i] and x[2i + 1]; the second stands in for the first when n is odd), common path and whole-wave
+// rare path as the data decide
+__global__ __launch_bounds__(64) void detmath_link_batch_kernel(int kind, int64_t n, const double* __restrict__ x, double* __restrict__ out) {
+    const int64_t i0 = 2 * ((int64_t)blockIdx.x * 64 + threadIdx.x), i1 = i0 + 1;
+    double eta[2], sig[2], l1pe[2];
+    eta[0] = i0 < n ? x[i0] : 0.0;
+    eta[1] = i1 < n ? x[i1] : eta[0];
+    logistic_link_batch<2>(eta, sig, l1pe);
+    if (i0 < n) out[i0] = kind == 10 ? sig[0] : l1pe[0];
+    if (i1 < n) out[i1] = kind == 10 ? sig[1] : l1pe[1];
 }
 
 // one value per wavefront: every lane holds the same argument, as the tree logic's scalars do
@@ -57,8 +72,9 @@ struct Buf {
 
 extern "C" int dhmc_detmath_selftest(int32_t device, int32_t kind, int32_t policy, int64_t n, const double* x, const double* y, double* out) {
     using namespace dhmc;
-    if (!x || !out || n < 1 || n > (1ll << 24) || kind < 0 || kind > 9 || policy < 0 || policy > 2) return DHMC_ERR_INVALID_ARGUMENT;
-    if ((kind >= 6 && kind != 9 && !y) || (kind == 9 && !y)) return DHMC_ERR_INVALID_ARGUMENT;
+    if (!x || !out || n < 1 || n > (1ll << 24) || kind < 0 || kind > 11 || policy < 0 || policy > 2) return DHMC_ERR_INVALID_ARGUMENT;
+    if (kind >= 10 && policy == 2) return DHMC_ERR_INVALID_ARGUMENT;        // the link's arguments are never wave-uniform
+    if (kind >= 6 && kind <= 9 && !y) return DHMC_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(device) != hipSuccess) return DHMC_ERR_NO_DEVICE;
     Buf dx, dy, dout;
     const size_t bytes = sizeof(double) * (size_t)n;
@@ -70,6 +86,7 @@ extern "C" int dhmc_detmath_selftest(int32_t device, int32_t kind, int32_t polic
     double* po = (double*)dout.p;
     const unsigned blocks = (unsigned)((n + 63) / 64);
     if (policy == 0) hipLaunchKernelGGL(detmath_lane_kernel<dm_generic>, dim3(blocks), dim3(64), 0, 0, kind, n, px, py, po);
+    else if (policy == 1 && kind >= 10) hipLaunchKernelGGL(detmath_link_batch_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, 0, kind, n, px, po);
     else if (policy == 1) hipLaunchKernelGGL(detmath_lane_kernel<dm_vector>, dim3(blocks), dim3(64), 0, 0, kind, n, px, py, po);
     else hipLaunchKernelGGL(detmath_uniform_kernel, dim3((unsigned)n), dim3(64), 0, 0, kind, n, px, py, po);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return DHMC_ERR_HIP;

@@ -120,4 +120,95 @@ __device__ __forceinline__ double det_log_v(double x) { return det_log_t<dm_v>(x
 __device__ __forceinline__ double det_randexp_v(uint64_t r) { return det_randexp_t<dm_rexp>(r); }
 __device__ __forceinline__ void det_randn2_v(uint64_t r1, uint64_t r2, double* z0, double* z1) { det_randn2_t<dm_v>(r1, r2, z0, z1); }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The Bernoulli-logit link of NE observations at once (the logistic round engine, logistic_rounds.hpp): sig = det_logistic_sigma(η),
+// l1pe = det_log1pexp(η) (include/dhmc_detmath.h), value by value the operations of det_exp_t<dm_v>(-|η|), det_log1p_nonneg_t<dm_v>(t)
+// and the two divisions by w = 1 + t — but
+//   * in PHASES over the NE arguments: all reductions, then all table gathers in flight together (one round trip per table instead
+//     of one per argument), then the polynomials;
+//   * with the functions' special cases taken out of the common path by ONE ballot: an argument with |η| > 707 or NaN anywhere in the
+//     wave (e^{-|η|} subnormal or zero) sends the whole wave through the functions themselves; for every other argument t is a normal
+//     number in [2^-1020, 1], w = 1 + t is in [1, 2] and none of det_exp_t's / det_log1p_nonneg_t's selects can fire except w == 1;
+//   * with both quotients n / w of an argument — (η >= 0 ? 1 : t) / w and (t - (w - 1)) / w — taken from ONE refined reciprocal of w:
+//     a correctly rounded fp64 division on this hardware IS  r₀ = v_rcp_f64(w), two Newton steps r ← fma(r, fma(-w, r, 1), r),
+//     q₀ = n·r, q = fma(fma(-w, q₀, n), r, q₀)  wrapped in v_div_scale / v_div_fmas / v_div_fixup, which pre-scale operands whose exponents
+//     are extreme and patch Inf / NaN / 0 — and are the identity for w in [1, 2] and a numerator that is 0 or of magnitude >= 2^-969.
+//     Smaller numerators exist only for t < 2^-53, where w == 1 exactly, r == 1 exactly and q = n exactly.  So the explicit sequence
+//     returns the bits of the IEEE quotient (the oracle's `/`), the reciprocal's five instructions are spent once, and the compiler
+//     can interleave the chains of the NE arguments (v_div_fmas reads VCC: its expansions run one after the other).
+//     Checked value by value against the CPU side: dhmc_detmath_selftest kinds 10 / 11 (tests/test_gpu_detmath.py).
+// ------------------------------------------------------------------------------------------------------------------------------
+struct dm_shared_recip {
+    double w, r;
+    __device__ __forceinline__ explicit dm_shared_recip(double w_) : w(w_) {
+        const double r0 = __builtin_amdgcn_rcp(w_);
+        const double r1 = __builtin_fma(r0, __builtin_fma(-w_, r0, 1.0), r0);
+        r = __builtin_fma(r1, __builtin_fma(-w_, r1, 1.0), r1);
+    }
+    __device__ __forceinline__ double quotient(double n) const {        // n / w, correctly rounded (see above for the operand ranges)
+        const double q0 = n * r;
+        return __builtin_fma(__builtin_fma(-w, q0, n), r, q0);
+    }
+};
+
+template <int NE>
+__device__ __forceinline__ void logistic_link_batch(const double (&eta)[NE], double (&sig)[NE], double (&l1pe)[NE]) {
+    double x[NE], r[NE], t[NE];
+    int j[NE], e[NE];
+    bool rare = false;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        x[i] = -__builtin_fabs(eta[i]);
+        dm_exp_reduce(x[i], &j[i], &e[i], &r[i]);
+        rare = rare || !(x[i] >= -707.0);                  // NaN, or e^x below 2^-1020 (x >= -707 has e >= -1020: no subnormal path)
+    }
+    if (__builtin_expect(__ballot(rare) != 0ull, 0)) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            sig[i] = det_logistic_sigma_t<dm_v>(eta[i]);
+            l1pe[i] = det_log1pexp_t<dm_v>(eta[i]);
+        }
+        return;
+    }
+    double T[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) T[i] = DM_EXP2_TBL[j[i]];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const uint64_t yb = dm_bits(dm_exp_poly<dm_v>(r[i], T[i]));
+        // 2^e by an exponent-field add (det_exp_t's e >= -1021 branch): (e << 52) has a zero low word, so only the high word moves
+        const uint32_t hi = (uint32_t)(yb >> 32) + ((uint32_t)e[i] << 20);
+        t[i] = dm_from_bits(((uint64_t)hi << 32) | (uint32_t)yb);
+    }
+    double w[NE], m[NE], row[NE][3];
+    int jl[NE], el[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        w[i] = 1.0 + t[i];
+        dm_log_reduce(dm_bits(w[i]), 0, &jl[i], &el[i], &m[i]);                       // w in [1, 2]
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const double* __restrict__ lp = DM_LOG_TBL[jl[i]];
+        row[i][0] = lp[0]; row[i][1] = lp[1]; row[i][2] = lp[2];
+    }
+    // the general values for EVERY argument first (opaque to the compiler below: written as one expression per argument it would put each
+    // argument's logarithm and quotients under that argument's own exec mask, one chain after the other), then the selects
+    double lg[NE], sg[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const dm_shared_recip rw(w[i]);
+        lg[i] = dm_log_finish<dm_v>(m[i], el[i], row[i][0], row[i][1], row[i][2]) + rw.quotient(t[i] - (w[i] - 1.0));
+        sg[i] = rw.quotient(eta[i] >= 0 ? 1.0 : t[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) asm volatile("" : "+v"(lg[i]));
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const double l1p = (w[i] == 1.0) ? t[i] : lg[i];       // det_log1p_nonneg_t's early return (w is finite here)
+        sig[i] = sg[i];
+        l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + l1p;
+    }
+}
+
 }  // namespace dhmc

@@ -75,67 +75,7 @@ __global__ __launch_bounds__(64) void rounds_k1_diag_kernel(RunParams P, RoundBu
     }
 }
 
-// The link of NE observations at once: t = e^{-|η|}, σ(η) = (η >= 0 ? 1 : t) / (1 + t), log(1 + e^η) = max(η, 0) + log1p(t) — the operations of
-// det_exp_t<dm_v>(-|η|) and det_log1p_nonneg_t<dm_v>(t) (include/dhmc_detmath.h), value by value, but in PHASES over the NE arguments:
-// all reductions, then all table gathers in flight together (one round trip per table instead of one per argument), then the
-// polynomials.  The functions' rare branches (a subnormal e^{-|η|}: |η| > 708.4) send the whole wave through the functions themselves.
-template <int NE>
-__device__ __forceinline__ void logistic_link_batch(const double (&eta)[NE], double (&sig)[NE], double (&l1pe)[NE]) {
-    double x[NE], r[NE], t[NE];
-    int j[NE], e[NE];
-    bool rare = false;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        x[i] = -__builtin_fabs(eta[i]);
-        dm_exp_reduce(x[i], &j[i], &e[i], &r[i]);
-        rare = rare || (e[i] < -1021 && x[i] >= -745.2);
-    }
-    if (__builtin_expect(__ballot(rare) != 0ull, 0)) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const double tt = det_exp_v(x[i]);
-            sig[i] = eta[i] >= 0 ? 1.0 / (1.0 + tt) : tt / (1.0 + tt);
-            l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + det_log1p_nonneg_t<dm_v>(tt);
-        }
-        return;
-    }
-    double T[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) T[i] = DM_EXP2_TBL[j[i]];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const double y = dm_exp_poly<dm_v>(r[i], T[i]);
-        double v = dm_from_bits(dm_bits(y) + ((uint64_t)(int64_t)e[i] << 52));      // (e >= -1021 here)
-        v = x[i] < -745.2 ? 0.0 : v;
-        t[i] = dm_isnan(x[i]) ? x[i] : v;
-    }
-    double w[NE], m[NE], row[NE][3];
-    int jl[NE], el[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        w[i] = 1.0 + t[i];
-        dm_log_reduce(dm_bits(w[i]), 0, &jl[i], &el[i], &m[i]);                       // w in [1, 2] (or NaN: any cell, not used)
-    }
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const double* __restrict__ lp = DM_LOG_TBL[jl[i]];
-        row[i][0] = lp[0]; row[i][1] = lp[1]; row[i][2] = lp[2];
-    }
-    // the general value for EVERY argument, then det_log1p_nonneg_t's early returns as selects: written as branches (the compiler's choice when
-    // the value is only needed on one side) each argument's logarithm and division would be a chain of its own under its own exec mask,
-    // one after the other; this way the NE chains interleave
-    double lg[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) lg[i] = dm_log_finish<dm_v>(m[i], el[i], row[i][0], row[i][1], row[i][2]) + (t[i] - (w[i] - 1.0)) / w[i];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) asm volatile("" : "+v"(lg[i]));
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const double l1p = (w[i] == 1.0) ? t[i] : (!dm_isfinite(w[i]) ? w[i] : lg[i]);
-        sig[i] = (eta[i] >= 0 ? 1.0 : t[i]) / w[i];
-        l1pe[i] = (eta[i] > 0 ? eta[i] : 0.0) + l1p;
-    }
-}
+// (the link of NE observations at once — logistic_link_batch — lives with the scalar math's device policies: detmath_dev.hpp)
 
 // K_r: link, residual and the block's share of the log-likelihood — one wave per (block of observations, listed chain).
 // H <- r (0 for the padding observations); S1P[z][chain] <- the block's Σ [y η − log(1+e^η)] in wave order (lane l adds
@@ -277,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
         }
         // the link of the lane's 8 elements (logistic_link_kernel's operations, in phases; four at a time: the A-fragments hold half
         // the wave's registers)
+        const bool whole = nb + (int64_t)WAVE * (m + 1) <= N;                     // no padding observation in this group (uniform)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int64_t n = n_lo + 16 * j;
@@ -288,10 +229,18 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
                 for (int r = 0; r < LK_NE; ++r) eta[r] = acc[j][LK_NE * h + r];
                 logistic_link_batch<LK_NE>(eta, sig, l1pe);
+                if (whole) {                                                       // every group but the data's last: no per-lane tests
 #pragma unroll
-                for (int r = 0; r < LK_NE; ++r) {
-                    hrow[LK_NE * h + r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
-                    if (valid) lp[j][LK_NE * h + r] = lp[j][LK_NE * h + r] + (y * eta[r] - l1pe[r]);
+                    for (int r = 0; r < LK_NE; ++r) {
+                        hrow[LK_NE * h + r][WAVE * m + 16 * j] = y - sig[r];
+                        lp[j][LK_NE * h + r] = lp[j][LK_NE * h + r] + (y * eta[r] - l1pe[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < LK_NE; ++r) {
+                        hrow[LK_NE * h + r][WAVE * m + 16 * j] = valid ? y - sig[r] : 0.0;
+                        if (valid) lp[j][LK_NE * h + r] = lp[j][LK_NE * h + r] + (y * eta[r] - l1pe[r]);
+                    }
                 }
             }
         }

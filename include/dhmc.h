@@ -443,9 +443,11 @@ uint64_t dhmc_workspace_bytes(const dhmc_ctx* ctx);
 
 /* ---- self-test of the numerical contract: the scalar functions of dhmc_detmath.h evaluated on the device ----
  * kind: 0 exp, 1 log, 2 log1p (x >= 0), 3 sin(2πx), 4 cos(2πx), 5 randexp (x = 64 random bits as a double's bit pattern),
- * 6 / 7 the two normals of randn2 (x, y = 2 × 64 random bits), 8 logaddexp(x, y), 9 x^y (x > 0);  policy: how the kernels
- * place operands — 0 the header as compiled for the device, 1 per-lane arguments, 2 wave-uniform arguments (scalar loads,
- * scalar-register coefficients).  Host arrays of n values (y may be null where unused).  Every policy must return the bits
+ * 6 / 7 the two normals of randn2 (x, y = 2 × 64 random bits), 8 logaddexp(x, y), 9 x^y (x > 0), 10 / 11 the logistic family's
+ * link σ(x) and log(1 + e^x) (det_logistic_sigma, det_log1pexp);  policy: how the kernels
+ * place operands — 0 the header as compiled for the device, 1 per-lane arguments (kinds 10 / 11: the logistic round engine's own
+ * batched evaluation, both quotients from one reciprocal), 2 wave-uniform arguments (scalar loads,
+ * scalar-register coefficients; not for kinds 10 / 11).  Host arrays of n values (y may be null where unused).  Every policy must return the bits
  * the CPU side of the same header returns: a caller that builds its own host code against dhmc_detmath.h can check its
  * compiler / flags against the device with this. */
 int dhmc_detmath_selftest(int32_t device, int32_t kind, int32_t policy, int64_t n, const double* x, const double* y, double* out);

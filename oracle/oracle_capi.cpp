@@ -326,7 +326,8 @@ void oracle_unit_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out)
     auto r = philox4x32_10({ctr[0], ctr[1], ctr[2], ctr[3]}, {key[0], key[1]});
     for (int i = 0; i < 4; ++i) out[i] = r[i];
 }
-// kind: 0 exp, 1 log, 2 log1p_nonneg, 3 sin2pi, 4 cos2pi, 5 randexp(bits), 6 randn z0 (x bits as r1, y bits as r2), 7 randn z1
+// kind: 0 exp, 1 log, 2 log1p_nonneg, 3 sin2pi, 4 cos2pi, 5 randexp(bits), 6 randn z0 (x bits as r1, y bits as r2), 7 randn z1,
+// 8 logaddexp, 9 pow, 10 / 11 the logistic link's σ(x) and log(1 + e^x) (targets.hpp LogisticTarget computes exactly these)
 void oracle_unit_detmath(int kind, int64_t n, const double* x, const double* y, double* out) {
     for (int64_t i = 0; i < n; ++i) {
         double s, c;
@@ -342,6 +343,8 @@ void oracle_unit_detmath(int kind, int64_t n, const double* x, const double* y, 
         case 7: dhmc::det_randn2(r1, r2, &s, &c); out[i] = c; break;
         case 8: out[i] = dhmc::det_logaddexp(x[i], y[i]); break;
         case 9: out[i] = dhmc::det_pow_pos(x[i], y[i]); break;
+        case 10: out[i] = dhmc::det_logistic_sigma(x[i]); break;
+        case 11: out[i] = dhmc::det_log1pexp(x[i]); break;
         default: out[i] = NAN;
         }
     }

@@ -56,6 +56,24 @@ def test_log1p_and_logaddexp():
     assert np.array_equal(got, ol.detmath(8, y, x))
 
 
+def test_logistic_link_is_exp_division_and_log1p():
+    """det_logistic_sigma / det_log1pexp (the logistic family's link; what oracle/targets.hpp LogisticTarget computes observation by
+    observation, and what the kernels must reproduce from one shared reciprocal) are t = exp(-|η|), ONE IEEE division and log1p(t)."""
+    eta = np.concatenate([RNG.normal(0, 3, 100000), RNG.uniform(-760, 760, 100000), [0.0, -0.0, 36.8, -36.8, 707.0, -707.0, np.inf, -np.inf]])
+    t = ol.detmath(0, -np.abs(eta))
+    with np.errstate(over="ignore"):
+        sig = np.where(eta >= 0, 1.0 / (1.0 + t), t / (1.0 + t))
+        l1pe = np.where(eta > 0, eta, 0.0) + ol.detmath(2, t)
+    assert np.array_equal(ol.detmath(10, eta), sig)
+    assert np.array_equal(ol.detmath(11, eta), l1pe)
+    assert np.isnan(ol.detmath(10, [np.nan])[0]) and np.isnan(ol.detmath(11, [np.nan])[0])
+    fin = np.isfinite(eta)
+    from scipy.special import expit
+    mid = np.abs(eta) < 700                      # (beyond: subnormal results, where an ulp is not a relative measure)
+    assert ulp_err(sig[mid], expit(eta[mid])).max() <= 4.0      # (expit itself is not correctly rounded)
+    assert np.abs(l1pe[fin] - np.logaddexp(0.0, eta[fin])).max() <= 2 * np.spacing(760.0)
+
+
 def test_sincos2pi():
     a = np.concatenate([RNG.uniform(0, 1, 300000), [0.0, 0.25, 0.5, 0.75, 0.125, 1 - 2.0**-53]])
     s, c = ol.detmath(3, a), ol.detmath(4, a)

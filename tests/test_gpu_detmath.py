@@ -88,6 +88,36 @@ def test_device_scalar_math_equals_the_cpu_side_bit_for_bit(kind):
                                f" y={None if y is None else y[sl][bad[0]]!r} device={got[bad[0]]!r} cpu={w[bad[0]]!r}")
 
 
+def _link_inputs(n):
+    """η for the logistic link: whole waves (128 consecutive values: two per lane) of ordinary arguments first — they take the batched common
+    path, one reciprocal for both quotients —, among them |η| > 36.74 (1 + e^{-|η|} == 1), exact zeros (the padding observations: w == 2)
+    and the last arguments before the rare path; then waves that mix in |η| > 707, infinities and NaN (whole-wave rare path)."""
+    inf, nan = np.inf, np.nan
+    n = (n // 128) * 128
+    common = np.concatenate([RNG.normal(0, 3, n), RNG.uniform(-40, 40, n), RNG.uniform(-707, 707, n), RNG.normal(0, 1e-8, n),
+                             np.repeat([0.0, -0.0, 707.0, -707.0, 36.7, -36.8, 1e-300, -1e-300], 16),
+                             np.ldexp(RNG.uniform(0.5, 1, n), RNG.integers(-60, 10, n)) * RNG.choice([-1.0, 1.0], n)])
+    assert common.size % 128 == 0 and np.all(np.abs(common) <= 707.0)
+    rare = np.concatenate([RNG.uniform(-760, 760, n), RNG.normal(0, 3, 100),
+                           [707.0000000000001, -707.0000000000001, 708.4, -708.4, 745.2, -745.2, 745.3, -746.0, 800.0, -800.0, inf, -inf, nan, 0.0, 5e-324]])
+    return np.concatenate([common, rare])
+
+
+@pytest.mark.parametrize("kind", [10, 11])
+def test_logistic_link_equals_the_cpu_side_bit_for_bit(kind):
+    """σ(η) and log(1 + e^η) of the logistic family as the round engine evaluates them (policy 1: logistic_link_batch) and as the
+    wave-per-chain functor does (policy 0: the header's functions), against the CPU side's IEEE divisions."""
+    pkg = load_package()
+    x = _link_inputs(40960)
+    want = ol.detmath(kind, x)
+    for policy in (0, 1):
+        got = _dev(pkg, kind, policy, x)
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        bad = np.flatnonzero(~same)
+        assert bad.size == 0, (f"kind {kind}, policy {POLICIES[policy]}: {bad.size} of {want.size} differ, first η={x[bad[0]]!r}"
+                               f" device={got[bad[0]]!r} cpu={want[bad[0]]!r}")
+
+
 def test_selftest_rejects_bad_arguments():
     pkg = load_package()
     L = pkg.abi.lib()
@@ -97,3 +127,4 @@ def test_selftest_rejects_bad_arguments():
     assert L.dhmc_detmath_selftest(0, 0, 7, C.c_int64(4), p, None, p) == 1
     assert L.dhmc_detmath_selftest(0, 8, 0, C.c_int64(4), p, None, p) == 1     # logaddexp needs y
     assert L.dhmc_detmath_selftest(0, 0, 0, C.c_int64(0), p, None, p) == 1
+    assert L.dhmc_detmath_selftest(0, 10, 2, C.c_int64(4), p, None, p) == 1    # the link has no wave-uniform form
