@@ -24,6 +24,7 @@
 namespace dhmc {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double gemm_d2s __attribute__((ext_vector_type(2)));
 
 // one DPP-rotated copy of a double inside each row of 16 lanes (two 32-bit DPP movs; every lane has a source)
 template <int CTRL>
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w / WT, wc = w % WT;
 
-    __shared__ double As[TK * LS];   // As[k][row]
-    __shared__ double Bs[TK * LS];   // Bs[k][col]
+    __shared__ __attribute__((aligned(16))) double As[TK * LS];   // As[k][row] (ROT: column (row + 8 (k >> 2)) mod TM)
+    __shared__ __attribute__((aligned(16))) double Bs[TK * LS];   // Bs[k][col]
 
     // global -> LDS assignment: A tile TM×TK and B tile TK×TN, (TM*TK)/NT doubles per thread each
     constexpr int PER = (TM * TK) / NT;
@@ -75,6 +76,12 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
         OUT += (size_t)blockIdx.z * zstride;
     }
     const double* a_src = A + (size_t)a_grow * lda + kbeg + a_k;
+    // LDS column of the thread's A row.  A write instruction covers, per group of 16 lanes, 4 rows × the 4 k-groups a_k = 0, 4, 8, 12 — with
+    // As[k][row] as it stands all four k-groups fall on the same banks (the k stride is a multiple of 64 dwords): a 4-way conflict on every
+    // store of the transposition.  ROT rotates the columns of k-group g by 8 g (mod TM): the four groups land on four bank ranges, the
+    // fragment reads of a step (one k-group) see the same uniform rotation.  (round 6: +4-6 % on the engines' shapes, same bits)
+    constexpr bool ROT = !BLK && PER == 4 && TM == 64;
+    const int a_col = ROT ? ((a_row + 2 * a_k) & (TM - 1)) : a_row;
     constexpr int B_TPR = TN / PER;                     // threads per B row (one k)
     const int b_k = t / B_TPR, b_c = (t % B_TPR) * PER;
     const double* b_src = B + (size_t)(kbeg + b_k) * ldb + col0 + b_c;
@@ -94,9 +101,13 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
     for (int k0 = 0; k0 < K; k0 += TK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            As[(a_k + i) * LS + a_row] = av[i];
-            Bs[b_k * LS + b_c + i] = bv[i];
+        for (int i = 0; i < PER; ++i) As[(a_k + i) * LS + a_col] = av[i];
+        if constexpr (PER % 2 == 0) {                      // the B row's PER consecutive doubles as 16-byte stores
+#pragma unroll
+            for (int i = 0; i < PER; i += 2) *reinterpret_cast<gemm_d2s*>(&Bs[b_k * LS + b_c + i]) = gemm_d2s{bv[i], bv[i + 1]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) Bs[b_k * LS + b_c + i] = bv[i];
         }
         __syncthreads();
         if (k0 + TK < K) {
@@ -113,7 +124,8 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
                 double a[FR], b[FR];
 #pragma unroll
                 for (int i = 0; i < FR; ++i) {
-                    a[i] = As[kr + wr * WS + 16 * i + (lane & 15)];
+                    const int ac = wr * WS + 16 * i + (lane & 15);
+                    a[i] = As[kr + (ROT ? ((ac + 2 * kk) & (TM - 1)) : ac)];          // 8 (k >> 2) = 2 kk for the step's four k
                     b[i] = Bs[kr + wc * WS + 16 * i + (lane & 15)];
                 }
 #pragma unroll
