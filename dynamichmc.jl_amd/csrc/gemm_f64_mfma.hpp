@@ -94,29 +94,38 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
 #pragma unroll
         for (int j = 0; j < FR; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 
-    // software pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied
-    double av[PER], bv[PER];
+    // software pipeline: the global loads of K-tiles t+1 … t+PD are in flight while tile t is multiplied (a ring of PD register sets, the
+    // k-loop unrolled by PD with no branch inside the unrolled body, so that the compiler's s_waitcnt placement keeps them in flight).
+    // PD = 2 for the 64×64 tile: +6-8 % over one tile on the engines' shapes, most of it at the launch's ramp (profiles/r06_gemm_lds_rotation.txt §5)
+#ifndef DHMC_GEMM_PD
+#define DHMC_GEMM_PD 2
+#endif
+    constexpr int PD = (PER <= 4) ? DHMC_GEMM_PD : 1;
+    const int nt = K / TK;
+    double av[PD][PER], bv[PD][PER];
+    auto issue = [&](int tile, double (&a)[PER], double (&b)[PER]) {
+        const int tt = tile < nt ? tile : (nt > 0 ? nt - 1 : 0);   // past the end: the last tile once more (never staged)
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { av[i] = a_src[i]; bv[i] = b_src[i]; }
-    for (int k0 = 0; k0 < K; k0 += TK) {
+        for (int i = 0; i < PER; ++i) {
+            a[i] = a_src[tt * TK + i];
+            b[i] = b_src[(size_t)(tt * TK) * ldb + i];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) issue(s, av[s], bv[s]);
+    auto step = [&](int tile, int s) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int i = 0; i < PER; ++i) As[(a_k + i) * LS + a_col] = av[i];
+        for (int i = 0; i < PER; ++i) As[(a_k + i) * LS + a_col] = av[s][i];
         if constexpr (PER % 2 == 0) {                      // the B row's PER consecutive doubles as 16-byte stores
 #pragma unroll
-            for (int i = 0; i < PER; i += 2) *reinterpret_cast<gemm_d2s*>(&Bs[b_k * LS + b_c + i]) = gemm_d2s{bv[i], bv[i + 1]};
+            for (int i = 0; i < PER; i += 2) *reinterpret_cast<gemm_d2s*>(&Bs[b_k * LS + b_c + i]) = gemm_d2s{bv[s][i], bv[s][i + 1]};
         } else {
 #pragma unroll
-            for (int i = 0; i < PER; ++i) Bs[b_k * LS + b_c + i] = bv[i];
+            for (int i = 0; i < PER; ++i) Bs[b_k * LS + b_c + i] = bv[s][i];
         }
         __syncthreads();
-        if (k0 + TK < K) {
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                av[i] = a_src[k0 + TK + i];
-                bv[i] = b_src[(size_t)(k0 + TK) * ldb + i];
-            }
-        }
+        issue(tile + PD, av[s], bv[s]);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 4) {
             const int kr = (kk + (lane >> 4)) * LS;
@@ -157,7 +166,15 @@ __global__ __launch_bounds__(64 * WT * WT) void gemm_rows_f64_kernel(const doubl
                             acc[i][j][uv] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][uv >> 1], b[j][uv & 1], acc[i][j][uv], 0, 0, 0);
             }
         }
+    };
+    const int nfull = nt - nt % PD;
+    for (int t0 = 0; t0 < nfull; t0 += PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) step(t0 + s, s);
     }
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (nfull + s < nt) step(nfull + s, s);            // uniform
     if constexpr (!BLK) {
         // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
