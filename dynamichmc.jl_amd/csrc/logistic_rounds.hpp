@@ -186,6 +186,13 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 
     bload(0, 0);
     int buf = 0;
+#ifdef DHMC_LK_CLOCKS      // timing build (tools/gpu_scripts/r6b/l_c5_clocks.sh): where a wave's clocks go — wait for the staged loads, barrier, products, link
+    unsigned long long ck_load = 0, ck_bar = 0, ck_mfma = 0, ck_link = 0;
+    const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();
+#define LK_CK(acc_, t_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - t_; t_ = now_; }
+#else
+#define LK_CK(acc_, t_)
+#endif
 #pragma nounroll
     for (int m = 0; m < nm; ++m) {
         mfma_d4 acc[2];
@@ -198,9 +205,15 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
         for (int st = 0; st < NST; ++st) {
             double* bs = Bs[buf];
             gemm_d2* bw = reinterpret_cast<gemm_d2*>(bs + b_k * LK_LS + b_c);
+#ifdef DHMC_LK_CLOCKS
+            unsigned long long ck_t = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LK_CK(ck_load, ck_t)
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
             __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
+            LK_CK(ck_bar, ck_t)
             {                                        // the next stage's loads fly under this stage's 32 products
                 int st1 = st + 1, m1 = m;
                 if (st1 == NST) { st1 = 0; m1 = m + 1; }
@@ -214,7 +227,14 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b1, acc[1], 0, 0, 0);
             }
             buf ^= 1;
+#ifdef DHMC_LK_CLOCKS
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            LK_CK(ck_mfma, ck_t)
+#endif
         }
+#ifdef DHMC_LK_CLOCKS
+        unsigned long long ck_t2 = __builtin_amdgcn_s_memtime();
+#endif
         // the link of the lane's 8 elements (logistic_link_kernel's operations, in phases; four at a time: the A-fragments hold half
         // the wave's registers)
         const bool whole = nb + (int64_t)WAVE * (m + 1) <= N;                     // no padding observation in this group (uniform)
@@ -229,6 +249,16 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
                 for (int r = 0; r < LK_NE; ++r) eta[r] = acc[j][LK_NE * h + r];
                 logistic_link_batch<LK_NE>(eta, sig, l1pe);
+#if defined(DHMC_LK_ABLATE) && DHMC_LK_ABLATE == 1          // timing build: the link twice, same results (tools/gpu_scripts/r6b/k_c5_ablate.sh)
+                {
+                    double eta2[LK_NE], sig2[LK_NE], l2[LK_NE];
+#pragma unroll
+                    for (int r = 0; r < LK_NE; ++r) { eta2[r] = eta[r]; asm volatile("" : "+v"(eta2[r])); }
+                    logistic_link_batch<LK_NE>(eta2, sig2, l2);
+#pragma unroll
+                    for (int r = 0; r < LK_NE; ++r) asm volatile("" :: "v"(sig2[r]), "v"(l2[r]));
+                }
+#endif
                 if (whole) {                                                       // every group but the data's last: no per-lane tests
 #pragma unroll
                     for (int r = 0; r < LK_NE; ++r) {
@@ -244,7 +274,20 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
                 }
             }
         }
+#ifdef DHMC_LK_CLOCKS
+        LK_CK(ck_link, ck_t2)
+#endif
     }
+#ifdef DHMC_LK_CLOCKS
+    {
+        __shared__ int dummy_;
+        static __device__ int printed_;
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - ck_begin;
+        if (count >= 1024 && lane == 0 && (blockIdx.x % 397) == 5 && atomicAdd(&printed_, 1) < 24)
+            printf("LKCLK block %d wave %d groups %d total %llu load-wait %llu barrier %llu products %llu link %llu\n", (int)blockIdx.x, wv, nm, total, ck_load, ck_bar, ck_mfma, ck_link);
+        (void)dummy_;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll

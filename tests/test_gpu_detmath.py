@@ -96,6 +96,8 @@ def _link_inputs(n):
     n = (n // 128) * 128
     common = np.concatenate([RNG.normal(0, 3, n), RNG.uniform(-40, 40, n), RNG.uniform(-707, 707, n), RNG.normal(0, 1e-8, n),
                              np.repeat([0.0, -0.0, 707.0, -707.0, 36.7, -36.8, 1e-300, -1e-300], 16),
+                             np.repeat([2.0**-52, -2.0**-52, 2.0**-53, 1.5 * 2.0**-53, -3e-16, 2.5e-16, 1e-15, -1e-15], 16),   # 1 + e^{-|η|} rounds to 2 or just below
+                             RNG.uniform(-1e-15, 1e-15, n),
                              np.ldexp(RNG.uniform(0.5, 1, n), RNG.integers(-60, 10, n)) * RNG.choice([-1.0, 1.0], n)])
     assert common.size % 128 == 0 and np.all(np.abs(common) <= 707.0)
     rare = np.concatenate([RNG.uniform(-760, 760, n), RNG.normal(0, 3, 100),

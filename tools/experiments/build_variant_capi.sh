@@ -8,7 +8,7 @@ NAME=$1; shift
 D=$ROOT/tools/experiments/_v/$NAME
 mkdir -p $D
 OBJ=$ROOT/dynamichmc.jl_amd/lib/obj
-FLAGS="-O3 -std=c++17 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wno-unused-result"
+FLAGS="-O3 -std=c++17 -ffp-contract=off -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-result"
 (cd $ROOT/dynamichmc.jl_amd/csrc && /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $D/dhmc_capi.o dhmc_capi.hip && /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $D/capi_run.o capi_run.hip)
 OTHERS=$(ls $OBJ/*.o | grep -v "dhmc_capi.o\|capi_run.o")
 /opt/rocm/bin/hipcc $FLAGS -shared -o $D/libdhmc_amd.so $OTHERS $D/dhmc_capi.o $D/capi_run.o -lhiprtc
