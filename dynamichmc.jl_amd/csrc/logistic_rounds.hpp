@@ -212,13 +212,13 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
-            __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
-            LK_CK(ck_bar, ck_t)
-            {                                        // the next stage's loads fly under this stage's 32 products
-                int st1 = st + 1, m1 = m;
+            {                                        // the next stage's loads fly under the barrier's wait and this stage's 32 products
+                int st1 = st + 1, m1 = m;            // (issued BEFORE the barrier: they go to registers, and the wait for the slowest wave is theirs too)
                 if (st1 == NST) { st1 = 0; m1 = m + 1; }
                 if (m1 < nm) bload(m1, st1);
             }
+            __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
+            LK_CK(ck_bar, ck_t)
 #pragma unroll
             for (int kk = 0; kk < LK_TK / 4; ++kk) {
                 const double b0 = bs[4 * kk * LK_LS + b_rd];
