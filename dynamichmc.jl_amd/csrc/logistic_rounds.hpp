@@ -129,11 +129,18 @@ static __global__ __launch_bounds__(64) void logistic_link_kernel(RunParams P, R
 #define DHMC_LK_NE 2
 #endif
 constexpr int LK_NE = DHMC_LK_NE;                              // arguments of the link in flight together (of a lane's 4 per accumulator)
-constexpr int LK_TL = 32, LK_TK = 64, LK_LS = LK_TL + 16;     // columns per workgroup, k per LDS stage, LDS row stride (doubles)
+// columns per workgroup; k per HALF stage (what one batch of loads / LDS stores covers: 64 k × 32 columns = 8 doubles per thread).  An LDS stage
+// is two halves — 128 k under ONE barrier (Dpad = 64: one half) — and the row of k holds its 32 columns with bit 4 of the column flipped for odd
+// k (k and k + 1 of a fragment read land on opposite bank halves: no padding, 64 KB for the two buffers, two workgroups per CU)
+constexpr int LK_TL = 32, LK_TK = 64;
 
 template <int DP>                                              // DP = Dpad (64, 128 or 256): the A-fragments are DP / 4 registers
 __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, LogisticRound L, const double* __restrict__ Q, int ntile_rows) {
-    constexpr int KS = DP / 4, NST = DP / LK_TK;
+    constexpr int KS = DP / 4;
+    constexpr int NH = DP / LK_TK;                             // half stages per group of observations: 1, 2, 4
+    constexpr int HPS = NH >= 2 ? 2 : 1;                       // halves per LDS stage
+    constexpr int NST = NH / HPS;                              // stages (barriers) per group: 1, 1, 2
+    constexpr int SROWS = HPS * LK_TK;                         // k rows per stage
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int rt = sq % ntile_rows, grp = (sq / ntile_rows) * 8 + xcd;           // grp = 2 z + lh
     const int z = grp >> 1, lh = grp & 1;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int l0 = LK_TL * lh;
 
-    __shared__ double Bs[2][LK_TK * LK_LS];
+    __shared__ __attribute__((aligned(16))) double Bs[2][SROWS * LK_TL];
 
     // A-fragments: lane (r16, kk) holds Q′[row r16 of the wave's 16][4 ks + kk], ks = 0 .. KS-1
     int arow = row0 + 16 * wv + (lane & 15);
@@ -158,16 +165,26 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = ap[4 * ks];
 
-    // B stage (64 k × 32 columns): thread t -> k row t / 4, the 8 columns from 8 (t % 4) — 64 contiguous bytes of Xᵀ's row
+    // a half stage (64 k × 32 columns): thread t -> k row t / 4 of the half, the 8 columns from 8 (t % 4) — 64 contiguous bytes of Xᵀ's row
     const int b_k = t >> 2, b_c = 8 * (t & 3);
-    const double* __restrict__ bsrc = P.tp.b + (size_t)b_k * Npad + nb + l0 + b_c;   // + 64 m + (size_t)64 st Npad
+    const double* __restrict__ bsrc = P.tp.b + (size_t)b_k * Npad + nb + l0 + b_c;   // + 64 m + (size_t)64 hs Npad
+    const int b_wr = b_k * LK_TL + (b_c ^ (16 * (b_k & 1)));                        // (64 is even: the half's first row has the parity of 0)
     double bv[8];
-    auto bload = [&](int m, int st) {
-        const gemm_d2* s2 = reinterpret_cast<const gemm_d2*>(bsrc + (size_t)(LK_TK * st) * Npad + WAVE * m);
+    auto bload = [&](int m, int hs) {                                               // half stage hs = 0 .. NH-1 of group m
+        const gemm_d2* s2 = reinterpret_cast<const gemm_d2*>(bsrc + (size_t)(LK_TK * hs) * Npad + WAVE * m);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const gemm_d2 v = s2[i]; bv[2 * i] = v[0]; bv[2 * i + 1] = v[1]; }
     };
-    const int b_rd = (lane >> 4) * LK_LS + (lane & 15);
+    auto bstore = [&](double* bs, int half) {
+        gemm_d2* bw = reinterpret_cast<gemm_d2*>(bs + half * (LK_TK * LK_TL) + b_wr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
+    };
+    auto next_half = [&](int m, int hs, int& m1, int& hs1) { hs1 = hs + 1; m1 = m; if (hs1 == NH) { hs1 = 0; m1 = m + 1; } };
+    // fragment reads: lane (c16, g) reads row 4 kk + g, columns c16 (b0) and 16 + c16 (b1), bit 4 flipped for odd rows (g odd)
+    const int g = lane >> 4;
+    const int b_rd0 = g * LK_TL + ((lane & 15) ^ (16 * (g & 1)));
+    const int b_rd1 = g * LK_TL + ((16 + (lane & 15)) ^ (16 * (g & 1)));
 
     mfma_d4 lp[2];                                   // the running partial sums of the lane's 8 (chain, l) pairs
     lp[0] = mfma_d4{0.0, 0.0, 0.0, 0.0};
@@ -179,13 +196,20 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int lr = row0 + 16 * wv + (lane >> 4) + 4 * r;
-        const int g = L.act[lr < count ? lr : count - 1];
-        hrow[r] = L.H + (size_t)g * Npad + nb + l0 + (lane & 15);
-        srow[r] = g - P.chain_base;
+        const int gg = L.act[lr < count ? lr : count - 1];
+        hrow[r] = L.H + (size_t)gg * Npad + nb + l0 + (lane & 15);
+        srow[r] = gg - P.chain_base;
     }
 
-    bload(0, 0);
+    // Pipeline of half stages.  Entering stage (m, st), bv holds the LAST half of that stage; its earlier half (HPS = 2) was stored into the
+    // stage's buffer in the middle of the stage before.  One barrier per stage: it publishes both halves and says that every wave is done
+    // with the other buffer, which then receives the next stage's first half in the middle of this one.
     int buf = 0;
+    bload(0, 0);
+    if constexpr (HPS == 2) {
+        bstore(Bs[0], 0);
+        bload(0, 1);
+    }
 #ifdef DHMC_LK_CLOCKS      // timing build (tools/gpu_scripts/r6b/l_c5_clocks.sh): where a wave's clocks go — wait for the staged loads, barrier, products, link
     unsigned long long ck_load = 0, ck_bar = 0, ck_mfma = 0, ck_link = 0;
     const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();
@@ -204,27 +228,37 @@ __global__ __launch_bounds__(256, 2) void logistic_eta_link_kernel(RunParams P, 
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             double* bs = Bs[buf];
-            gemm_d2* bw = reinterpret_cast<gemm_d2*>(bs + b_k * LK_LS + b_c);
+            const int hs_last = HPS * st + HPS - 1;                                 // the half bv holds
 #ifdef DHMC_LK_CLOCKS
             unsigned long long ck_t = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LK_CK(ck_load, ck_t)
 #endif
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bw[i] = gemm_d2{bv[2 * i], bv[2 * i + 1]};
-            {                                        // the next stage's loads fly under the barrier's wait and this stage's 32 products
-                int st1 = st + 1, m1 = m;            // (issued BEFORE the barrier: they go to registers, and the wait for the slowest wave is theirs too)
-                if (st1 == NST) { st1 = 0; m1 = m + 1; }
-                if (m1 < nm) bload(m1, st1);
-            }
+            bstore(bs, HPS - 1);
+            int m1, hs1;
+            next_half(m, hs_last, m1, hs1);
+            if (m1 < nm) bload(m1, hs1);             // the next stage's first half: in flight under the barrier's wait and this stage's first products
             __syncthreads();                         // stage visible; every wave is done with the other buffer's previous contents
             LK_CK(ck_bar, ck_t)
 #pragma unroll
-            for (int kk = 0; kk < LK_TK / 4; ++kk) {
-                const double b0 = bs[4 * kk * LK_LS + b_rd];
-                const double b1 = bs[4 * kk * LK_LS + b_rd + 16];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(LK_TK / 4) * st + kk], b1, acc[1], 0, 0, 0);
+            for (int hh = 0; hh < HPS; ++hh) {
+#pragma unroll
+                for (int kk = 0; kk < LK_TK / 4; ++kk) {
+                    const int kr = (hh * LK_TK + 4 * kk) * LK_TL;
+                    const double b0 = bs[kr + b_rd0];
+                    const double b1 = bs[kr + b_rd1];
+                    const int ka = (SROWS / 4) * st + (LK_TK / 4) * hh + kk;
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ka], b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ka], b1, acc[1], 0, 0, 0);
+                }
+                if (HPS == 2 && hh == 0) {           // middle of the stage: the next stage's first half into the other buffer, its last half requested
+                    if (m1 < nm) {
+                        bstore(Bs[buf ^ 1], 0);
+                        int m2, hs2;
+                        next_half(m1, hs1, m2, hs2);
+                        bload(m2, hs2);              // (m2 == m1: a stage's two halves belong to one group)
+                    }
+                }
             }
             buf ^= 1;
 #ifdef DHMC_LK_CLOCKS
