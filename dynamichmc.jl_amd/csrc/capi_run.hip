@@ -387,7 +387,7 @@ int run_logistic_rounds(RunCall& r) {
             e = hipMemsetAsync(c->rb.list_count, 0, sizeof(int), c->stream);
             launch_logistic_op(1, c->NPL, ra, c->lr, c->stream);                                   // q′
             launch_logistic_op(4, c->NPL, ra, c->lr, c->stream);                                   // the rows of this round
-            launch_logistic_eta_link(ra.P, ra.R, c->lr, c->st.q, C, c->stream);                    // η = Q′·Xᵀ, r, S₁ (one kernel)
+            launch_logistic_eta_link(ra.P, ra.R, c->lr, c->st.q, C, c->stream, /*sums_kernel=*/false);                    // η = Q′·Xᵀ, r, S₁ (one kernel)
             launch_gemm_splitk(c->lr.H, npad, c->tp.a, ld, c->lr.P, ld, (size_t)C * ld, C, npad, ld, DHMC_LOGISTIC_BLOCK,
                                c->lr.act, c->lr.act_count, c->stream);                             // Xᵀr = R·X, block by block
             launch_logistic_op(3, c->NPL, ra, c->lr, c->stream);                                   // ∇ℓ, ℓ, p′, p♯

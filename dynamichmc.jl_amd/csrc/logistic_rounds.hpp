@@ -337,17 +337,24 @@ static __global__ __launch_bounds__(64) void logistic_block_sums_kernel(RunParam
     if (lane == 0) L.S1P[o] = bs;
 }
 
-// η, the link and the blocks' sums of the rows listed in L.act: fused where the chain's row fits the A-fragments, else G_eta + K_r
-inline void launch_logistic_eta_link(const RunParams& P, const RoundBuffers& R, const LogisticRound& L, const double* Q, int C, hipStream_t s) {
+// does the fused η + link kernel serve this context?  (then the blocks' sums exist as 64 lane partials each: S1L)
+__host__ __device__ inline bool logistic_link_is_fused(const LogisticRound& L, int ld, int64_t npad) {
+    return L.S1L && (ld == 64 || ld == 128 || ld == 256) && npad % WAVE == 0;
+}
+
+// η, the link and the blocks' sums of the rows listed in L.act: fused where the chain's row fits the A-fragments, else G_eta + K_r.
+// sums_kernel = false: the caller's next kernel folds the lane partials S1L itself (rounds_k2_logistic_kernel); S1P is then not written.
+inline void launch_logistic_eta_link(const RunParams& P, const RoundBuffers& R, const LogisticRound& L, const double* Q, int C, hipStream_t s,
+                                     bool sums_kernel = true) {
     const int ld = P.Dpad, npad = (int)P.tp.npad;
-    if (L.S1L && (ld == 64 || ld == 128 || ld == 256) && npad % WAVE == 0) {
+    if (logistic_link_is_fused(L, ld, P.tp.npad)) {
         const int ntr = (C + 63) / 64;
         const int ngrp = 2 * L.nz;
         const dim3 grid((unsigned)(8 * ntr * ((ngrp + 7) / 8)));
         if (ld == 256) hipLaunchKernelGGL((logistic_eta_link_kernel<256>), grid, dim3(256), 0, s, P, L, Q, ntr);
         else if (ld == 128) hipLaunchKernelGGL((logistic_eta_link_kernel<128>), grid, dim3(256), 0, s, P, L, Q, ntr);
         else hipLaunchKernelGGL((logistic_eta_link_kernel<64>), grid, dim3(256), 0, s, P, L, Q, ntr);
-        hipLaunchKernelGGL(logistic_block_sums_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, s, P, L);
+        if (sums_kernel) hipLaunchKernelGGL(logistic_block_sums_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, s, P, L);
     } else {
         launch_gemm_list(Q, ld, P.tp.b, npad, L.H, npad, C, ld, npad, L.act, L.act_count, s);          // η = Q′·Xᵀ
         hipLaunchKernelGGL(logistic_link_kernel, dim3((unsigned)L.nz, C), dim3(WAVE), 0, s, P, R, L);   // r, the blocks' sums
@@ -389,8 +396,21 @@ __global__ __launch_bounds__(64) void rounds_k2_logistic_kernel(RunParams P, Rou
         qq.add(0, k, q[k], q[k]);
         g[k] = g[k] - q[k];
     }
-    double s1 = 0.0;                                      // the blocks' sums, added in ascending order: lane z fetches block z's
-    for (int z0 = 0; z0 < L.nz; z0 += WAVE) {
+    double s1 = 0.0;                                      // the blocks' sums, added in ascending order
+    if (logistic_link_is_fused(L, P.Dpad, P.tp.npad)) {   // … each the butterfly of its 64 lane partials (what logistic_block_sums_kernel computes),
+        constexpr int ZB = 8;                             //     eight blocks' butterflies side by side
+        const double* __restrict__ sl = L.S1L + (size_t)(chain - P.chain_base) * WAVE + lane;
+        for (int z0 = 0; z0 < L.nz; z0 += ZB) {
+            double v[ZB];
+#pragma unroll
+            for (int u = 0; u < ZB; ++u) v[u] = z0 + u < L.nz ? sl[(size_t)(z0 + u) * P.C * WAVE] : 0.0;
+            wave_allreduce<ZB>(v);
+#pragma unroll
+            for (int u = 0; u < ZB; ++u)
+                if (z0 + u < L.nz) s1 = (z0 + u == 0) ? v[u] : s1 + v[u];
+        }
+    } else
+    for (int z0 = 0; z0 < L.nz; z0 += WAVE) {             //     … lane z fetches block z's
         const int zl = z0 + lane;
         const double v = zl < L.nz ? L.S1P[(size_t)zl * P.C + (chain - P.chain_base)] : 0.0;
         const int cnt = (L.nz - z0) < WAVE ? (L.nz - z0) : WAVE;
