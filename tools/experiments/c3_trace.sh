@@ -14,7 +14,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-4000:]
 t0 = int(rows[0]["Start_Timestamp"])
 with open(sys.argv[2] + "/timeline.txt", "w") as o:
-    for r in rows[-400:]:
+    for r in rows[-1300:-700]:
         o.write("%10.1f %10.1f q=%s %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                         r.get("Queue_Id", "?"), r["Kernel_Name"][:60]))
 span = int(rows[-1]["End_Timestamp"]) - t0
