@@ -124,6 +124,65 @@ static void run(const char* name, int M, int K, int N, const double* A, const do
     printf("  %-28s alone %7.3f ms (%5.1f TFLOP/s)   beside the stream %7.3f ms (%5.1f)   [stream alone %6.3f ms = %4.2f TB/s, with 4 products inside %6.3f ms; stream start -> first product's end %6.3f, -> fourth product's end %6.3f ms]\n", name, alone,
            2.0 * M * K * N / alone / 1e9, beside, 2.0 * M * K * N / beside / 1e9, hog_alone, 16.0 * hn / hog_alone / 1e9, hog_ms, first_ms, span_ms);
 }
+
+// a neighbour shaped like the tree kernel: 2048 short-lived workgroups of 256 threads, ~100 VGPRs (40 doubles held per thread), 13 KB of LDS, each
+// streaming ~140 KB (17 rows of 8 KB in, 8 out) with two barriers
+__global__ __launch_bounds__(256) void treeish(const double* __restrict__ in, double* __restrict__ out) {
+    __shared__ double xch[6][4][64];
+    const size_t base = (size_t)blockIdx.x * 17 * 1024;
+    double v[17][4];
+#pragma unroll
+    for (int r = 0; r < 17; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[r][k] = in[base + r * 1024 + threadIdx.x + 256 * k];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[r % 6] = __builtin_fma(v[r][k], v[r + 1][k], acc[r % 6]);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) xch[n][threadIdx.x >> 6][threadIdx.x & 63] = acc[n];
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += xch[n][w][threadIdx.x & 63];
+    __syncthreads();
+    const size_t ob = (size_t)blockIdx.x * 8 * 1024;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[ob + r * 1024 + threadIdx.x + 256 * k] = v[r][k] + v[r + 8][k] + t;
+}
+
+static void tree_run(const char* name, int M, int K, int N, const double* A, const double* B, double* O, const double* hin, double* hout, hipStream_t sg, hipStream_t st) {
+    hipEvent_t e[8], h0, h1; for (auto& x : e) (void)hipEventCreate(&x); (void)hipEventCreate(&h0); (void)hipEventCreate(&h1);
+    float g_alone = 1e9, t_alone = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e[0], sg); hipLaunchKernelGGL(gemm_pd<2>, dim3(N / 64, M / 64), dim3(256), 0, sg, A, K, B, N, O, N, K); (void)hipEventRecord(e[1], sg);
+        (void)hipEventSynchronize(e[1]); float ms; (void)hipEventElapsedTime(&ms, e[0], e[1]); g_alone = ms < g_alone ? ms : g_alone;
+        (void)hipEventRecord(h0, st); hipLaunchKernelGGL(treeish, dim3(2048), dim3(256), 0, st, hin, hout); (void)hipEventRecord(h1, st);
+        (void)hipEventSynchronize(h1); (void)hipEventElapsedTime(&ms, h0, h1); t_alone = ms < t_alone ? ms : t_alone;
+    }
+    // six tree-like launches back to back on one stream; three products on the other, the first enqueued once the neighbour is running
+    float best_span = 1e9, g_in[3] = {0, 0, 0}, t_total = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(h0, st);
+        for (int q = 0; q < 6; ++q) hipLaunchKernelGGL(treeish, dim3(2048), dim3(256), 0, st, hin, hout);
+        (void)hipEventRecord(h1, st);
+        (void)hipEventRecord(e[0], sg);
+        for (int q = 0; q < 3; ++q) { hipLaunchKernelGGL(gemm_pd<2>, dim3(N / 64, M / 64), dim3(256), 0, sg, A, K, B, N, O, N, K); (void)hipEventRecord(e[q + 1], sg); }
+        (void)hipDeviceSynchronize();
+        float span; (void)hipEventElapsedTime(&span, h0, e[3]);
+        float tt; (void)hipEventElapsedTime(&tt, h0, h1);
+        if (span < best_span) { best_span = span; t_total = tt; for (int q = 0; q < 3; ++q) (void)hipEventElapsedTime(&g_in[q], e[q], e[q + 1]); }
+    }
+    printf("  %-34s product alone %6.3f ms, tree-like launch alone %6.3f ms;  six tree-like launches with three products beside them: %6.3f ms, the products %6.3f / %6.3f / %6.3f ms, all done after %6.3f ms  (serial: %6.3f)\n",
+           name, g_alone, t_alone, t_total, g_in[0], g_in[1], g_in[2], best_span, 6 * t_alone + 3 * g_alone);
+}
+
 int main() {
     const int K = 1024, N = 1024, Mmax = 4096;
     std::vector<double> h((size_t)Mmax * K);
@@ -136,7 +195,16 @@ int main() {
     (void)hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), (size_t)K * N * 8, hipMemcpyHostToDevice);
     (void)hipMemset(hin, 0, hn * 8);
     hipStream_t s1, s2; (void)hipStreamCreate(&s1); (void)hipStreamCreate(&s2);
-    for (int hog_blocks : {256, 512, 1024, 2048}) {
+    {
+        int lo, hi; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipStream_t s_hi, s_lo; (void)hipStreamCreateWithPriority(&s_hi, hipStreamNonBlocking, hi); (void)hipStreamCreateWithPriority(&s_lo, hipStreamNonBlocking, lo);
+        printf("a neighbour shaped like the tree kernel (2048 short-lived workgroups per launch); stream priorities %d (low) .. %d (high)\n", lo, hi);
+        tree_run("both streams at default priority", 2048, K, N, A, B, O, hin, hout, s1, s2);
+        tree_run("products on a HIGH-priority stream", 2048, K, N, A, B, O, hin, hout, s_hi, s2);
+        tree_run("... and the neighbour on a LOW one", 2048, K, N, A, B, O, hin, hout, s_hi, s_lo);
+        tree_run("both streams at default priority", 2048, K, N, A, B, O, hin, hout, s1, s2);
+    }
+    for (int hog_blocks : {512}) {
         for (int M : {2048}) {
             printf("M = %d, K = N = 1024, neighbour of %d blocks:\n", M, hog_blocks);
             run<1>("1 k-tile of loads in flight", M, K, N, A, B, O, hin, hout, hn, hog_blocks, s1, s2);
