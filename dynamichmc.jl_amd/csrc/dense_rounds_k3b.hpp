@@ -4,7 +4,8 @@
 //
 // Why: the one-wave-per-chain K3 needs the whole 512-register budget of a SIMD lane at NPL = 16 (one wave per SIMD),
 // so it can neither hide its HBM latency behind other waves nor share a CU with the other half-batch's GEMM.  This
-// form holds 5 × 4 doubles per lane (≈100 VGPRs), runs 4+ waves per SIMD and co-resides with the MFMA waves.
+// form holds 5 × 4 doubles per lane and co-resides with the MFMA waves.  (As compiled since K2 was fused in: 211 VGPRs, two waves per SIMD;
+// forcing three or four by launch bounds spills and is 8 / 15 % slower on config 3 — profiles/r06_gemm_lds_rotation.txt §9.)
 //
 // The bits do not change: the ABI's dot product (wave.hpp LaneAcc) is, per lane, one fma chain per 256-coordinate
 // block, the blocks' partial sums combined per lane by an adjacent-pairs tree, then the 64-lane butterfly — so every
